@@ -1,0 +1,573 @@
+"""CPU restatement of the katsdpimager imaging hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is the parity *oracle*: a plain numpy / C restatement of the
+reference's CPU ("Host") algorithms for the per-channel imaging path.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product package (``katsdpimager_amd``) never does.
+
+Parity status: PINNED.  Every function here is checked in
+``tests/test_oracle_golden.py`` against golden vectors in ``tests/golden/``
+that were produced by importing the reference itself in the build container
+(``tools/gen_golden.py``; the reference's third-party deps numba /
+katsdpsigproc / astropy are replaced by the stand-ins in
+``tools/oracle_shims``), plus the known-answer vectors of the reference's
+own unit tests (``tests/test_oracle_known_answers.py``).
+
+All ``file:line`` citations are relative to the reference checkout
+(ska-sa/katsdpimager @ 2024_10_08).
+"""
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+CLEAN_I = 0          # clean.py:29
+CLEAN_SUMSQ = 1      # clean.py:31
+MEDIAN_TO_RMS = 1.4826022185056031   # clean.py:34
+
+NATURAL, UNIFORM, ROBUST = 0, 1, 2   # weight.py:55-58
+
+
+# --------------------------------------------------------------------------
+# fast_math.py:7-16
+# --------------------------------------------------------------------------
+def expj2pi(x):
+    """e^{2 pi i x} with range reduction, f32->c64 / f64->c128 (fast_math.py:7-16)."""
+    x = np.asarray(x)
+    if x.dtype == np.float32:
+        # numba semantics: the reduction x - rint(x) is float32, the product
+        # with the float64 constant 2*pi and cos/sin are float64, result -> c64.
+        y = 2 * np.pi * (x - np.rint(x)).astype(np.float64)
+        return (np.cos(y) + 1j * np.sin(y)).astype(np.complex64)
+    x = x.astype(np.float64)
+    y = 2 * np.pi * (x - np.rint(x))
+    return np.cos(y) + 1j * np.sin(y)
+
+
+# --------------------------------------------------------------------------
+# grid.py:136-334  convolution kernel generation
+# --------------------------------------------------------------------------
+def kaiser_bessel(x, width, beta):
+    """grid.py:136-155."""
+    param = 1 - (2 * x / width) ** 2
+    values = np.i0(beta * np.sqrt(np.maximum(0, param))) / np.i0(beta)
+    return np.select([param >= 0], [values])
+
+
+def kaiser_bessel_fourier(f, width, beta):
+    """grid.py:158-184."""
+    alpha = beta / math.pi
+    return width / np.i0(beta) * np.sinc(
+        np.lib.scimath.sqrt((width * f) ** 2 - alpha * alpha)).real
+
+
+def kernel_beta(antialias_width):
+    """grid.py:374-378."""
+    return 1.2 * math.pi * math.sqrt(0.25 * antialias_width ** 2 - 1.0)
+
+
+def antialias_w_kernel(cell_wavelengths, w, width, oversample, antialias_width,
+                       image_oversample, beta):
+    """grid.py:235-334.  Returns complex128 [len(w)][oversample][width]."""
+    w = np.asarray(w, np.float64)
+    out_pixels = oversample * width
+    assert out_pixels % 2 == 0
+    pixels = out_pixels * image_oversample
+    uv_width = width * cell_wavelengths * image_oversample
+    image_step = 1 / uv_width
+    l = (np.arange(pixels) - (pixels // 2)) * image_step
+    shift_by = -0.5 * cell_wavelengths / oversample
+    scale_l = l * cell_wavelengths
+    aa_factor = cell_wavelengths * kaiser_bessel_fourier(scale_l, antialias_width, beta)
+    shift_arg = shift_by * l
+    l2 = l * l
+    l4 = l2 * l2
+    w_arg = np.outer(-w, -0.5 * l2 - 5.0 / 24.0 * l4)
+    image_values = aa_factor * expj2pi(w_arg + shift_arg)
+    uv_values = np.fft.fft(np.fft.ifftshift(image_values, axes=-1), axis=-1) * image_step
+    uv_values = np.concatenate(
+        (uv_values[..., -(out_pixels // 2):], uv_values[..., :(out_pixels // 2)]), axis=-1)
+    kernel = np.reshape(uv_values, np.shape(w) + (width, oversample))[..., ::-1]
+    return np.ascontiguousarray(np.swapaxes(kernel, 1, 2))
+
+
+def convolution_kernel(cell_size, wavelength, max_w, w_slices, w_planes, oversample,
+                       kernel_width, antialias_width, image_oversample):
+    """ConvolutionKernel.__init__ (grid.py:358-389) -> (complex64 table, beta)."""
+    cell_wavelengths = float(cell_size / wavelength)
+    w_slice_wavelengths = float(max_w / (w_slices * wavelength))
+    w_plane_wavelengths = w_slice_wavelengths / w_planes
+    beta = kernel_beta(antialias_width)
+    max_w_wavelengths = (w_slice_wavelengths - w_plane_wavelengths) * 0.5
+    ws = np.linspace(-max_w_wavelengths, max_w_wavelengths, w_planes)
+    data = antialias_w_kernel(cell_wavelengths, ws, kernel_width, oversample,
+                              antialias_width, image_oversample, beta)
+    return data.astype(np.complex64), beta
+
+
+def taper(N, antialias_width, beta, oversample, dtype=np.float64):
+    """ConvolutionKernel.taper (grid.py:404-423)."""
+    x = np.arange(N) / N - 0.5
+    out = kaiser_bessel_fourier(x, antialias_width, beta)
+    out = out * np.sinc(x / oversample)
+    return out.astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# preprocess.cpp:313-323, 435-507   UVW quantisation
+# --------------------------------------------------------------------------
+def subpixel_coord(x, oversample):
+    """preprocess.cpp:313-323 (vectorised).  x float32 array -> (pixel, subpixel) int16."""
+    x = np.asarray(x, np.float32)
+    xs = np.floor(x * np.float32(oversample)).astype(np.int32)
+    pixel = np.trunc(xs / oversample).astype(np.int32)   # C integer division truncates
+    sub = xs - pixel * oversample
+    neg = sub < 0
+    pixel = np.where(neg, pixel - 1, pixel)
+    sub = np.where(neg, sub + oversample, sub)
+    return pixel.astype(np.int16), sub.astype(np.int16)
+
+
+def quantise_uvw(uvw, vis, weights, cell_size, max_w, w_slices, w_planes, oversample):
+    """The per-visibility arithmetic of visibility_collector::add_impl2 with an
+    identity Mueller matrix (preprocess.cpp:435-507): w<0 flip, weight
+    pre-multiply, NaN squash, quantisation.  No compression / sorting.
+
+    uvw float32 [N][3] (same length unit as cell_size/max_w), vis c64 [N][P],
+    weights f32 [N][P].  Returns dict of arrays (uv, sub_uv, w_plane, w_slice,
+    vis, weights); rows with any zero weight are dropped as in :446-454 + compress.
+    """
+    uvw = np.asarray(uvw, np.float32)
+    vis = np.asarray(vis, np.complex64).copy()
+    weights = np.asarray(weights, np.float32).copy()
+    keep = ~np.any(weights == 0, axis=1)
+    uvw, vis, weights = uvw[keep], vis[keep], weights[keep]
+    # xweights = 1/(|M|^2 * 1/|w|) with M = I  ->  |w| up to two roundings
+    with np.errstate(divide='ignore'):
+        weights = (np.float32(1) / (np.float32(1) / np.abs(weights))).astype(np.float32)
+    u = uvw[:, 0].copy()
+    v = uvw[:, 1].copy()
+    w = uvw[:, 2].copy()
+    flip = w < 0
+    u[flip] = -u[flip]
+    v[flip] = -v[flip]
+    w[flip] = -w[flip]
+    vis[flip] = np.conj(vis[flip])
+    vis = (vis * weights).astype(np.complex64)
+    bad = ~(np.isfinite(vis.real) & np.isfinite(vis.imag))
+    vis[bad] = 0
+    weights[bad] = 0
+    uv_scale = np.float32(1.0) / np.float32(cell_size)
+    w_scale = np.float32((np.float32(w_slices) - np.float32(0.5)) * np.float32(w_planes)
+                         / np.float32(max_w))
+    u = (u * uv_scale).astype(np.float32)
+    v = (v * uv_scale).astype(np.float32)
+    wq = np.trunc((w * w_scale + np.float32(w_planes) * np.float32(0.5)).astype(np.float32))
+    w_slice_plane = np.minimum(wq.astype(np.int64), w_slices * w_planes - 1)
+    pu, su = subpixel_coord(u, oversample)
+    pv, sv = subpixel_coord(v, oversample)
+    return dict(
+        uv=np.stack([pu, pv], axis=1), sub_uv=np.stack([su, sv], axis=1),
+        w_plane=(w_slice_plane % w_planes).astype(np.int16),
+        w_slice=(w_slice_plane // w_planes).astype(np.int16),
+        vis=vis, weights=weights)
+
+
+def compress(rec):
+    """Adjacent-merge compression (preprocess.cpp:334-372): consecutive records
+    with identical (uv, sub_uv, w_plane, w_slice) are summed."""
+    key = np.concatenate([rec['uv'], rec['sub_uv'], rec['w_plane'][:, None],
+                          rec['w_slice'][:, None]], axis=1)
+    n = len(key)
+    if n == 0:
+        return rec
+    new = np.ones(n, bool)
+    new[1:] = np.any(key[1:] != key[:-1], axis=1)
+    group = np.cumsum(new) - 1
+    ng = group[-1] + 1
+    out = {k: rec[k][new] for k in ('uv', 'sub_uv', 'w_plane', 'w_slice')}
+    vis = np.zeros((ng,) + rec['vis'].shape[1:], np.complex64)
+    wts = np.zeros((ng,) + rec['weights'].shape[1:], np.float32)
+    # sequential float32 accumulation in arrival order, as the C++ loop does
+    for i in range(n):
+        vis[group[i]] += rec['vis'][i]
+        wts[group[i]] += rec['weights'][i]
+    out['vis'] = vis
+    out['weights'] = wts
+    return out
+
+
+# --------------------------------------------------------------------------
+# C restatement loader (oracle/kimg_oracle.c)
+# --------------------------------------------------------------------------
+_clib = None
+
+
+def build_c(force=False):
+    """Compile oracle/kimg_oracle.c -> oracle/libkimg_oracle.so with gcc."""
+    src = os.path.join(_HERE, 'kimg_oracle.c')
+    out = os.path.join(_HERE, 'libkimg_oracle.so')
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(
+            ['gcc', '-O2', '-ffp-contract=off', '-fno-fast-math', '-march=x86-64-v2',
+             '-shared', '-fPIC', '-o', out, src, '-lm'])
+    return out
+
+
+def clib():
+    global _clib
+    if _clib is None:
+        _clib = ctypes.CDLL(build_c())
+        _clib.oracle_version.restype = ctypes.c_int
+    return _clib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype)
+    return a
+
+
+# --------------------------------------------------------------------------
+# grid.py:1032-1052 / 1138-1154   gridding and degridding
+# --------------------------------------------------------------------------
+def grid_py(kernel, grid, weights_grid, uv, sub_uv, w_plane, vis):
+    """Pure-numpy transcription of _grid (grid.py:1032-1052); small cases only."""
+    ksize = kernel.shape[2]
+    uv_bias = (ksize - 1) // 2 - grid.shape[2] // 2
+    ctype = grid.dtype.type
+    for row in range(uv.shape[0]):
+        u0 = int(uv[row, 0]) - uv_bias
+        v0 = int(uv[row, 1]) - uv_bias
+        sub_u, sub_v = int(sub_uv[row, 0]), int(sub_uv[row, 1])
+        wu = int(uv[row, 0]) + weights_grid.shape[2] // 2
+        wv = int(uv[row, 1]) + weights_grid.shape[1] // 2
+        wp = int(w_plane[row])
+        for pol in range(grid.shape[0]):
+            sample = ctype(vis[row, pol] * weights_grid[pol, wv, wu])
+            kv = kernel[wp, sub_v, :]
+            ku = kernel[wp, sub_u, :]
+            weight = np.conj(kv[:, None] * ku[None, :])          # complex64 products
+            grid[pol, v0:v0 + ksize, u0:u0 + ksize] += (sample * weight).astype(grid.dtype)
+
+
+def grid(kernel, grid_, weights_grid, uv, sub_uv, w_plane, vis):
+    """_grid (grid.py:1032-1052) via the C restatement.  grid_ is complex64
+    [P][G][G] (modified in place) or complex128."""
+    lib = clib()
+    kernel = _c(kernel, np.complex64)
+    weights_grid = _c(weights_grid, np.float32)
+    uv = _c(uv, np.int16)
+    sub_uv = _c(sub_uv, np.int16)
+    w_plane = _c(w_plane, np.int16)
+    vis = _c(vis, np.complex64)
+    assert grid_.flags.c_contiguous
+    P, G = grid_.shape[0], grid_.shape[2]
+    assert grid_.shape[1] == G and weights_grid.shape == grid_.shape
+    fn = lib.oracle_grid_c64 if grid_.dtype == np.complex64 else lib.oracle_grid_c128
+    fn(_p(kernel), ctypes.c_int(kernel.shape[1]), ctypes.c_int(kernel.shape[2]),
+       _p(grid_), ctypes.c_int(P), ctypes.c_int(G), _p(weights_grid),
+       _p(uv), _p(sub_uv), _p(w_plane), _p(vis), ctypes.c_long(uv.shape[0]))
+
+
+def degrid_py(kernel, values, uv, sub_uv, w_plane, weights, vis):
+    """Pure-numpy transcription of _degrid (grid.py:1138-1154)."""
+    ksize = kernel.shape[2]
+    uv_bias = (ksize - 1) // 2 - values.shape[2] // 2
+    for row in range(uv.shape[0]):
+        u0 = int(uv[row, 0]) - uv_bias
+        v0 = int(uv[row, 1]) - uv_bias
+        wp = int(w_plane[row])
+        kv = kernel[wp, int(sub_uv[row, 1]), :]
+        ku = kernel[wp, int(sub_uv[row, 0]), :]
+        weight = kv[:, None] * ku[None, :]
+        for pol in range(values.shape[0]):
+            fp = values[pol, v0:v0 + ksize, u0:u0 + ksize]
+            sample = values.dtype.type(0)
+            for j in range(ksize):
+                for k in range(ksize):
+                    sample += weight[j, k] * fp[j, k]
+            vis[row, pol] -= weights[row, pol] * sample
+
+
+def degrid(kernel, values, uv, sub_uv, w_plane, weights, vis):
+    """_degrid (grid.py:1138-1154) via the C restatement.  vis modified in place."""
+    lib = clib()
+    kernel = _c(kernel, np.complex64)
+    uv = _c(uv, np.int16)
+    sub_uv = _c(sub_uv, np.int16)
+    w_plane = _c(w_plane, np.int16)
+    weights = _c(weights, np.float32)
+    assert vis.dtype == np.complex64 and vis.flags.c_contiguous
+    assert values.flags.c_contiguous
+    P, G = values.shape[0], values.shape[2]
+    fn = lib.oracle_degrid_c64 if values.dtype == np.complex64 else lib.oracle_degrid_c128
+    fn(_p(kernel), ctypes.c_int(kernel.shape[1]), ctypes.c_int(kernel.shape[2]),
+       _p(values), ctypes.c_int(P), ctypes.c_int(G),
+       _p(uv), _p(sub_uv), _p(w_plane), _p(weights), _p(vis), ctypes.c_long(uv.shape[0]))
+
+
+# --------------------------------------------------------------------------
+# predict.py:73-149, 419-438
+# --------------------------------------------------------------------------
+def extract_sky_image(pixels, pixel_size, image_size, oversample, components, dtype=np.float32):
+    """_extract_sky_image (predict.py:73-119).  components: {(y,x): array[P]}."""
+    N = len(components)
+    pols = len(next(iter(components.values()))) if N else 0
+    lmn = np.empty((N, 3), np.float32)
+    flux = np.empty((N, pols), dtype)
+    x = np.array([pos[1] for pos in components])
+    y = np.array([pos[0] for pos in components])
+    l = (x - 0.5 * pixels) * pixel_size
+    m = (y - 0.5 * pixels) * pixel_size
+    n1 = np.sqrt(1.0 - (np.square(l) + np.square(m))) - 1.0
+    lmn[:, 0] = l
+    lmn[:, 1] = m
+    lmn[:, 2] = n1
+    if N:
+        flux[:] = list(components.values())
+    taper_scale = float(image_size * oversample)
+    tap = np.sinc(l / taper_scale) * np.sinc(m / taper_scale)
+    flux *= tap[:, np.newaxis]
+    return lmn, flux
+
+
+def uvw_scale_bias(cell_size, wavelength, max_w, w_slices, w_planes, oversample):
+    """_uvw_scale_bias (predict.py:122-149)."""
+    uv_scale = float((cell_size / oversample) / wavelength)
+    w_scale = float((max_w / ((w_slices - 0.5) * w_planes)) / wavelength)
+    w_bias = (0.5 - 0.5 * w_planes) * w_scale
+    return uv_scale, w_scale, w_bias
+
+
+def predict(vis, uv, sub_uv, w_plane, weights, lmn, flux, oversample, uv_scale, w_scale, w_bias):
+    """_predict_host (predict.py:419-438) via the C restatement; vis in place."""
+    lib = clib()
+    assert vis.dtype == np.complex64 and vis.flags.c_contiguous
+    uv = _c(uv, np.int16)
+    sub_uv = _c(sub_uv, np.int16)
+    w_plane = _c(w_plane, np.int16)
+    weights = _c(weights, np.float32)
+    lmn = _c(lmn, np.float32)
+    flux = _c(flux, np.float32)
+    lib.oracle_predict(_p(vis), _p(uv), _p(sub_uv), _p(w_plane), _p(weights), _p(lmn), _p(flux),
+                       ctypes.c_long(vis.shape[0]), ctypes.c_int(lmn.shape[0]),
+                       ctypes.c_int(vis.shape[1]),
+                       ctypes.c_float(oversample), ctypes.c_float(uv_scale),
+                       ctypes.c_float(w_scale), ctypes.c_float(w_bias))
+
+
+# --------------------------------------------------------------------------
+# image.py:743-848   grid <-> image
+# --------------------------------------------------------------------------
+def grid_to_image(grid_, image, kernel1d, lm_scale, lm_bias, w):
+    """GridToImageHost.__call__ (image.py:781-799): image += ...; returns layer."""
+    layer = np.fft.ifft2(np.fft.ifftshift(grid_, axes=(1, 2)), axes=(1, 2)).astype(grid_.dtype)
+    scale = layer.shape[1] * layer.shape[2]
+    lm = np.arange(image.shape[1]).astype(image.dtype) * lm_scale + lm_bias
+    lm = np.fft.ifftshift(lm)
+    lm2 = lm * lm
+    n = np.sqrt(1 - (lm2[:, np.newaxis] + lm2[np.newaxis, :]))
+    w_correct = expj2pi(w * (n - 1))
+    layer *= w_correct
+    img = layer.real.copy()
+    img *= scale
+    img *= n[np.newaxis, ...]
+    img = np.fft.fftshift(img, axes=(1, 2))
+    img /= np.outer(kernel1d, kernel1d)[np.newaxis, ...]
+    image += img
+    return layer
+
+
+def image_to_grid(image, kernel1d, lm_scale, lm_bias, w, complex_dtype=np.complex64):
+    """ImageToGridHost.__call__ (image.py:836-848): returns (grid, layer)."""
+    lm = np.arange(image.shape[1]).astype(image.dtype) * lm_scale + lm_bias
+    lm2 = lm * lm
+    n = np.sqrt(1 - (lm2[:, np.newaxis] + lm2[np.newaxis, :]))[np.newaxis, ...]
+    w_correct = expj2pi(-w * (n - 1))
+    kernel = np.outer(kernel1d, kernel1d)[np.newaxis, ...]
+    layer = (image / (kernel * n) * w_correct).astype(complex_dtype)
+    grid_ = np.fft.fftshift(
+        np.fft.fft2(np.fft.ifftshift(layer, axes=(1, 2)), axes=(1, 2)), axes=(1, 2))
+    return grid_.astype(complex_dtype), layer
+
+
+# --------------------------------------------------------------------------
+# weight.py:541-605
+# --------------------------------------------------------------------------
+def weights_grid_add(weights_grid, uv, weights):
+    """WeightsHost.grid (weight.py:567-572).  NB the reference biases `uv` in
+    place; this restatement leaves the caller's array untouched."""
+    shape = weights_grid.shape
+    uu = uv[:, 0].astype(np.int64) + shape[2] // 2
+    vv = uv[:, 1].astype(np.int64) + shape[1] // 2
+    for i in range(len(uv)):
+        weights_grid[:, vv[i], uu[i]] += weights[i, :]
+
+
+def weights_finalize(weight_type, weights_grid, robustness=0.0):
+    """WeightsHost.finalize (weight.py:574-605): in place; returns (rms, normalized_rms)."""
+    if weight_type == NATURAL:
+        weights_grid.fill(1)
+        return None, 1.0
+    if weight_type == UNIFORM:
+        sum_w = np.sum(weights_grid[0])
+        sum_dw = np.count_nonzero(weights_grid[0])
+        weights_grid[weights_grid == 0] = np.inf
+        np.reciprocal(weights_grid, out=weights_grid)
+        sum_d2w = np.sum(weights_grid[0])
+        rms = np.sqrt(sum_d2w) / sum_dw
+        return rms, rms * np.sqrt(sum_w)
+    if weight_type == ROBUST:
+        sum_sq = np.dot(weights_grid[0].flat, weights_grid[0].flat)
+        sum_ = np.sum(weights_grid[0])
+        mean_weight = sum_sq / sum_
+        S2 = (5 * 10 ** (-robustness)) ** 2 / mean_weight
+        old0 = weights_grid[0].copy()
+        weights_grid[weights_grid == 0] = np.inf
+        np.reciprocal(weights_grid * S2 + 1, out=weights_grid)
+        sum_w = np.sum(old0)
+        sum_dw = np.sum(weights_grid[0] * old0)
+        sum_d2w = np.sum(weights_grid[0] ** 2 * old0)
+        rms = np.sqrt(sum_d2w) / sum_dw
+        return rms, rms * np.sqrt(sum_w)
+    raise ValueError('Unknown weight_type {}'.format(weight_type))
+
+
+# --------------------------------------------------------------------------
+# clean.py:894-1075
+# --------------------------------------------------------------------------
+def psf_patch(psf, threshold, limit=None):
+    """psf_patch_host (clean.py:894-935)."""
+    if limit is not None:
+        hlimit = (round(limit * min(psf.shape[1], psf.shape[2])) - 1) // 2
+        mid_x = psf.shape[2] // 2
+        mid_y = psf.shape[1] // 2
+        min_x = max(0, mid_x - hlimit)
+        min_y = max(0, mid_y - hlimit)
+        max_x = min(psf.shape[2] - 1, mid_x + hlimit)
+        max_y = min(psf.shape[1] - 1, mid_y + hlimit)
+        psf = psf[:, min_y:max_y + 1, min_x:max_x + 1]
+    nz = np.nonzero(np.abs(psf) >= threshold)
+    if len(nz[0]) == 0:
+        return (psf.shape[0], 1, 1)
+    y_dist = np.max(np.abs(nz[1] - psf.shape[1] // 2))
+    x_dist = np.max(np.abs(nz[2] - psf.shape[2] // 2))
+    return (psf.shape[0], int(min(psf.shape[1], 2 * y_dist + 1)),
+            int(min(psf.shape[2], 2 * x_dist + 1)))
+
+
+def noise_est(image, border):
+    """noise_est_host (clean.py:938-943)."""
+    bp = round(border * min(image.shape[1], image.shape[2]))
+    image = image[:, bp:-bp, bp:-bp]
+    return np.median(np.abs(image)) * MEDIAN_TO_RMS
+
+
+def metric_to_power(mode, metric):
+    """clean.py:166-174."""
+    return metric if mode == CLEAN_I else math.sqrt(metric)
+
+
+def power_to_metric(mode, power):
+    """clean.py:177-184."""
+    return power if mode == CLEAN_I else power * power
+
+
+def noise_threshold_scale(mode, threshold, num_polarizations):
+    """clean.py:187-203."""
+    if mode == CLEAN_I:
+        return threshold
+    import scipy.stats
+    p = 2 * scipy.stats.norm.sf(threshold)
+    return np.sqrt(scipy.stats.chi2.isf(p, num_polarizations))
+
+
+class Clean:
+    """CleanHost (clean.py:971-1075): tiled Hogbom CLEAN on float32 arrays.
+
+    The tile scan (_tile_peak, clean.py:946-968) runs in the C restatement
+    (first strict maximum in row-major order; all-zero tile keeps the
+    reference's (x0, y0) initial position quirk, clean.py:950)."""
+
+    def __init__(self, pixels, border, loop_gain, mode, image, psf, model):
+        self.loop_gain = loop_gain
+        self.mode = mode
+        self.image = image
+        self.psf = psf
+        self.model = model
+        self.tile_size = 32
+        self.border_pixels = round(pixels * border)
+        tiles_x = -(-(image.shape[2] - 2 * self.border_pixels) // self.tile_size)
+        tiles_y = -(-(image.shape[1] - 2 * self.border_pixels) // self.tile_size)
+        self._tile_max = np.zeros((tiles_y, tiles_x), image.dtype)
+        self._tile_pos = np.empty((tiles_y, tiles_x, 2), np.int32)
+        assert image.dtype == np.float32 and image.flags.c_contiguous
+
+    def _update_tiles(self, ty0, tx0, ty1, tx1):
+        clib().oracle_update_tiles(
+            _p(self.image), ctypes.c_int(self.image.shape[0]), ctypes.c_int(self.image.shape[1]),
+            ctypes.c_int(self.image.shape[2]), ctypes.c_int(self.border_pixels),
+            ctypes.c_int(self.tile_size), ctypes.c_int(self.mode),
+            _p(self._tile_max), _p(self._tile_pos), ctypes.c_int(self._tile_max.shape[1]),
+            ctypes.c_int(ty0), ctypes.c_int(tx0), ctypes.c_int(ty1), ctypes.c_int(tx1))
+
+    def reset(self):
+        self._update_tiles(0, 0, self._tile_max.shape[0], self._tile_max.shape[1])
+
+    def _subtract_psf(self, y, x, psf_patch_):
+        """clean.py:1014-1048."""
+        px, py = psf_patch_[2], psf_patch_[1]
+        sx, sy = self.image.shape[2], self.image.shape[1]
+        psf_x = self.psf.shape[2] // 2
+        psf_y = self.psf.shape[1] // 2
+        x0 = x - px // 2
+        x1 = x0 + px
+        y0 = y - py // 2
+        y1 = y0 + py
+        psf_x0 = psf_x - px // 2
+        psf_y0 = psf_y - py // 2
+        psf_x1 = psf_x0 + px
+        psf_y1 = psf_y0 + py
+        if x0 < 0:
+            psf_x0 -= x0
+            x0 = 0
+        if y0 < 0:
+            psf_y0 -= y0
+            y0 = 0
+        if x1 > sx:
+            psf_x1 -= (x1 - sx)
+            x1 = sx
+        if y1 > sy:
+            psf_y1 -= (y1 - sy)
+            y1 = sy
+        scale = (np.float32(self.loop_gain) * self.image[:, y, x]).astype(self.image.dtype)
+        self.image[..., y0:y1, x0:x1] -= (
+            scale[:, np.newaxis, np.newaxis] * self.psf[..., psf_y0:psf_y1, psf_x0:psf_x1])
+        self.model[..., y, x] += scale
+        return (y0, x0, y1, x1), scale
+
+    def __call__(self, psf_patch_, threshold=0.0):
+        """clean.py:1060-1075."""
+        peak_tile = np.unravel_index(np.argmax(self._tile_max), self._tile_max.shape)
+        peak_pos = self._tile_pos[peak_tile]
+        peak_value = self._tile_max[peak_tile]
+        if peak_value < threshold:
+            return None, None, None
+        (y0, x0, y1, x1), model_pixel = self._subtract_psf(int(peak_pos[0]), int(peak_pos[1]),
+                                                           psf_patch_)
+        ts, bp = self.tile_size, self.border_pixels
+        ty0 = max((y0 - bp) // ts, 0)
+        tx0 = max((x0 - bp) // ts, 0)
+        ty1 = min(-(-(y1 - bp) // ts), self._tile_max.shape[0])
+        tx1 = min(-(-(x1 - bp) // ts), self._tile_max.shape[1])
+        self._update_tiles(ty0, tx0, ty1, tx1)
+        return peak_value, tuple(int(v) for v in peak_pos), model_pixel
