@@ -1,0 +1,206 @@
+/* libkimg -- C ABI of the MI355X (gfx950) imaging hot path.
+ *
+ * Drop-in boundary for the per-channel imaging loop of ska-sa/katsdpimager:
+ * each entry point replaces one device-kernel launch site of the reference's
+ * operator classes (file:line relative to the reference checkout).  The
+ * reference reaches its kernels through katsdpsigproc's
+ * `command_queue.enqueue_kernel(...)`; a maintainer binds these functions with
+ * ctypes/cffi instead.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless the name
+ *    ends in `_host`; nothing is allocated or freed here except FFT plans;
+ *  - arrays come with explicit element strides (row, polarization) exactly
+ *    like the reference kernels' arguments;
+ *  - `stream` is a hipStream_t (NULL = default stream); all calls are
+ *    asynchronous on it and may be captured into a hipGraph unless noted;
+ *  - return value: 0 on success, a negated hipError_t on a HIP failure, or a
+ *    KIMG_E* code below for argument errors.  Kernels themselves never report
+ *    errors (same as the reference).
+ *  - complex numbers are interleaved float (re, im) = numpy complex64.
+ */
+#ifndef KIMG_H
+#define KIMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KIMG_VERSION 1
+
+#define KIMG_EINVAL (-10001)      /* bad argument (null pointer, negative size ...) */
+#define KIMG_EUNSUPPORTED (-10002) /* parameter combination not supported by this build */
+#define KIMG_EWORKSPACE (-10003)   /* workspace too small */
+
+#define KIMG_CLEAN_I 0      /* clean.py:29 */
+#define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */
+
+int kimg_version(void);
+/* Static string describing a return code of this library. */
+const char *kimg_error_string(int code);
+
+/* ---- gridding: grid.py:786-867 Gridder.static_run/_run + imager_kernels/grid.mako:63-197
+ * grid[p][v0+j][u0+k] += vis[r][p] * weights_grid[p][v+Gg/2][u+Gg/2]
+ *                        * conj(kern[w][sub_v][j] * kern[w][sub_u][k]),
+ * u0 = u - ((K-1)/2 - Gg/2)  (grid.py:1038-1041).
+ *   grid            complex64 [P][grid_size][grid_size] (strides in complex elements)
+ *   weights_grid    float32   [P][grid_size][grid_size] (strides in elements)
+ *   uv              int16 [N][4] = (u, v, sub_u, sub_v)       grid.py:661-664
+ *   w_plane         int16 [N]
+ *   vis             complex64 [N][P]
+ *   convolve_kernel complex64 [w_planes][oversample][kernel_width], unpadded
+ *   workspace       scratch, at least kimg_grid_workspace_bytes(max N, P) bytes
+ *   variant         0 = automatic; 1 = generic scatter kernel; 2 = MFMA window kernel
+ */
+size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations);
+int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
+              int num_polarizations,
+              const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
+              const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
+              const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
+              void *workspace, size_t workspace_bytes, int variant, void *stream);
+
+/* ---- degridding: grid.py:985-1029 Degridder.static_run/_run + degrid.mako:77-199
+ * vis[r][p] -= weights[r][p] * sum_{j,k} kern[w][sub_v][j]*kern[w][sub_u][k]*grid[p][v0+j][u0+k]
+ *   weights  float32 [N][P] statistical weights
+ */
+int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
+                int num_polarizations,
+                const int16_t *uv, const int16_t *w_plane, const float *weights, void *vis,
+                int64_t num_vis,
+                const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
+                void *stream);
+
+/* ---- direct prediction: predict.py:386-416 Predict._run + predict.mako:10-87
+ * vis[r][p] -= weights[r][p] * sum_s flux[s][p] * exp(-2 pi i (l u + m v + (n-1) w)),
+ * u = (uv.x*oversample + uv.z + 0.5)*uv_scale, w = w_plane*w_scale + w_bias.
+ *   lmn float32 [S][3] (l, m, n-1);  flux float32 [S][P]
+ */
+int kimg_predict(void *vis, const int16_t *uv, const int16_t *w_plane, const float *weights,
+                 const float *lmn, const float *flux, int64_t num_vis, int num_sources,
+                 int num_polarizations, int oversample, float uv_scale, float w_scale,
+                 float w_bias, void *stream);
+
+/* ---- imaging weights: weight.py:155-176 / 261-284 / 357-376 + grid_weights.mako,
+ * density_weights.mako, mean_weight.mako; fill = katsdpsigproc fill.FillTemplate (weight.py:403).
+ *   kimg_grid_weights:    grid[p][v+H/2][u+W/2] += weights[r][p]   (uv = first 2 of 4 int16)
+ *   kimg_mean_weight:     sums[0] = sum w, sums[1] = sum w^2 over polarization 0
+ *   kimg_density_weights: in place d = w != 0 ? 1/(a*w+b) : 0;
+ *                         sums[0..2] = sum w, sum d*w, sum d*d*w over polarization 0
+ *   `sums` are device float64 and are zeroed by the call.
+ */
+int kimg_grid_weights(float *grid, int64_t row_stride, int64_t pol_stride, int width, int height,
+                      int num_polarizations, const int16_t *uv, const float *weights,
+                      int64_t num_vis, void *stream);
+int kimg_mean_weight(double *sums, const float *grid, int64_t row_stride, int width, int height,
+                     void *stream);
+int kimg_density_weights(double *sums, float *grid, int64_t row_stride, int64_t pol_stride,
+                         int width, int height, int num_polarizations, float a, float b,
+                         void *stream);
+int kimg_fill(float *data, int64_t count, float value, void *stream);
+
+/* ---- grid <-> image: image.py:649-673 GridToImage._run, :716-740 ImageToGrid._run,
+ * :153-180 _LayerImage._run + layer_to_image.mako / image_to_layer.mako.
+ *   kimg_grid_to_layer: zero the GxG layer and copy the centred Gg x Gg grid of one
+ *       polarization into its corners (DC at [0][0]) -- the reference's zero + 4 copy_region.
+ *   kimg_layer_to_grid: the inverse copy (corners -> centred grid).
+ *   kimg_layer_to_image: image[pol] += Re(layer * e^{2 pi i w (n-1)}) * n / (k1d[y] k1d[x]),
+ *       with fftshift; l = x*lm_scale + lm_bias.  layer is row-contiguous GxG.
+ *   kimg_image_to_layer: layer = image[pol] / (k1d[y] k1d[x] n) * e^{-2 pi i w (n-1)}.
+ */
+int kimg_grid_to_layer(void *layer, int layer_size, const void *grid, int64_t grid_row_stride,
+                       int grid_size, void *stream);
+int kimg_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size, const void *layer,
+                       int layer_size, void *stream);
+int kimg_layer_to_image(float *image, int64_t image_row_stride, const void *layer, int size,
+                        const float *kernel1d, float lm_scale, float lm_bias, float w,
+                        void *stream);
+int kimg_image_to_layer(void *layer, const float *image, int64_t image_row_stride, int size,
+                        const float *kernel1d, float lm_scale, float lm_bias, float w,
+                        void *stream);
+
+/* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
+ * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */
+int kimg_fft_plan_create(void **plan, int size_y, int size_x);
+int kimg_fft_exec(void *plan, void *layer, int direction, void *stream);
+int kimg_fft_plan_destroy(void *plan);
+
+/* ---- image-plane streams: image.py:351-367, :439-458, :539-558 (+ scale.mako,
+ * add_image.mako, apply_primary_beam.mako).  scale_host: P floats on the HOST. */
+int kimg_scale(float *image, int64_t row_stride, int64_t pol_stride, int width, int height,
+               int num_polarizations, const float *scale_host, void *stream);
+int kimg_add_image(float *dest, int64_t dest_row_stride, int64_t dest_pol_stride,
+                   const float *src, int64_t src_row_stride, int64_t src_pol_stride,
+                   int width, int height, int num_polarizations, void *stream);
+int kimg_apply_primary_beam(float *image, int64_t row_stride, int64_t pol_stride,
+                            const float *beam_power, int64_t beam_row_stride,
+                            int width, int height, int num_polarizations,
+                            float threshold, float replacement, void *stream);
+
+/* ---- CLEAN support: clean.py:123-163 PsfPatch.__call__ + psf_patch.mako
+ * bound (device int32[2], zeroed by the call) receives max |x-mid_x|, max |y-mid_y| over
+ * pixels in [min_x,max_x]x[min_y,max_y] where any polarization has |psf| >= threshold. */
+int kimg_psf_patch(const float *psf, int64_t row_stride, int64_t pol_stride, int num_polarizations,
+                   int min_x, int min_y, int max_x, int max_y, int mid_x, int mid_y,
+                   float threshold, int32_t *bound, void *stream);
+
+/* Noise estimate support (clean.py:295-353 NoiseEst.__call__ + rank.mako, host semantics of
+ * clean.py:938-943): one radix-select pass.  hist (device uint32[256], zeroed by the call)
+ * receives the histogram of byte `pass` (3 = most significant) of the bit pattern of |x| over
+ * the region inside `border`, restricted to values whose higher bytes equal `prefix`. */
+int kimg_abs_histogram(const float *image, int64_t row_stride, int64_t pol_stride,
+                       int width, int height, int num_polarizations, int border,
+                       int pass, uint32_t prefix, uint32_t *hist, void *stream);
+/* out[0] = count of |x| <= value, out[1] = bit pattern of min |x| > value (0xFFFFFFFF if none);
+ * out is device uint32[2], initialised by the call. */
+int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t pol_stride,
+                      int width, int height, int num_polarizations, int border,
+                      float value, uint32_t *out, void *stream);
+
+/* ---- CLEAN minor cycle: clean.py:451-480 _UpdateTiles.__call__, :566-587 _FindPeak._run,
+ * :683-726 _SubtractPsf.__call__ (+ update_tiles.mako, find_peak.mako, subtract_psf.mako).
+ * Tie-breaks follow the reference HOST path bit-exactly: first strict maximum in row-major
+ * order within a tile (clean.py:953-958), first maximum tile in row-major order
+ * (np.argmax, clean.py:1062).
+ *   dirty/model/psf float32 [P][height][width]; tile_max float32 [tiles_y][tiles_x];
+ *   tile_pos int32 [tiles_y][tiles_x][2] = (y, x); tiles are 32x32 starting at `border`.
+ */
+int kimg_update_tiles(const float *dirty, int64_t row_stride, int64_t pol_stride,
+                      int width, int height, int num_polarizations, int border, int mode,
+                      float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
+                      int tile_x0, int tile_y0, int tile_x1, int tile_y1, void *stream);
+int kimg_find_peak(const float *dirty, int64_t row_stride, int64_t pol_stride,
+                   int num_polarizations, const float *tile_max, const int32_t *tile_pos,
+                   int tiles_x, int tiles_y,
+                   float *peak_value, int32_t *peak_pos, float *peak_pixel, void *stream);
+int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
+                      int width, int height, int num_polarizations,
+                      const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                      int psf_width, int psf_height, int patch_width, int patch_height,
+                      const float *peak_pixel, int pos_x, int pos_y, float loop_gain,
+                      void *stream);
+
+/* Device-resident minor-cycle loop (replaces the per-cycle host round trip of
+ * clean.py:848-891): runs up to `max_cycles` cycles of find-peak -> threshold test ->
+ * subtract -> tile update without host synchronisation.
+ *   state  device scratch, kimg_clean_state_bytes(P) bytes, zeroed by the call
+ *   log    device float32 [max_cycles][3 + P]: (metric, y, x as float bits, loop_gain*pixel[p])
+ *   After the stream is synchronised, ((int32*)state)[0] holds the number of cycles done
+ *   (stops early when the peak metric < threshold, clean.py:879-880).
+ */
+size_t kimg_clean_state_bytes(int num_polarizations);
+int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
+                      int width, int height, int num_polarizations,
+                      const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                      int psf_width, int psf_height, int patch_width, int patch_height,
+                      int border, int mode, float loop_gain, float threshold,
+                      float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
+                      int max_cycles, void *state, float *log, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIMG_H */

@@ -1,0 +1,425 @@
+"""Tiled Hogbom CLEAN on MI355X.
+
+Operator surface of the reference's ``katsdpimager.clean`` (PsfPatch, NoiseEst,
+_UpdateTiles, _FindPeak, _SubtractPsf, Clean; clean.py:37-891) on libkimg.so,
+plus :meth:`Clean.run_cycles`: a device-resident minor-cycle loop that removes
+the per-cycle host round trip of clean.py:870-878 while producing the same
+component list.
+
+Peak selection and tie-breaks are bit-exact with the reference HOST path
+(CleanHost, clean.py:971-1075); see csrc/clean.hip.
+"""
+import math
+
+import numpy as np
+
+from . import accel, types
+from ._lib import lib, check
+from .parameters import CLEAN_I, CLEAN_SUMSQ  # noqa: F401
+
+#: median(|x|) -> sigma for a zero-mean Gaussian (clean.py:34)
+_MEDIAN_TO_RMS = 1.4826022185056031
+
+TILE = 32
+
+
+def metric_to_power(mode, metric):
+    """clean.py:166-174."""
+    if mode == CLEAN_I:
+        return metric
+    elif mode == CLEAN_SUMSQ:
+        return math.sqrt(metric)
+    raise ValueError('Invalid mode {}'.format(mode))
+
+
+def power_to_metric(mode, power):
+    """clean.py:177-184."""
+    if mode == CLEAN_I:
+        return power
+    elif mode == CLEAN_SUMSQ:
+        return power * power
+    raise ValueError('Invalid mode {}'.format(mode))
+
+
+def noise_threshold_scale(mode, threshold, num_polarizations):
+    """clean.py:187-203."""
+    if mode == CLEAN_I:
+        return threshold
+    elif mode == CLEAN_SUMSQ:
+        import scipy.stats
+        p = 2 * scipy.stats.norm.sf(threshold)
+        return np.sqrt(scipy.stats.chi2.isf(p, num_polarizations))
+    raise ValueError('Invalid mode {}'.format(mode))
+
+
+def _image_args(array):
+    P, H, W = array.shape
+    return array.ptr, W, H * W, W, H, P
+
+
+class PsfPatchTemplate:
+    """clean.py:37-69."""
+    def __init__(self, context, dtype, num_polarizations, tuning=None):
+        types.require_float32(dtype, 'PsfPatchTemplate')
+        lib()
+        self.context = context
+        self.num_polarizations = num_polarizations
+        self.dtype = np.dtype(dtype)
+
+    def instantiate(self, *args, **kwargs):
+        return PsfPatch(self, *args, **kwargs)
+
+
+class PsfPatch(accel.Operation):
+    """Size of the central PSF box holding every |psf| >= threshold (clean.py:72-163).
+    Slots: **psf** [P][H][W]; **bound** int32 [2]."""
+
+    def __init__(self, template, command_queue, shape, allocator=None):
+        if shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        super().__init__(command_queue, allocator)
+        self.template = template
+        self.slots['psf'] = accel.IOSlot(shape, template.dtype)
+        self.slots['bound'] = accel.IOSlot((2,), np.int32)
+
+    def _run(self):
+        pass
+
+    def __call__(self, threshold, limit=None, **kwargs):
+        self.bind(**kwargs)
+        self.ensure_all_bound()
+        psf = self.buffer('psf')
+        bound = self.buffer('bound')
+        P, H, W = psf.shape
+        min_x, min_y, max_x, max_y = 0, 0, W - 1, H - 1
+        mid_x, mid_y = W // 2, H // 2
+        if limit is not None:
+            hlimit = (round(limit * min(H, W)) - 1) // 2
+            min_x = max(min_x, mid_x - hlimit)
+            min_y = max(min_y, mid_y - hlimit)
+            max_x = min(max_x, mid_x + hlimit)
+            max_y = min(max_y, mid_y + hlimit)
+        rc = lib().kimg_psf_patch(psf.ptr, W, H * W, P, min_x, min_y, max_x, max_y, mid_x, mid_y,
+                                  threshold, bound.ptr, self.command_queue.handle)
+        check(rc, 'kimg_psf_patch')
+        b = bound.get(self.command_queue)
+        box = 2 * b + 1
+        return (P, int(min(box[1], H)), int(min(box[0], W)))
+
+
+class NoiseEstTemplate:
+    """clean.py:206-244."""
+    def __init__(self, context, dtype, num_polarizations, tuning=None):
+        types.require_float32(dtype, 'NoiseEstTemplate')
+        lib()
+        self.context = context
+        self.dtype = np.dtype(dtype)
+        self.num_polarizations = num_polarizations
+
+    def instantiate(self, *args, **kwargs):
+        return NoiseEst(self, *args, **kwargs)
+
+
+class NoiseEst(accel.Operation):
+    """Robust noise estimate median(|dirty| inside the border) * 1.4826 (clean.py:247-353).
+
+    The reference's GPU class bisects the float bit pattern to ~1e-4 relative accuracy with
+    ~30 ranking passes; this one finds the EXACT median (as the reference's host path,
+    clean.py:938-943) with a 4-pass byte-wise radix select plus one counting pass.
+    Slots: **dirty** [P][H][W]; **rank** uint32 [256] (histogram scratch).
+    """
+
+    def __init__(self, template, command_queue, image_shape, border, allocator=None):
+        if image_shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        if border >= 0.5:
+            raise ValueError('Border must be less than half the image size')
+        super().__init__(command_queue, allocator)
+        self.template = template
+        self.border_pixels = round(border * min(image_shape[1], image_shape[2]))
+        self.slots['dirty'] = accel.IOSlot(image_shape, template.dtype)
+        self.slots['rank'] = accel.IOSlot((256,), np.uint32)
+
+    def _run(self):
+        pass
+
+    def _kth(self, k):
+        """k-th smallest (0-based) |x| as a uint32 bit pattern."""
+        dirty, hist = self.buffer('dirty'), self.buffer('rank')
+        prefix = 0
+        for p in (3, 2, 1, 0):
+            rc = lib().kimg_abs_histogram(*_image_args(dirty), self.border_pixels, p, prefix,
+                                          hist.ptr, self.command_queue.handle)
+            check(rc, 'kimg_abs_histogram')
+            h = hist.get(self.command_queue).astype(np.int64)
+            cum = np.cumsum(h)
+            digit = int(np.searchsorted(cum, k, side='right'))
+            k -= int(cum[digit - 1]) if digit else 0
+            prefix = (prefix << 8) | digit
+        return prefix
+
+    def __call__(self, **kwargs):
+        self.bind(**kwargs)
+        self.ensure_all_bound()
+        dirty = self.buffer('dirty')
+        P, H, W = dirty.shape
+        bp = self.border_pixels
+        n = (H - 2 * bp) * (W - 2 * bp) * P
+        lo_bits = self._kth((n - 1) // 2)
+        lo = np.array([lo_bits], np.uint32).view(np.float32)[0]
+        hi = lo
+        if n % 2 == 0:
+            out = self.buffer('rank')
+            rc = lib().kimg_abs_count_le(*_image_args(dirty), bp, float(lo), out.ptr,
+                                         self.command_queue.handle)
+            check(rc, 'kimg_abs_count_le')
+            res = out.get(self.command_queue)
+            if int(res[0]) <= n // 2:          # the upper middle element is the next value up
+                hi = np.array([res[1]], np.uint32).view(np.float32)[0]
+        median = (lo + hi) / np.float32(2)     # np.median of float32 data (clean.py:942)
+        return median * np.float32(_MEDIAN_TO_RMS)
+
+
+class _CleanStepTemplate:
+    def __init__(self, context, dtype, num_polarizations, tuning=None):
+        types.require_float32(dtype, type(self).__name__)
+        lib()
+        self.context = context
+        self.dtype = np.dtype(dtype)
+        self.num_polarizations = num_polarizations
+
+
+def _tile_shape(image_shape, border_pixels):
+    return (accel.divup(image_shape[1] - 2 * border_pixels, TILE),
+            accel.divup(image_shape[2] - 2 * border_pixels, TILE))
+
+
+class _UpdateTilesTemplate(_CleanStepTemplate):
+    """clean.py:356-395."""
+    def __init__(self, context, dtype, num_polarizations, mode, tuning=None):
+        super().__init__(context, dtype, num_polarizations, tuning)
+        self.mode = mode
+        self.tilex = self.tiley = TILE
+
+    def instantiate(self, *args, **kwargs):
+        return _UpdateTiles(self, *args, **kwargs)
+
+
+class _UpdateTiles(accel.Operation):
+    """Peak (value and position) of every 32x32 tile intersecting a window
+    (clean.py:398-480).  Slots **dirty**, **tile_max** [ty][tx], **tile_pos** [ty][tx][2]."""
+
+    def __init__(self, template, command_queue, image_shape, border, allocator=None):
+        if image_shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        if border >= 0.5:
+            raise ValueError('Border must be less than half the image size')
+        super().__init__(command_queue, allocator)
+        self.template = template
+        self.border_pixels = round(border * min(image_shape[1], image_shape[2]))
+        ty, tx = _tile_shape(image_shape, self.border_pixels)
+        self.slots['dirty'] = accel.IOSlot(image_shape, template.dtype)
+        self.slots['tile_max'] = accel.IOSlot((ty, tx), template.dtype)
+        self.slots['tile_pos'] = accel.IOSlot((ty, tx, accel.Dimension(2, exact=True)), np.int32)
+
+    def _run(self):
+        pass
+
+    def __call__(self, x0, y0, x1, y1, **kwargs):
+        """Update all tiles intersected by the pixel range [x0, x1) x [y0, y1)."""
+        self.bind(**kwargs)
+        self.ensure_all_bound()
+        tile_max, tile_pos = self.buffer('tile_max'), self.buffer('tile_pos')
+        bp = self.border_pixels
+        x0 = max((x0 - bp) // TILE, 0)
+        y0 = max((y0 - bp) // TILE, 0)
+        x1 = min(accel.divup(x1 - bp, TILE), tile_max.shape[1])
+        y1 = min(accel.divup(y1 - bp, TILE), tile_max.shape[0])
+        if x0 < x1 and y0 < y1:
+            rc = lib().kimg_update_tiles(
+                *_image_args(self.buffer('dirty')), bp, self.template.mode,
+                tile_max.ptr, tile_pos.ptr, tile_max.shape[1], tile_max.shape[0],
+                x0, y0, x1, y1, self.command_queue.handle)
+            check(rc, 'kimg_update_tiles')
+
+
+class _FindPeakTemplate(_CleanStepTemplate):
+    """clean.py:483-513."""
+    def instantiate(self, *args, **kwargs):
+        return _FindPeak(self, *args, **kwargs)
+
+
+class _FindPeak(accel.Operation):
+    """Global peak from the per-tile peaks (clean.py:516-587)."""
+
+    def __init__(self, template, command_queue, image_shape, tile_shape, allocator=None):
+        if image_shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        super().__init__(command_queue, allocator)
+        self.template = template
+        pair = accel.Dimension(2, exact=True)
+        self.slots['dirty'] = accel.IOSlot(image_shape, template.dtype)
+        self.slots['tile_max'] = accel.IOSlot(tile_shape, template.dtype)
+        self.slots['tile_pos'] = accel.IOSlot(tuple(tile_shape) + (pair,), np.int32)
+        self.slots['peak_value'] = accel.IOSlot([1], template.dtype)
+        self.slots['peak_pos'] = accel.IOSlot([2], np.int32)
+        self.slots['peak_pixel'] = accel.IOSlot([template.num_polarizations], template.dtype)
+
+    def _run(self):
+        dirty = self.buffer('dirty')
+        tile_max = self.buffer('tile_max')
+        P, H, W = dirty.shape
+        rc = lib().kimg_find_peak(
+            dirty.ptr, W, H * W, P, tile_max.ptr, self.buffer('tile_pos').ptr,
+            tile_max.shape[1], tile_max.shape[0], self.buffer('peak_value').ptr,
+            self.buffer('peak_pos').ptr, self.buffer('peak_pixel').ptr,
+            self.command_queue.handle)
+        check(rc, 'kimg_find_peak')
+
+
+class _SubtractPsfTemplate(_CleanStepTemplate):
+    """clean.py:590-622."""
+    def instantiate(self, *args, **kwargs):
+        return _SubtractPsf(self, *args, **kwargs)
+
+
+class _SubtractPsf(accel.Operation):
+    """dirty[patch] -= loop_gain * peak_pixel * psf[centre patch]; model[pos] += ...
+    (clean.py:625-726)."""
+
+    def __init__(self, template, command_queue, loop_gain, image_shape, psf_shape,
+                 allocator=None):
+        super().__init__(command_queue, allocator)
+        if image_shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        if psf_shape[0] != template.num_polarizations:
+            raise ValueError('Mismatch in number of polarizations')
+        self.slots['dirty'] = accel.IOSlot(image_shape, template.dtype)
+        self.slots['model'] = accel.IOSlot(image_shape, template.dtype)
+        self.slots['psf'] = accel.IOSlot(psf_shape, template.dtype)
+        self.slots['peak_pixel'] = accel.IOSlot([template.num_polarizations], template.dtype)
+        self.loop_gain = loop_gain
+        self.template = template
+
+    def _run(self):
+        pass
+
+    def __call__(self, pos, psf_patch, **kwargs):
+        self.bind(**kwargs)
+        self.ensure_all_bound()
+        dirty, psf = self.buffer('dirty'), self.buffer('psf')
+        P, H, W = dirty.shape
+        rc = lib().kimg_subtract_psf(
+            dirty.ptr, self.buffer('model').ptr, W, H * W, W, H, P,
+            psf.ptr, psf.shape[2], psf.shape[1] * psf.shape[2], psf.shape[2], psf.shape[1],
+            psf_patch[2], psf_patch[1], self.buffer('peak_pixel').ptr,
+            pos[1], pos[0], self.loop_gain, self.command_queue.handle)
+        check(rc, 'kimg_subtract_psf')
+
+
+class CleanTemplate:
+    """clean.py:729-753."""
+    def __init__(self, context, clean_parameters, dtype, num_polarizations):
+        types.require_float32(dtype, 'CleanTemplate')
+        self.context = context
+        self.clean_parameters = clean_parameters
+        self.dtype = np.dtype(dtype)
+        self.num_polarizations = num_polarizations
+        self._update_tiles = _UpdateTilesTemplate(context, dtype, num_polarizations,
+                                                  clean_parameters.mode)
+        self._find_peak = _FindPeakTemplate(context, dtype, num_polarizations)
+        self._subtract_psf = _SubtractPsfTemplate(context, dtype, num_polarizations)
+
+    def instantiate(self, *args, **kwargs):
+        return Clean(self, *args, **kwargs)
+
+
+class Clean(accel.OperationSequence):
+    """CLEAN minor cycles (clean.py:756-891).  Slots: **dirty**, **model**, **psf**,
+    **tile_max**, **tile_pos**, **peak_value**, **peak_pos**, **peak_pixel**."""
+
+    def __init__(self, template, command_queue, image_parameters, allocator=None):
+        if image_parameters.fixed.real_dtype != template.dtype:
+            raise ValueError('dtype mismatch')
+        image_shape = (len(image_parameters.fixed.polarizations),
+                       image_parameters.pixels, image_parameters.pixels)
+        self.template = template
+        cp = template.clean_parameters
+        self._update_tiles = template._update_tiles.instantiate(
+            command_queue, image_shape, cp.border, allocator)
+        tile_shape = self._update_tiles.slots['tile_max'].shape
+        self._find_peak = template._find_peak.instantiate(
+            command_queue, image_shape, tile_shape, allocator)
+        self._subtract_psf = template._subtract_psf.instantiate(
+            command_queue, cp.loop_gain, image_shape, image_shape, allocator)
+        ops = [('update_tiles', self._update_tiles), ('find_peak', self._find_peak),
+               ('subtract_psf', self._subtract_psf)]
+        compounds = {
+            'dirty': ['update_tiles:dirty', 'find_peak:dirty', 'subtract_psf:dirty'],
+            'model': ['subtract_psf:model'],
+            'psf': ['subtract_psf:psf'],
+            'tile_max': ['update_tiles:tile_max', 'find_peak:tile_max'],
+            'tile_pos': ['update_tiles:tile_pos', 'find_peak:tile_pos'],
+            'peak_value': ['find_peak:peak_value'],
+            'peak_pos': ['find_peak:peak_pos'],
+            'peak_pixel': ['find_peak:peak_pixel', 'subtract_psf:peak_pixel'],
+        }
+        super().__init__(command_queue, ops, compounds, allocator=allocator)
+        self._state = accel.DeviceArray(
+            command_queue.context, (lib().kimg_clean_state_bytes(image_shape[0]) // 4,), np.int32)
+        self._log = None
+
+    def _run(self):
+        raise NotImplementedError('use __call__(psf_patch, threshold) or run_cycles')
+
+    def reset(self):
+        """Call after populating the buffers but before the first minor cycle (clean.py:842)."""
+        self.ensure_all_bound()
+        dirty = self.buffer('dirty')
+        self._update_tiles(0, 0, dirty.shape[2], dirty.shape[1])
+
+    def __call__(self, psf_patch, threshold=0.0):
+        """One minor cycle with a host round trip, as clean.py:848-891.  Returns
+        (peak_value, (y, x), loop_gain * pixel) or (None, None, None) below threshold."""
+        self.ensure_all_bound()
+        self._find_peak()
+        q = self.command_queue
+        peak_value = self.buffer('peak_value').get(q)
+        if peak_value[0] < threshold:
+            return None, None, None
+        peak_pos = tuple(int(x) for x in self.buffer('peak_pos').get(q))
+        peak_pixel = self.buffer('peak_pixel').get(q)
+        model_pixel = np.float32(self.template.clean_parameters.loop_gain) * peak_pixel
+        self._subtract_psf(peak_pos, psf_patch)
+        x0 = peak_pos[1] - psf_patch[2] // 2
+        y0 = peak_pos[0] - psf_patch[1] // 2
+        self._update_tiles(x0, y0, x0 + psf_patch[2], y0 + psf_patch[1])
+        return peak_value[0], peak_pos, model_pixel
+
+    def run_cycles(self, psf_patch, threshold, max_cycles):
+        """Up to `max_cycles` minor cycles entirely on the device (no host sync between
+        cycles).  Returns a list of (peak_value, (y, x), model_pixel) -- exactly what
+        `max_cycles` calls of :meth:`__call__` would have returned before the first None."""
+        self.ensure_all_bound()
+        if max_cycles <= 0:
+            return []
+        dirty, psf = self.buffer('dirty'), self.buffer('psf')
+        P, H, W = dirty.shape
+        cp = self.template.clean_parameters
+        if self._log is None or self._log.shape[0] < max_cycles:
+            self._log = accel.DeviceArray(self.command_queue.context, (max_cycles, 3 + P),
+                                          np.float32)
+        tile_max = self.buffer('tile_max')
+        rc = lib().kimg_clean_cycles(
+            dirty.ptr, self.buffer('model').ptr, W, H * W, W, H, P,
+            psf.ptr, psf.shape[2], psf.shape[1] * psf.shape[2], psf.shape[2], psf.shape[1],
+            psf_patch[2], psf_patch[1], self._update_tiles.border_pixels, cp.mode,
+            cp.loop_gain, threshold, tile_max.ptr, self.buffer('tile_pos').ptr,
+            tile_max.shape[1], tile_max.shape[0], max_cycles, self._state.ptr, self._log.ptr,
+            self.command_queue.handle)
+        check(rc, 'kimg_clean_cycles')
+        count = int(self._state.get(self.command_queue)[0])
+        log = self._log.get(self.command_queue)[:count]
+        pos = log[:, 1:3].copy().view(np.int32)
+        return [(log[i, 0], (int(pos[i, 0]), int(pos[i, 1])), log[i, 3:].copy())
+                for i in range(count)]

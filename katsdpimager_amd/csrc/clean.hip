@@ -1,0 +1,547 @@
+// Hogbom CLEAN kernels: per-tile peak, global peak, PSF subtract, PSF patch bound, the
+// radix-select passes of the noise estimate, and a device-resident minor-cycle loop.
+// Mirrors clean.py:123-163, 295-353, 451-480, 566-587, 683-726, 848-891 of the reference.
+//
+// Peak selection is BIT-EXACT with the reference host path (CleanHost, clean.py:946-1075):
+//  - within a tile: first strict maximum in row-major order (clean.py:953-958), and a tile
+//    with no positive metric keeps value 0 and the (x0, y0) initial position (clean.py:950);
+//  - across tiles: first maximum in row-major tile order (np.argmax, clean.py:1062);
+//  - subtraction is dirty -= (loop_gain*pixel) * psf with separately rounded multiply and
+//    subtract (clean.py:1044-1046): this file is built with -ffp-contract=off.
+#include "kimg_common.h"
+#include <limits.h>
+#include <string.h>
+
+namespace {
+
+constexpr int TILE = 32;            // clean.py:996
+
+struct best_t {
+    float value;
+    int idx;                        // row-major index; INT_MAX = none yet
+};
+
+__device__ inline bool better(const best_t &a, const best_t &b)
+{
+    return a.value > b.value || (a.value == b.value && a.idx < b.idx);
+}
+
+__device__ inline best_t wave_best(best_t b)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        best_t o;
+        o.value = __shfl_xor(b.value, off, WAVE);
+        o.idx = __shfl_xor(b.idx, off, WAVE);
+        if (better(o, b))
+            b = o;
+    }
+    return b;
+}
+
+// Block-wide argmax with the tie-break of better(); result valid in thread 0.
+__device__ inline best_t block_best(best_t b)
+{
+    __shared__ best_t scratch[16];
+    b = wave_best(b);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+        scratch[wv] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++)
+            if (better(scratch[w], b))
+                b = scratch[w];
+    }
+    return b;
+}
+
+template <int MODE>
+__device__ inline float clean_metric(const float *__restrict__ dirty, int64_t addr,
+                                     int64_t pol_stride, int P)
+{
+    if (MODE == KIMG_CLEAN_I)
+        return fabsf(dirty[addr]);
+    float value = 0.0f;                                // clean.py:962-964
+    for (int p = 0; p < P; p++) {
+        float pix = dirty[addr + p * pol_stride];
+        value += pix * pix;
+    }
+    return value;
+}
+
+// Scan tile (tx, ty): pixels [x0,x1) x [y0,y1); 256 threads, 4 pixels each in row-major order.
+template <int MODE>
+__device__ inline void tile_peak(const float *__restrict__ dirty, int64_t row_stride,
+                                 int64_t pol_stride, int width, int height, int P, int border,
+                                 int tx, int ty, float *__restrict__ tile_max,
+                                 int32_t *__restrict__ tile_pos, int tiles_x)
+{
+    const int x0 = tx * TILE + border, y0 = ty * TILE + border;
+    best_t b = {0.0f, INT_MAX};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = threadIdx.x + k * 256;
+        const int x = x0 + (idx & 31), y = y0 + (idx >> 5);
+        if (x < width - border && y < height - border) {
+            float v = clean_metric<MODE>(dirty, (int64_t) y * row_stride + x, pol_stride, P);
+            if (v > b.value) {
+                b.value = v;
+                b.idx = idx;
+            }
+        }
+    }
+    b = block_best(b);
+    if (threadIdx.x == 0) {
+        const int t = ty * tiles_x + tx;
+        tile_max[t] = b.value;
+        if (b.idx == INT_MAX) {             // clean.py:950 best_pos = (x0, y0)
+            tile_pos[2 * t] = x0;
+            tile_pos[2 * t + 1] = y0;
+        } else {
+            tile_pos[2 * t] = y0 + (b.idx >> 5);
+            tile_pos[2 * t + 1] = x0 + (b.idx & 31);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void update_tiles_kernel(
+    const float *__restrict__ dirty, int64_t row_stride, int64_t pol_stride, int width,
+    int height, int P, int border, float *__restrict__ tile_max, int32_t *__restrict__ tile_pos,
+    int tiles_x, int tile_x0, int tile_y0)
+{
+    tile_peak<MODE>(dirty, row_stride, pol_stride, width, height, P, border,
+                    tile_x0 + blockIdx.x, tile_y0 + blockIdx.y, tile_max, tile_pos, tiles_x);
+}
+
+// Global argmax over tiles; thread 0 returns the winning tile index (or -1 when no tiles).
+__device__ inline int peak_tile(const float *__restrict__ tile_max, int num_tiles, float &value)
+{
+    best_t b = {-1.0f, INT_MAX};
+    for (int i = threadIdx.x; i < num_tiles; i += blockDim.x) {
+        float v = tile_max[i];
+        if (v > b.value) {
+            b.value = v;
+            b.idx = i;
+        }
+    }
+    b = block_best(b);
+    value = b.value;
+    return b.idx == INT_MAX ? -1 : b.idx;
+}
+
+__global__ __launch_bounds__(1024) void find_peak_kernel(
+    const float *__restrict__ dirty, int64_t row_stride, int64_t pol_stride, int P,
+    const float *__restrict__ tile_max, const int32_t *__restrict__ tile_pos, int num_tiles,
+    float *__restrict__ peak_value, int32_t *__restrict__ peak_pos, float *__restrict__ peak_pixel)
+{
+    float value;
+    int t = peak_tile(tile_max, num_tiles, value);
+    if (threadIdx.x == 0 && t >= 0) {
+        const int y = tile_pos[2 * t], x = tile_pos[2 * t + 1];
+        *peak_value = value;
+        peak_pos[0] = y;
+        peak_pos[1] = x;
+        for (int p = 0; p < P; p++)
+            peak_pixel[p] = dirty[p * pol_stride + (int64_t) y * row_stride + x];
+    }
+}
+
+struct pixel_t { float v[4]; };
+
+__global__ __launch_bounds__(256) void subtract_psf_kernel(
+    float *__restrict__ dirty, float *__restrict__ model, int64_t row_stride, int64_t pol_stride,
+    int width, int height, int P, const float *__restrict__ psf, int64_t psf_row_stride,
+    int64_t psf_pol_stride, int psf_x0, int psf_y0, int patch_w, int patch_h,
+    const float *__restrict__ peak_pixel, int pos_x, int pos_y, int start_x, int start_y,
+    float loop_gain)
+{
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float scale[4];
+    for (int p = 0; p < P; p++)
+        scale[p] = loop_gain * peak_pixel[p];
+    if (gx == 0 && gy == 0)
+        for (int p = 0; p < P; p++)
+            model[p * pol_stride + (int64_t) pos_y * row_stride + pos_x] += scale[p];
+    if (gx >= patch_w || gy >= patch_h)
+        return;
+    const int x = start_x + gx, y = start_y + gy;
+    if (x < 0 || x >= width || y < 0 || y >= height)
+        return;
+    const int64_t pa = (int64_t) (psf_y0 + gy) * psf_row_stride + (psf_x0 + gx);
+    const int64_t ia = (int64_t) y * row_stride + x;
+    for (int p = 0; p < P; p++) {
+        const float t = scale[p] * psf[p * psf_pol_stride + pa];
+        dirty[p * pol_stride + ia] -= t;
+    }
+}
+
+// ---- device-resident minor cycles ------------------------------------------------------
+struct clean_state {
+    int count;          // cycles completed
+    int done;           // threshold reached
+    int pos_y, pos_x;
+    float scale[4];     // loop_gain * pixel at the current peak
+};
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
+    const float *__restrict__ dirty, float *__restrict__ model, int64_t row_stride,
+    int64_t pol_stride, int P, const float *__restrict__ tile_max,
+    const int32_t *__restrict__ tile_pos, int num_tiles, float loop_gain, float threshold,
+    clean_state *__restrict__ state, float *__restrict__ log)
+{
+    if (state->done)
+        return;
+    float value;
+    int t = peak_tile(tile_max, num_tiles, value);
+    if (threadIdx.x != 0)
+        return;
+    if (t < 0 || value < threshold) {           // clean.py:1065-1066
+        state->done = 1;
+        return;
+    }
+    const int y = tile_pos[2 * t], x = tile_pos[2 * t + 1];
+    float *entry = log + (int64_t) state->count * (3 + P);
+    entry[0] = value;
+    entry[1] = __int_as_float(y);
+    entry[2] = __int_as_float(x);
+    state->pos_y = y;
+    state->pos_x = x;
+    for (int p = 0; p < P; p++) {
+        const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
+        const float s = loop_gain * dirty[a];   // clean.py:1044
+        state->scale[p] = s;
+        entry[3 + p] = s;
+        model[a] += s;                          // clean.py:1047
+    }
+    state->count += 1;
+}
+
+// One workgroup per 32x32 block of the tile lattice that the PSF patch can touch: subtract
+// the scaled PSF from the block's pixels that lie in the patch, then (if the block is a real
+// tile) rescan the tile.  Fuses _subtract_psf + _update_tile of clean.py:1067-1074.
+template <int MODE>
+__global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
+    float *__restrict__ dirty, int64_t row_stride, int64_t pol_stride, int width, int height,
+    int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+    int psf_w, int psf_h, int patch_w, int patch_h, int border,
+    float *__restrict__ tile_max, int32_t *__restrict__ tile_pos, int tiles_x, int tiles_y,
+    const clean_state *__restrict__ state)
+{
+    if (state->done)
+        return;
+    const int px = state->pos_x, py = state->pos_y;
+    const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
+    // floor division: the lattice extends into the border with negative indices
+    const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
+    const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
+    const int tx = bx0 + (int) blockIdx.x, ty = by0 + (int) blockIdx.y;
+    const int ox = tx * TILE + border, oy = ty * TILE + border;
+    const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;  // psf index = image index + d
+    const bool is_tile = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;
+    float scale[4];
+    for (int p = 0; p < P; p++)
+        scale[p] = state->scale[p];
+
+    best_t b = {0.0f, INT_MAX};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = threadIdx.x + k * 256;
+        const int x = ox + (idx & 31), y = oy + (idx >> 5);
+        if (x < 0 || x >= width || y < 0 || y >= height)
+            continue;
+        const int64_t ia = (int64_t) y * row_stride + x;
+        const bool in_patch = x >= x0 && x < x0 + patch_w && y >= y0 && y < y0 + patch_h;
+        const bool in_tile = is_tile && x < width - border && y < height - border;
+        float metric = 0.0f;
+        if (MODE == KIMG_CLEAN_I) {
+            float d = dirty[ia];
+            if (in_patch) {
+                const float t = scale[0] * psf[(int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
+                d -= t;
+                dirty[ia] = d;
+                for (int p = 1; p < P; p++) {
+                    const float tp = scale[p] * psf[p * psf_pol_stride
+                                                    + (int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
+                    dirty[p * pol_stride + ia] -= tp;
+                }
+            }
+            metric = fabsf(d);
+        } else {
+            for (int p = 0; p < P; p++) {
+                float d = dirty[p * pol_stride + ia];
+                if (in_patch) {
+                    const float t = scale[p] * psf[p * psf_pol_stride
+                                                   + (int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
+                    d -= t;
+                    dirty[p * pol_stride + ia] = d;
+                }
+                metric += d * d;
+            }
+        }
+        if (in_tile && metric > b.value) {
+            b.value = metric;
+            b.idx = idx;
+        }
+    }
+    if (!is_tile)
+        return;
+    b = block_best(b);
+    if (threadIdx.x == 0) {
+        const int t = ty * tiles_x + tx;
+        tile_max[t] = b.value;
+        if (b.idx == INT_MAX) {
+            tile_pos[2 * t] = ox;
+            tile_pos[2 * t + 1] = oy;
+        } else {
+            tile_pos[2 * t] = oy + (b.idx >> 5);
+            tile_pos[2 * t + 1] = ox + (b.idx & 31);
+        }
+    }
+}
+
+// ---- PSF patch bound ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psf_patch_kernel(
+    const float *__restrict__ psf, int64_t row_stride, int64_t pol_stride, int P,
+    int min_x, int min_y, int max_x, int max_y, int mid_x, int mid_y, float threshold,
+    int32_t *__restrict__ bound)
+{
+    int dx = 0, dy = 0;
+    for (int y = min_y + blockIdx.y; y <= max_y; y += gridDim.y)
+        for (int x = min_x + blockIdx.x * blockDim.x + threadIdx.x; x <= max_x;
+             x += gridDim.x * blockDim.x) {
+            bool over = false;
+            for (int p = 0; p < P; p++)
+                over |= fabsf(psf[p * pol_stride + (int64_t) y * row_stride + x]) >= threshold;
+            if (over) {
+                dx = max(dx, abs(x - mid_x));
+                dy = max(dy, abs(y - mid_y));
+            }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dx = max(dx, __shfl_xor(dx, off, WAVE));
+        dy = max(dy, __shfl_xor(dy, off, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0 && (dx | dy)) {
+        atomicMax(&bound[0], dx);
+        atomicMax(&bound[1], dy);
+    }
+}
+
+// ---- noise estimate: radix select on the bit pattern of |x| ------------------------------
+__global__ __launch_bounds__(256) void abs_histogram_kernel(
+    const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
+    int height, int P, int border, int pass, uint32_t prefix, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t local[256];
+    local[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 8 * pass;
+    for (int p = 0; p < P; p++)
+        for (int y = border + blockIdx.y; y < height - border; y += gridDim.y)
+            for (int x = border + blockIdx.x * blockDim.x + threadIdx.x; x < width - border;
+                 x += gridDim.x * blockDim.x) {
+                uint32_t key = __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
+                               & 0x7fffffffu;
+                if (pass == 3 || (key >> (shift + 8)) == prefix)
+                    atomicAdd(&local[(key >> shift) & 255u], 1u);
+            }
+    __syncthreads();
+    if (local[threadIdx.x])
+        atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void abs_count_le_kernel(
+    const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
+    int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out)
+{
+    uint32_t count = 0, next = 0xffffffffu;
+    for (int p = 0; p < P; p++)
+        for (int y = border + blockIdx.y; y < height - border; y += gridDim.y)
+            for (int x = border + blockIdx.x * blockDim.x + threadIdx.x; x < width - border;
+                 x += gridDim.x * blockDim.x) {
+                uint32_t key = __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
+                               & 0x7fffffffu;
+                if (key <= value_bits)
+                    count++;
+                else
+                    next = min(next, key);
+            }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        count += __shfl_xor(count, off, WAVE);
+        next = min(next, (uint32_t) __shfl_xor((int) next, off, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (count)
+            atomicAdd(&out[0], count);
+        atomicMin(&out[1], next);
+    }
+}
+
+dim3 region_grid(int width, int height)
+{
+    int bx = kimg_divup(width, 256);
+    if (bx < 1) bx = 1;
+    int by = height < 2048 / bx ? height : 2048 / bx;
+    return dim3(bx, by > 0 ? by : 1);
+}
+
+} // namespace
+
+extern "C" int kimg_update_tiles(const float *dirty, int64_t row_stride, int64_t pol_stride,
+                                 int width, int height, int num_polarizations, int border,
+                                 int mode, float *tile_max, int32_t *tile_pos, int tiles_x,
+                                 int tiles_y, int tile_x0, int tile_y0, int tile_x1, int tile_y1,
+                                 void *stream)
+{
+    KIMG_CHECK_ARG(dirty && tile_max && tile_pos && width > 0 && height > 0);
+    KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && border >= 0);
+    KIMG_CHECK_ARG(tile_x0 >= 0 && tile_y0 >= 0 && tile_x1 <= tiles_x && tile_y1 <= tiles_y);
+    if (tile_x0 >= tile_x1 || tile_y0 >= tile_y1)
+        return 0;                                           // clean.py:462
+    dim3 g(tile_x1 - tile_x0, tile_y1 - tile_y0);
+    hipStream_t s = (hipStream_t) stream;
+    if (mode == KIMG_CLEAN_I)
+        update_tiles_kernel<KIMG_CLEAN_I><<<g, 256, 0, s>>>(
+            dirty, row_stride, pol_stride, width, height, num_polarizations, border, tile_max,
+            tile_pos, tiles_x, tile_x0, tile_y0);
+    else if (mode == KIMG_CLEAN_SUMSQ)
+        update_tiles_kernel<KIMG_CLEAN_SUMSQ><<<g, 256, 0, s>>>(
+            dirty, row_stride, pol_stride, width, height, num_polarizations, border, tile_max,
+            tile_pos, tiles_x, tile_x0, tile_y0);
+    else
+        return KIMG_EINVAL;
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_find_peak(const float *dirty, int64_t row_stride, int64_t pol_stride,
+                              int num_polarizations, const float *tile_max,
+                              const int32_t *tile_pos, int tiles_x, int tiles_y,
+                              float *peak_value, int32_t *peak_pos, float *peak_pixel,
+                              void *stream)
+{
+    KIMG_CHECK_ARG(dirty && tile_max && tile_pos && peak_value && peak_pos && peak_pixel);
+    KIMG_CHECK_ARG(tiles_x > 0 && tiles_y > 0 && num_polarizations >= 1);
+    find_peak_kernel<<<1, 1024, 0, (hipStream_t) stream>>>(
+        dirty, row_stride, pol_stride, num_polarizations, tile_max, tile_pos, tiles_x * tiles_y,
+        peak_value, peak_pos, peak_pixel);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride,
+                                 int64_t pol_stride, int width, int height, int num_polarizations,
+                                 const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                                 int psf_width, int psf_height, int patch_width, int patch_height,
+                                 const float *peak_pixel, int pos_x, int pos_y, float loop_gain,
+                                 void *stream)
+{
+    KIMG_CHECK_ARG(dirty && model && psf && peak_pixel);
+    KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4);
+    KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
+                   && patch_height <= psf_height);
+    KIMG_CHECK_ARG(pos_x >= 0 && pos_x < width && pos_y >= 0 && pos_y < height);
+    const int psf_x0 = psf_width / 2 - patch_width / 2;     // clean.py:699-700
+    const int psf_y0 = psf_height / 2 - patch_height / 2;
+    dim3 g(kimg_divup(patch_width, 64), kimg_divup(patch_height, 4));
+    subtract_psf_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf,
+        psf_row_stride, psf_pol_stride, psf_x0, psf_y0, patch_width, patch_height, peak_pixel,
+        pos_x, pos_y, pos_x - patch_width / 2, pos_y - patch_height / 2, loop_gain);
+    return kimg_launch_status();
+}
+
+extern "C" size_t kimg_clean_state_bytes(int num_polarizations)
+{
+    (void) num_polarizations;
+    return sizeof(clean_state);
+}
+
+extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
+                                 int64_t pol_stride, int width, int height, int num_polarizations,
+                                 const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                                 int psf_width, int psf_height, int patch_width, int patch_height,
+                                 int border, int mode, float loop_gain, float threshold,
+                                 float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
+                                 int max_cycles, void *state, float *log, void *stream)
+{
+    KIMG_CHECK_ARG(dirty && model && psf && tile_max && tile_pos && state && log);
+    KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && max_cycles >= 0);
+    KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
+                   && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
+    KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(state, 0, sizeof(clean_state), s));
+    clean_state *st = static_cast<clean_state *>(state);
+    dim3 g(kimg_divup(patch_width, TILE) + 1, kimg_divup(patch_height, TILE) + 1);
+    const int num_tiles = tiles_x * tiles_y;
+    for (int i = 0; i < max_cycles; i++) {
+        if (mode == KIMG_CLEAN_I) {
+            cycle_find_peak_kernel<KIMG_CLEAN_I><<<1, 1024, 0, s>>>(
+                dirty, model, row_stride, pol_stride, num_polarizations, tile_max, tile_pos,
+                num_tiles, loop_gain, threshold, st, log);
+            cycle_subtract_update_kernel<KIMG_CLEAN_I><<<g, 256, 0, s>>>(
+                dirty, row_stride, pol_stride, width, height, num_polarizations, psf,
+                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
+                border, tile_max, tile_pos, tiles_x, tiles_y, st);
+        } else {
+            cycle_find_peak_kernel<KIMG_CLEAN_SUMSQ><<<1, 1024, 0, s>>>(
+                dirty, model, row_stride, pol_stride, num_polarizations, tile_max, tile_pos,
+                num_tiles, loop_gain, threshold, st, log);
+            cycle_subtract_update_kernel<KIMG_CLEAN_SUMSQ><<<g, 256, 0, s>>>(
+                dirty, row_stride, pol_stride, width, height, num_polarizations, psf,
+                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
+                border, tile_max, tile_pos, tiles_x, tiles_y, st);
+        }
+    }
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_psf_patch(const float *psf, int64_t row_stride, int64_t pol_stride,
+                              int num_polarizations, int min_x, int min_y, int max_x, int max_y,
+                              int mid_x, int mid_y, float threshold, int32_t *bound, void *stream)
+{
+    KIMG_CHECK_ARG(psf && bound && num_polarizations >= 1 && max_x >= min_x && max_y >= min_y);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(bound, 0, 2 * sizeof(int32_t), s));
+    psf_patch_kernel<<<region_grid(max_x - min_x + 1, max_y - min_y + 1), 256, 0, s>>>(
+        psf, row_stride, pol_stride, num_polarizations, min_x, min_y, max_x, max_y, mid_x, mid_y,
+        threshold, bound);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_abs_histogram(const float *image, int64_t row_stride, int64_t pol_stride,
+                                  int width, int height, int num_polarizations, int border,
+                                  int pass, uint32_t prefix, uint32_t *hist, void *stream)
+{
+    KIMG_CHECK_ARG(image && hist && pass >= 0 && pass <= 3 && border >= 0);
+    KIMG_CHECK_ARG(width > 2 * border && height > 2 * border && num_polarizations >= 1);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
+    abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border), 256, 0, s>>>(
+        image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t pol_stride,
+                                 int width, int height, int num_polarizations, int border,
+                                 float value, uint32_t *out, void *stream)
+{
+    KIMG_CHECK_ARG(image && out && border >= 0 && num_polarizations >= 1);
+    KIMG_CHECK_ARG(width > 2 * border && height > 2 * border);
+    hipStream_t s = (hipStream_t) stream;
+    static const uint32_t init[2] = {0u, 0xffffffffu};
+    KIMG_HIP(hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, s));
+    union { float f; uint32_t u; } conv;
+    conv.f = value;
+    const uint32_t bits = conv.u;
+    abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border), 256, 0, s>>>(
+        image, row_stride, pol_stride, width, height, num_polarizations, border,
+        bits & 0x7fffffffu, out);
+    return kimg_launch_status();
+}

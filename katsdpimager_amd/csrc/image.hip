@@ -1,0 +1,234 @@
+// Image-plane kernels: grid<->layer quadrant copies, layer<->image (fftshift + W-stack phase
+// + n-term + taper), scale, add_image, apply_primary_beam.  All HBM-bound streams.
+// Mirrors image.py:153-180, 351-367, 439-458, 539-558, 649-673, 716-740 of the reference.
+// The arithmetic order follows the reference HOST classes (image.py:781-799, 836-848) so that
+// float32 results agree to rounding; this file is built with -ffp-contract=off.
+#include "kimg_common.h"
+
+namespace {
+
+struct c64 { float re, im; };
+
+// layer[ly][lx] = grid cell with the same (centred) frequency, or 0 outside the grid.
+// Fuses the reference's layer.zero() + 4 copy_region calls (image.py:660-671).
+__global__ __launch_bounds__(256) void grid_to_layer_kernel(
+    float2 *__restrict__ layer, int G, const float2 *__restrict__ grid, int64_t grid_row_stride,
+    int Gg)
+{
+    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ly = blockIdx.y;
+    if (lx >= G)
+        return;
+    const int half = Gg / 2;
+    // centred coordinates of this layer pixel: 0..G/2-1 positive, G/2.. negative
+    const int cx = lx < G - half ? lx : lx - G;
+    const int cy = ly < G - half ? ly : ly - G;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (cx >= -half && cx < half && cy >= -half && cy < half)
+        v = grid[(int64_t) (cy + half) * grid_row_stride + (cx + half)];
+    layer[(int64_t) ly * G + lx] = v;
+}
+
+__global__ __launch_bounds__(256) void layer_to_grid_kernel(
+    float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, const float2 *__restrict__ layer,
+    int G)
+{
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gy = blockIdx.y;
+    if (gx >= Gg)
+        return;
+    const int half = Gg / 2;
+    int lx = gx - half, ly = gy - half;
+    if (lx < 0) lx += G;
+    if (ly < 0) ly += G;
+    grid[(int64_t) gy * grid_row_stride + gx] = layer[(int64_t) ly * G + lx];
+}
+
+// e^{2 pi i x} with the reference's range reduction (fast_math.py:14-15).
+__device__ inline void expj2pi(float x, float &c, float &s)
+{
+    float r = x - rintf(x);
+    sincospif(2.0f * r, &s, &c);
+}
+
+// n(l, m) following GridToImageHost.__call__ (image.py:785-790) operation by operation.
+__device__ inline float lm_coord(int i, float lm_scale, float lm_bias)
+{
+    return (float) i * lm_scale + lm_bias;
+}
+
+// One thread: one image pixel pair... kept simple: one pixel per thread, x fastest.
+// image[y][x] += Re(layer[(y+G/2)%G][(x+G/2)%G] * e^{2 pi i w (n-1)}) * n / (k[y] k[x])
+__global__ __launch_bounds__(256) void layer_to_image_kernel(
+    float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ layer, int G,
+    const float *__restrict__ kernel1d, float lm_scale, float lm_bias, float w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= G)
+        return;
+    const int half = G / 2;
+    const int sx = x < half ? x + half : x - half;
+    const int sy = y < half ? y + half : y - half;
+    const float2 v = layer[(int64_t) sy * G + sx];
+    const float l = lm_coord(x, lm_scale, lm_bias);
+    const float m = lm_coord(y, lm_scale, lm_bias);
+    const float l2 = l * l, m2 = m * m;
+    const float n = sqrtf(1.0f - (m2 + l2));
+    float c, s;
+    expj2pi(w * (n - 1.0f), c, s);
+    const float rotated = v.x * c - v.y * s;
+    const float taper = kernel1d[y] * kernel1d[x];
+    image[(int64_t) y * image_row_stride + x] += (rotated * n) / taper;
+}
+
+// layer[(y+G/2)%G][(x+G/2)%G] = image[y][x] / (k[y] k[x] n) * e^{-2 pi i w (n-1)}
+__global__ __launch_bounds__(256) void image_to_layer_kernel(
+    float2 *__restrict__ layer, const float *__restrict__ image, int64_t image_row_stride, int G,
+    const float *__restrict__ kernel1d, float lm_scale, float lm_bias, float w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= G)
+        return;
+    const int half = G / 2;
+    const int sx = x < half ? x + half : x - half;
+    const int sy = y < half ? y + half : y - half;
+    const float l = lm_coord(x, lm_scale, lm_bias);
+    const float m = lm_coord(y, lm_scale, lm_bias);
+    const float l2 = l * l, m2 = m * m;
+    const float n = sqrtf(1.0f - (m2 + l2));
+    float c, s;
+    expj2pi(-w * (n - 1.0f), c, s);
+    const float taper = kernel1d[y] * kernel1d[x];
+    const float v = image[(int64_t) y * image_row_stride + x] / (taper * n);
+    layer[(int64_t) sy * G + sx] = make_float2(v * c, v * s);
+}
+
+struct scale_t { float v[4]; };
+
+__global__ __launch_bounds__(256) void scale_kernel(
+    float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width, int num_pols,
+    scale_t scale)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width)
+        return;
+    int64_t addr = (int64_t) blockIdx.y * row_stride + x;
+    for (int p = 0; p < num_pols; p++, addr += pol_stride)
+        image[addr] *= scale.v[p];
+}
+
+__global__ __launch_bounds__(256) void add_image_kernel(
+    float *__restrict__ dest, int64_t dest_row_stride, int64_t dest_pol_stride,
+    const float *__restrict__ src, int64_t src_row_stride, int64_t src_pol_stride,
+    int width, int num_pols)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width)
+        return;
+    int64_t d = (int64_t) blockIdx.y * dest_row_stride + x;
+    int64_t s = (int64_t) blockIdx.y * src_row_stride + x;
+    for (int p = 0; p < num_pols; p++, d += dest_pol_stride, s += src_pol_stride)
+        dest[d] += src[s];
+}
+
+__global__ __launch_bounds__(256) void apply_primary_beam_kernel(
+    float *__restrict__ image, int64_t row_stride, int64_t pol_stride,
+    const float *__restrict__ beam_power, int64_t beam_row_stride, int width, int num_pols,
+    float threshold, float replacement)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width)
+        return;
+    const float beam = beam_power[(int64_t) blockIdx.y * beam_row_stride + x];
+    int64_t addr = (int64_t) blockIdx.y * row_stride + x;
+    for (int p = 0; p < num_pols; p++, addr += pol_stride)
+        image[addr] = beam < threshold ? replacement : image[addr] / beam;
+}
+
+} // namespace
+
+extern "C" int kimg_grid_to_layer(void *layer, int layer_size, const void *grid,
+                                  int64_t grid_row_stride, int grid_size, void *stream)
+{
+    KIMG_CHECK_ARG(layer && grid && layer_size > 0 && grid_size > 0 && grid_size <= layer_size);
+    KIMG_CHECK_ARG(layer_size % 2 == 0 && grid_size % 2 == 0);      // image.py:655-656
+    dim3 g(kimg_divup(layer_size, 256), layer_size);
+    grid_to_layer_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        (float2 *) layer, layer_size, (const float2 *) grid, grid_row_stride, grid_size);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
+                                  const void *layer, int layer_size, void *stream)
+{
+    KIMG_CHECK_ARG(layer && grid && layer_size > 0 && grid_size > 0 && grid_size <= layer_size);
+    KIMG_CHECK_ARG(layer_size % 2 == 0 && grid_size % 2 == 0);
+    dim3 g(kimg_divup(grid_size, 256), grid_size);
+    layer_to_grid_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        (float2 *) grid, grid_row_stride, grid_size, (const float2 *) layer, layer_size);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_layer_to_image(float *image, int64_t image_row_stride, const void *layer,
+                                   int size, const float *kernel1d, float lm_scale,
+                                   float lm_bias, float w, void *stream)
+{
+    KIMG_CHECK_ARG(image && layer && kernel1d && size > 0 && size % 2 == 0);   // image.py:127-128
+    dim3 g(kimg_divup(size, 256), size);
+    layer_to_image_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        image, image_row_stride, (const float2 *) layer, size, kernel1d, lm_scale, lm_bias, w);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_image_to_layer(void *layer, const float *image, int64_t image_row_stride,
+                                   int size, const float *kernel1d, float lm_scale,
+                                   float lm_bias, float w, void *stream)
+{
+    KIMG_CHECK_ARG(image && layer && kernel1d && size > 0 && size % 2 == 0);
+    dim3 g(kimg_divup(size, 256), size);
+    image_to_layer_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        (float2 *) layer, image, image_row_stride, size, kernel1d, lm_scale, lm_bias, w);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_scale(float *image, int64_t row_stride, int64_t pol_stride, int width,
+                          int height, int num_polarizations, const float *scale_host, void *stream)
+{
+    KIMG_CHECK_ARG(image && scale_host && width > 0 && height > 0);
+    if (num_polarizations < 1 || num_polarizations > 4)
+        return KIMG_EUNSUPPORTED;
+    scale_t sc = {};
+    for (int p = 0; p < num_polarizations; p++)
+        sc.v[p] = scale_host[p];
+    dim3 g(kimg_divup(width, 256), height);
+    scale_kernel<<<g, 256, 0, (hipStream_t) stream>>>(image, row_stride, pol_stride, width,
+                                                      num_polarizations, sc);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_add_image(float *dest, int64_t dest_row_stride, int64_t dest_pol_stride,
+                              const float *src, int64_t src_row_stride, int64_t src_pol_stride,
+                              int width, int height, int num_polarizations, void *stream)
+{
+    KIMG_CHECK_ARG(dest && src && width > 0 && height > 0 && num_polarizations > 0);
+    dim3 g(kimg_divup(width, 256), height);
+    add_image_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        dest, dest_row_stride, dest_pol_stride, src, src_row_stride, src_pol_stride, width,
+        num_polarizations);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_apply_primary_beam(float *image, int64_t row_stride, int64_t pol_stride,
+                                       const float *beam_power, int64_t beam_row_stride,
+                                       int width, int height, int num_polarizations,
+                                       float threshold, float replacement, void *stream)
+{
+    KIMG_CHECK_ARG(image && beam_power && width > 0 && height > 0 && num_polarizations > 0);
+    dim3 g(kimg_divup(width, 256), height);
+    apply_primary_beam_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
+        image, row_stride, pol_stride, beam_power, beam_row_stride, width, num_polarizations,
+        threshold, replacement);
+    return kimg_launch_status();
+}

@@ -1,0 +1,37 @@
+// Shared helpers for the libkimg HIP sources (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/kimg.h"
+
+#define KIMG_CHECK_ARG(cond) do { if (!(cond)) return KIMG_EINVAL; } while (0)
+
+// Return the negated hipError_t of the last launch on failure.
+static inline int kimg_launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int) e;
+}
+
+#define KIMG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return -(int) e_; } while (0)
+
+static inline int kimg_divup(int64_t a, int64_t b) { return (int) ((a + b - 1) / b); }
+
+constexpr int WAVE = 64;    // gfx950 wavefront
+
+// Wave-wide sum by DPP-backed shuffles; result valid in every lane.
+__device__ inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, WAVE);
+    return v;
+}

@@ -1,0 +1,284 @@
+"""Convolutional gridding / degridding operators on MI355X.
+
+Operator surface of the reference's ``katsdpimager.grid`` (GridderTemplate /
+Gridder, DegridderTemplate / Degridder, ConvolutionKernel[Device];
+grid.py:344-463, 549-1029), re-implemented on top of libkimg.so.  The device
+kernels are not Romein-style thread-per-cell kernels: see
+``csrc/grid_mfma.hip`` for the MFMA moving-window design.
+
+The combined anti-aliasing x W-projection kernel table is computed on the
+host in float64 exactly as the reference does for both its CPU and GPU paths
+(grid.py:235-334: the device classes also build the table with numpy and
+upload it).
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import accel, types
+from ._lib import lib, check
+
+
+# --------------------------------------------------------------------------
+# Kernel table
+# --------------------------------------------------------------------------
+def _i0_ratio(x, beta):
+    return np.i0(x) / np.i0(beta)
+
+
+def kaiser_bessel(x, width, beta):
+    """Kaiser-Bessel window with support [-width/2, width/2] (grid.py:136-155)."""
+    x = np.asarray(x, np.float64)
+    t = 1.0 - np.square(2.0 * x / width)
+    inside = t >= 0
+    out = np.zeros_like(t)
+    out[inside] = _i0_ratio(beta * np.sqrt(t[inside]), beta)
+    return out
+
+
+def kaiser_bessel_fourier(f, width, beta):
+    """Continuous Fourier transform of :func:`kaiser_bessel` (grid.py:158-184):
+    width/I0(beta) * sinc(sqrt((width f)^2 - (beta/pi)^2)), analytically continued."""
+    f = np.asarray(f, np.float64)
+    q = np.square(width * f) - (beta / math.pi) ** 2
+    root = np.sqrt(q.astype(np.complex128))
+    return (width / np.i0(beta)) * np.sinc(root).real
+
+
+def antialias_beta(antialias_width):
+    """Shape parameter: first null of the taper just outside the image (grid.py:373-378)."""
+    return 1.2 * math.pi * math.sqrt(0.25 * antialias_width ** 2 - 1.0)
+
+
+def make_kernel_table(cell_wavelengths, ws, width, oversample, antialias_width,
+                      image_oversample, beta):
+    """Separable AA x W kernel table, complex128 [len(ws)][oversample][width].
+
+    Same construction as the reference's ``antialias_w_kernel`` (grid.py:235-334):
+    sample aa(l) * exp(2 pi i (w (l^2/2 + 5 l^4/24) + shift l)) on an
+    ``image_oversample``-times finer image grid, DFT to uv space, crop to
+    ``oversample*width`` samples and deinterleave the sub-pixel phases (reversed,
+    because the sub-pixel index is that of the visibility, not of the tap).
+    """
+    ws = np.asarray(ws, np.float64)
+    n_out = oversample * width
+    if n_out % 2:
+        raise ValueError('oversample * kernel_width must be even')
+    n_img = n_out * image_oversample
+    step = 1.0 / (width * cell_wavelengths * image_oversample)
+    l = (np.arange(n_img) - n_img // 2) * step
+    aa = cell_wavelengths * kaiser_bessel_fourier(l * cell_wavelengths, antialias_width, beta)
+    half_subcell = -0.5 * cell_wavelengths / oversample
+    l2 = l * l
+    phase = np.outer(-ws, -0.5 * l2 - (5.0 / 24.0) * l2 * l2) + half_subcell * l
+    phase -= np.rint(phase)
+    img = aa * np.exp(2j * np.pi * phase)
+    uv = np.fft.fft(np.fft.ifftshift(img, axes=-1), axis=-1) * step
+    uv = np.concatenate([uv[..., -(n_out // 2):], uv[..., :n_out // 2]], axis=-1)
+    table = uv.reshape(ws.shape + (width, oversample))[..., ::-1]
+    return np.ascontiguousarray(np.swapaxes(table, -1, -2))
+
+
+class ConvolutionKernel:
+    """Separable convolution kernel with metadata (grid.py:344-423)."""
+
+    def __init__(self, image_parameters, grid_parameters, data=None):
+        self.grid_parameters = grid_parameters
+        fixed = grid_parameters.fixed
+        shape = (grid_parameters.w_planes, fixed.oversample, fixed.kernel_width)
+        self.data = np.empty(shape, np.complex64) if data is None else data
+        cell_wavelengths = float(image_parameters.cell_size / image_parameters.wavelength)
+        slice_wl = float(fixed.max_w / (grid_parameters.w_slices * image_parameters.wavelength))
+        plane_wl = slice_wl / grid_parameters.w_planes
+        self.beta = antialias_beta(fixed.antialias_width)
+        w_edge = 0.5 * (slice_wl - plane_wl)
+        ws = np.linspace(-w_edge, w_edge, grid_parameters.w_planes)
+        self.data[:] = make_kernel_table(cell_wavelengths, ws, fixed.kernel_width,
+                                         fixed.oversample, fixed.antialias_width,
+                                         fixed.image_oversample, self.beta)
+
+    def taper(self, N, out=None):
+        """Image-plane correction for an N-pixel image (grid.py:404-423)."""
+        x = np.arange(N) / N - 0.5
+        fixed = self.grid_parameters.fixed
+        values = kaiser_bessel_fourier(x, fixed.antialias_width, self.beta)
+        values = values * np.sinc(x / fixed.oversample)
+        if out is None:
+            return values
+        out[:] = values
+        return out
+
+
+class ConvolutionKernelDevice(ConvolutionKernel):
+    """:class:`ConvolutionKernel` with a device copy (grid.py:426-463).  The table is
+    stored unpadded: the HIP kernels pad rows to the window width when staging to LDS."""
+
+    def __init__(self, context, image_parameters, grid_parameters, pad=0, allocator=None):
+        super().__init__(image_parameters, grid_parameters)
+        if allocator is None:
+            allocator = accel.DeviceAllocator(context)
+        self.padded_data = allocator.allocate(self.data.shape, np.complex64)
+        queue = context.create_command_queue()
+        self.padded_data.set(queue, self.data)
+        queue.finish()
+        self.pad = 0
+
+    @property
+    def bin_size(self):
+        return self.data.shape[-1]
+
+
+# --------------------------------------------------------------------------
+# Operators
+# --------------------------------------------------------------------------
+GRID_VARIANTS = {'auto': 0, 'generic': 1, 'mfma': 2}
+
+
+class GridderTemplate:
+    """grid.py:549-653.  ``tuning`` may hold ``{'variant': 'auto'|'generic'|'mfma'}``;
+    there is no autotuner -- the kernel geometry is fixed by the MFMA tile shape."""
+
+    def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
+        types.require_float32(fixed_image_parameters.real_dtype, 'GridderTemplate')
+        lib()
+        self.context = context
+        self.fixed_image_parameters = fixed_image_parameters
+        self.fixed_grid_parameters = fixed_grid_parameters
+        self.variant = GRID_VARIANTS[(tuning or {}).get('variant', 'auto')]
+        self.kernel_pad = 0
+
+    def instantiate(self, *args, **kwargs):
+        return Gridder(self, *args, **kwargs)
+
+
+class VisOperation(accel.Operation):
+    """Operations that hold visibilities in device buffers (grid.py:656-703).
+
+    Slots: **uv** int16 [max_vis][4] (u, v, sub_u, sub_v); **w_plane** int16 [max_vis];
+    **vis** complex64 [max_vis][pols] (pre-multiplied by statistical weights).
+    """
+
+    def __init__(self, command_queue, num_polarizations, max_vis, allocator=None):
+        super().__init__(command_queue, allocator)
+        self.max_vis = max_vis
+        self.slots['uv'] = accel.IOSlot((max_vis, accel.Dimension(4, exact=True)), np.int16)
+        self.slots['w_plane'] = accel.IOSlot((max_vis,), np.int16)
+        self.slots['vis'] = accel.IOSlot(
+            (max_vis, accel.Dimension(num_polarizations, exact=True)), np.complex64)
+        self._num_vis = 0
+
+    @property
+    def num_vis(self):
+        return self._num_vis
+
+    @num_vis.setter
+    def num_vis(self, n):
+        if n < 0 or n > self.max_vis:
+            raise ValueError('Number of visibilities {} is out of range 0..{}'.format(
+                n, self.max_vis))
+        self._num_vis = n
+
+
+class GridDegrid(VisOperation):
+    """Common part of :class:`Gridder` and :class:`Degridder` (grid.py:706-773)."""
+
+    def __init__(self, template, command_queue, array_parameters,
+                 image_parameters, grid_parameters, max_vis, allocator=None):
+        assert image_parameters.fixed == template.fixed_image_parameters
+        assert grid_parameters.fixed == template.fixed_grid_parameters
+        num_polarizations = len(image_parameters.fixed.polarizations)
+        super().__init__(command_queue, num_polarizations, max_vis, allocator)
+        self.convolve_kernel = ConvolutionKernelDevice(
+            template.context, image_parameters, grid_parameters, template.kernel_pad)
+        # Longest baseline must leave the whole footprint inside the grid (grid.py:753-761)
+        max_uv_src = float(array_parameters.longest_baseline / image_parameters.cell_size)
+        kernel_size = self.convolve_kernel.padded_data.shape[-1]
+        grid_pixels = 2 * (int(max_uv_src) + kernel_size // 2 + 1)
+        if grid_pixels > image_parameters.pixels:
+            raise ValueError('image_oversample is too small '
+                             'to capture all visibilities in the UV plane')
+        self.template = template
+        self.image_parameters = image_parameters
+        self.grid_parameters = grid_parameters
+        self.slots['grid'] = accel.IOSlot(
+            (num_polarizations, grid_pixels, grid_pixels), image_parameters.fixed.complex_dtype)
+
+    def parameters(self):
+        return {'grid_parameters': self.grid_parameters,
+                'image_parameters': self.image_parameters}
+
+    def _kernel_args(self):
+        table = self.convolve_kernel.padded_data
+        return (table.ptr, table.shape[0], table.shape[1], table.shape[2])
+
+
+class Gridder(GridDegrid):
+    """Instantiation of :class:`GridderTemplate` (grid.py:776-867).
+
+    Extra slot **weights_grid** float32 [pols][G][G]: density weights looked up per
+    visibility.  ``__call__`` adds ``num_vis`` visibilities to **grid**.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.slots['weights_grid'] = accel.IOSlot(self.slots['grid'].shape, np.float32)
+        num_pols = self.slots['grid'].shape[0]
+        nbytes = lib().kimg_grid_workspace_bytes(self.max_vis, num_pols)
+        self._workspace = None
+        self._workspace_bytes = nbytes
+        if nbytes:
+            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8)
+
+    def _run(self):
+        grid = self.buffer('grid')
+        wg = self.buffer('weights_grid')
+        P, G = grid.shape[0], grid.shape[1]
+        table, W, OV, K = self._kernel_args()
+        rc = lib().kimg_grid(
+            grid.ptr, G, G * G, G, P,
+            wg.ptr, G, G * G,
+            self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('vis').ptr,
+            self.num_vis, table, W, OV, K,
+            self._workspace.ptr if self._workspace is not None else None,
+            self._workspace_bytes, self.template.variant, self.command_queue.handle)
+        check(rc, 'kimg_grid')
+
+
+class DegridderTemplate:
+    """grid.py:870-970."""
+
+    def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
+        types.require_float32(fixed_image_parameters.real_dtype, 'DegridderTemplate')
+        lib()
+        self.context = context
+        self.fixed_image_parameters = fixed_image_parameters
+        self.fixed_grid_parameters = fixed_grid_parameters
+        self.kernel_pad = 0
+
+    def instantiate(self, *args, **kwargs):
+        return Degridder(self, *args, **kwargs)
+
+
+class Degridder(GridDegrid):
+    """Instantiation of :class:`DegridderTemplate` (grid.py:973-1029).
+
+    Extra slot **weights** float32 [max_vis][pols] (statistical weights).  ``__call__``
+    subtracts the visibilities predicted from **grid** from **vis** in place.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        num_pols = self.slots['grid'].shape[0]
+        self.slots['weights'] = accel.IOSlot(
+            (self.max_vis, accel.Dimension(num_pols, exact=True)), np.float32)
+
+    def _run(self):
+        grid = self.buffer('grid')
+        P, G = grid.shape[0], grid.shape[1]
+        table, W, OV, K = self._kernel_args()
+        rc = lib().kimg_degrid(
+            grid.ptr, G, G * G, G, P,
+            self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('weights').ptr,
+            self.buffer('vis').ptr, self.num_vis, table, W, OV, K, self.command_queue.handle)
+        check(rc, 'kimg_degrid')

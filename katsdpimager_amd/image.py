@@ -1,0 +1,286 @@
+"""Image-domain operators and grid<->image conversion on MI355X.
+
+Operator surface of the reference's ``katsdpimager.image`` (LayerToImage,
+ImageToLayer, Scale, AddImage, ApplyPrimaryBeam, GridImageTemplate,
+GridToImage, ImageToGrid; image.py:15-740) on libkimg.so + rocFFT.
+"""
+import ctypes
+
+import numpy as np
+
+from . import accel, types
+from ._lib import lib, check
+
+
+def _pol_ptr(array, pol):
+    """Device address of polarization `pol` of a [P][H][W] array."""
+    return array.ptr + pol * array.shape[1] * array.shape[2] * array.dtype.itemsize
+
+
+class _LayerImageTemplate:
+    """image.py:15-86."""
+    def __init__(self, context, real_dtype, tuning=None):
+        types.require_float32(real_dtype, type(self).__name__)
+        lib()
+        self.context = context
+        self.real_dtype = np.dtype(real_dtype)
+
+
+class _LayerImage(accel.Operation):
+    """Conversion between a "layer" (raw FFT of one uv plane, DC in the corner) and the
+    stacked image (image.py:89-180).  Slots: **layer** complex [G][G], **image** real
+    [P][G][G], **kernel1d** real [G]."""
+
+    def __init__(self, template, command_queue, shape, lm_scale, lm_bias, allocator=None):
+        if len(shape) != 3 or shape[-1] != shape[-2]:
+            raise ValueError('shape must be square, not {}'.format(shape))
+        if shape[-1] % 2 != 0:
+            raise ValueError('image size must be even, not {}'.format(shape[-1]))
+        super().__init__(command_queue, allocator)
+        self.template = template
+        complex_dtype = types.real_to_complex(template.real_dtype)
+        self.slots['layer'] = accel.IOSlot(shape[-2:], complex_dtype)
+        self.slots['image'] = accel.IOSlot(shape, template.real_dtype)
+        self.slots['kernel1d'] = accel.IOSlot((shape[-1],), template.real_dtype)
+        self.lm_scale = lm_scale
+        self.lm_bias = lm_bias
+        self.w = 0
+        self.polarization = 0
+
+    def set_w(self, w):
+        self.w = w
+
+    def set_polarization(self, polarization):
+        if polarization < 0 or polarization >= self.slots['image'].shape[0]:
+            raise IndexError('polarization index out of range')
+        self.polarization = polarization
+
+
+class LayerToImageTemplate(_LayerImageTemplate):
+    def instantiate(self, *args, **kwargs):
+        return LayerToImage(self, *args, **kwargs)
+
+
+class LayerToImage(_LayerImage):
+    """image += Re(layer e^{2 pi i w (n-1)}) n / taper, with fftshift (image.py:203-229)."""
+    def _run(self):
+        image = self.buffer('image')
+        size = image.shape[-1]
+        rc = lib().kimg_layer_to_image(
+            _pol_ptr(image, self.polarization), size, self.buffer('layer').ptr, size,
+            self.buffer('kernel1d').ptr, self.lm_scale, self.lm_bias, self.w,
+            self.command_queue.handle)
+        check(rc, 'kimg_layer_to_image')
+
+
+class ImageToLayerTemplate(_LayerImageTemplate):
+    def instantiate(self, *args, **kwargs):
+        return ImageToLayer(self, *args, **kwargs)
+
+
+class ImageToLayer(_LayerImage):
+    """layer = image / (taper n) e^{-2 pi i w (n-1)} (image.py:252-278)."""
+    def _run(self):
+        image = self.buffer('image')
+        size = image.shape[-1]
+        rc = lib().kimg_image_to_layer(
+            self.buffer('layer').ptr, _pol_ptr(image, self.polarization), size, size,
+            self.buffer('kernel1d').ptr, self.lm_scale, self.lm_bias, self.w,
+            self.command_queue.handle)
+        check(rc, 'kimg_image_to_layer')
+
+
+class _ImageTemplate:
+    def __init__(self, context, dtype, num_polarizations, tuning=None):
+        types.require_float32(dtype, type(self).__name__)
+        lib()
+        self.context = context
+        self.dtype = np.dtype(dtype)
+        self.num_polarizations = num_polarizations
+
+
+def _check_image_shape(template, shape):
+    if len(shape) != 3:
+        raise ValueError('Wrong number of dimensions in shape')
+    if shape[0] != template.num_polarizations:
+        raise ValueError('Mismatch in number of polarizations')
+
+
+class ScaleTemplate(_ImageTemplate):
+    """image.py:281-314."""
+    def instantiate(self, *args, **kwargs):
+        return Scale(self, *args, **kwargs)
+
+
+class Scale(accel.Operation):
+    """data[p] *= scale_factor[p] (image.py:317-367)."""
+    def __init__(self, template, command_queue, shape, allocator=None):
+        super().__init__(command_queue, allocator)
+        self.template = template
+        _check_image_shape(template, shape)
+        self.slots['data'] = accel.IOSlot(shape, template.dtype)
+        self.scale_factor = np.zeros((shape[0],), template.dtype)
+
+    def set_scale_factor(self, scale_factor):
+        self.scale_factor[:] = scale_factor
+
+    def _run(self):
+        data = self.buffer('data')
+        P, H, W = data.shape
+        sf = np.ascontiguousarray(self.scale_factor, np.float32)
+        rc = lib().kimg_scale(data.ptr, W, H * W, W, H, P,
+                              sf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                              self.command_queue.handle)
+        check(rc, 'kimg_scale')
+
+
+class AddImageTemplate(_ImageTemplate):
+    """image.py:370-403."""
+    def instantiate(self, *args, **kwargs):
+        return AddImage(self, *args, **kwargs)
+
+
+class AddImage(accel.Operation):
+    """dest += src (image.py:406-458)."""
+    def __init__(self, template, command_queue, shape, allocator=None):
+        super().__init__(command_queue, allocator)
+        self.template = template
+        _check_image_shape(template, shape)
+        self.slots['src'] = accel.IOSlot(shape, template.dtype)
+        self.slots['dest'] = accel.IOSlot(shape, template.dtype)
+
+    def _run(self):
+        src, dest = self.buffer('src'), self.buffer('dest')
+        P, H, W = src.shape
+        rc = lib().kimg_add_image(dest.ptr, W, H * W, src.ptr, W, H * W, W, H, P,
+                                  self.command_queue.handle)
+        check(rc, 'kimg_add_image')
+
+
+class ApplyPrimaryBeamTemplate(_ImageTemplate):
+    """image.py:461-494."""
+    def instantiate(self, *args, **kwargs):
+        return ApplyPrimaryBeam(self, *args, **kwargs)
+
+
+class ApplyPrimaryBeam(accel.Operation):
+    """data = beam < threshold ? replacement : data / beam (image.py:497-558)."""
+    def __init__(self, template, command_queue, shape, threshold, replacement, allocator=None):
+        super().__init__(command_queue, allocator)
+        self.template = template
+        _check_image_shape(template, shape)
+        self.slots['data'] = accel.IOSlot(shape, template.dtype)
+        self.slots['beam_power'] = accel.IOSlot(shape[1:], template.dtype)
+        self.threshold = threshold
+        self.replacement = replacement
+
+    def _run(self):
+        data = self.buffer('data')
+        P, H, W = data.shape
+        rc = lib().kimg_apply_primary_beam(
+            data.ptr, W, H * W, self.buffer('beam_power').ptr, W, W, H, P,
+            self.threshold, self.replacement, self.command_queue.handle)
+        check(rc, 'kimg_apply_primary_beam')
+
+
+class FftPlan:
+    """rocFFT 2-D C2C plan (stands in for katsdpsigproc.fft.FftTemplate, image.py:599)."""
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.dtype_src = self.dtype_dest = np.dtype(np.complex64)
+        handle = ctypes.c_void_p()
+        check(lib().kimg_fft_plan_create(ctypes.byref(handle), self.shape[0], self.shape[1]),
+              'kimg_fft_plan_create')
+        self._handle = handle
+
+    def execute(self, command_queue, layer, inverse):
+        check(lib().kimg_fft_exec(self._handle, layer.ptr, 1 if inverse else -1,
+                                  command_queue.handle), 'kimg_fft_exec')
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib().kimg_fft_plan_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class GridImageTemplate:
+    """Grid <-> image through a complex-to-complex transform keeping the real part
+    (image.py:561-606).  The grid need not be Hermitian."""
+
+    def __init__(self, context, real_dtype):
+        types.require_float32(real_dtype, 'GridImageTemplate')
+        self.context = context
+        self.real_dtype = np.dtype(real_dtype)
+        self.layer_to_image = LayerToImageTemplate(context, real_dtype)
+        self.image_to_layer = ImageToLayerTemplate(context, real_dtype)
+
+    def make_fft_plan(self, shape_layer, padded_shape_layer=None):
+        return FftPlan(shape_layer)
+
+    def instantiate_grid_to_image(self, *args, **kwargs):
+        return GridToImage(self, *args, **kwargs)
+
+    def instantiate_image_to_grid(self, *args, **kwargs):
+        return ImageToGrid(self, *args, **kwargs)
+
+
+class _GridImage(accel.Operation):
+    def __init__(self, template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
+                 layer_image_template, allocator=None):
+        super().__init__(command_queue, allocator)
+        self.template = template
+        self._fft = fft_plan
+        shape_image = (shape_grid[0],) + tuple(fft_plan.shape)
+        self._layer_image = layer_image_template.instantiate(
+            command_queue, shape_image, lm_scale, lm_bias, allocator)
+        for name in ('layer', 'image', 'kernel1d'):
+            self.slots[name] = self._layer_image.slots[name]
+        self.slots['grid'] = accel.IOSlot(shape_grid, np.complex64)
+        if shape_grid[1] != shape_grid[2] or shape_grid[1] % 2:
+            raise ValueError('grid must be square with even size')     # image.py:655-656
+
+    def set_w(self, w):
+        self._layer_image.set_w(w)
+
+
+class GridToImage(_GridImage):
+    """Per polarization: centred grid -> corner-DC layer (zero padded), inverse FFT,
+    layer_to_image accumulate (image.py:609-673)."""
+    def __init__(self, template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
+                 allocator=None):
+        super().__init__(template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
+                         template.layer_to_image, allocator)
+
+    def _run(self):
+        grid, layer = self.buffer('grid'), self.buffer('layer')
+        P, Gg, _ = grid.shape
+        G = layer.shape[0]
+        for pol in range(P):
+            check(lib().kimg_grid_to_layer(layer.ptr, G, _pol_ptr(grid, pol), Gg, Gg,
+                                           self.command_queue.handle), 'kimg_grid_to_layer')
+            self._fft.execute(self.command_queue, layer, inverse=True)
+            self._layer_image.set_polarization(pol)
+            self._layer_image()
+
+
+class ImageToGrid(_GridImage):
+    """Per polarization: image_to_layer, forward FFT, layer corners -> centred grid
+    (image.py:676-740)."""
+    def __init__(self, template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
+                 allocator=None):
+        super().__init__(template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
+                         template.image_to_layer, allocator)
+
+    def _run(self):
+        grid, layer = self.buffer('grid'), self.buffer('layer')
+        P, Gg, _ = grid.shape
+        G = layer.shape[0]
+        for pol in range(P):
+            self._layer_image.set_polarization(pol)
+            self._layer_image()
+            self._fft.execute(self.command_queue, layer, inverse=False)
+            check(lib().kimg_layer_to_grid(_pol_ptr(grid, pol), Gg, Gg, layer.ptr, G,
+                                           self.command_queue.handle), 'kimg_layer_to_grid')

@@ -1,0 +1,351 @@
+"""Top-level imaging facade: the drop-in boundary of the hot path.
+
+Same method surface as the reference's ``katsdpimager.imaging.Imaging`` /
+``ImagingHost`` (imaging.py:81-588), so that the per-channel driver
+(``frontend.process_channel``, frontend.py:465-658, and ``make_weights`` /
+``make_dirty``, frontend.py:86-142) runs on it unchanged.  Everything executes
+on one HIP stream; all buffers live in HBM for the whole channel.
+
+Additions over the reference surface (both optional for a caller):
+``clean_cycles`` runs a batch of minor cycles on the device without host
+round trips, and ``set_sky_arrays`` feeds the continuum predictor from arrays.
+"""
+import numpy as np
+
+from . import accel, clean, grid, image, predict, weight
+
+
+class ImagingTemplate:
+    """Holds all operator templates (imaging.py:11-51)."""
+
+    def __init__(self, context, array_parameters, fixed_image_parameters,
+                 weight_parameters, fixed_grid_parameters, clean_parameters, tuning=None):
+        self.context = context
+        self.array_parameters = array_parameters
+        self.fixed_image_parameters = fixed_image_parameters
+        self.weight_parameters = weight_parameters
+        self.fixed_grid_parameters = fixed_grid_parameters
+        self.clean_parameters = clean_parameters
+        dtype = fixed_image_parameters.real_dtype
+        num_pols = len(fixed_image_parameters.polarizations)
+        tuning = tuning or {}
+        self.weights = weight.WeightsTemplate(context, weight_parameters.weight_type, num_pols)
+        self.gridder = grid.GridderTemplate(context, fixed_image_parameters,
+                                            fixed_grid_parameters, tuning.get('gridder'))
+        self.predict = predict.PredictTemplate(context, dtype, num_pols)
+        self.grid_image = image.GridImageTemplate(context, dtype)
+        self.psf_patch = clean.PsfPatchTemplate(context, dtype, num_pols)
+        self.noise_est = clean.NoiseEstTemplate(context, dtype, num_pols)
+        self.clean = clean.CleanTemplate(context, clean_parameters, dtype, num_pols)
+        self.scale = image.ScaleTemplate(context, dtype, num_pols)
+        self.add_image = image.AddImageTemplate(context, dtype, num_pols)
+        self.apply_primary_beam = image.ApplyPrimaryBeamTemplate(context, dtype, num_pols)
+        self.degridder = grid.DegridderTemplate(
+            context, fixed_image_parameters, fixed_grid_parameters) \
+            if fixed_grid_parameters.degrid else None
+
+    def instantiate(self, *args, **kwargs):
+        return Imaging(self, *args, **kwargs)
+
+
+def _get_uv(coords):
+    """(N, 4) int16 view of the contiguous ``uv`` and ``sub_uv`` fields (imaging.py:63-78)."""
+    dt = coords.dtype
+    if dt['uv'] != np.dtype(('i2', (2,))) or dt['sub_uv'] != np.dtype(('i2', (2,))):
+        raise TypeError('uv and sub_uv must be pairs of int16')
+    if dt.fields['sub_uv'][1] != dt.fields['uv'][1] + 4:
+        raise TypeError('uv and sub_uv must be adjacent in the record')
+    alias = np.dtype(dict(names=['uv_sub_uv'], formats=[('i2', (4,))],
+                          offsets=[dt.fields['uv'][1]], itemsize=dt.itemsize))
+    return np.asarray(coords).view(alias)['uv_sub_uv']
+
+
+class Imaging(accel.OperationSequence):
+    """All operations and buffers for imaging one channel (imaging.py:81-419)."""
+
+    def __init__(self, template, command_queue, image_parameters, grid_parameters,
+                 max_vis, max_sources, major, allocator=None):
+        assert image_parameters.fixed == template.fixed_image_parameters
+        assert grid_parameters.fixed == template.fixed_grid_parameters
+        self.template = template
+        lm_scale = float(image_parameters.pixel_size)
+        lm_bias = -0.5 * image_parameters.pixels * lm_scale
+        num_pols = len(image_parameters.fixed.polarizations)
+        pixels = image_parameters.pixels
+        image_shape = (num_pols, pixels, pixels)
+        fft_plan = template.grid_image.make_fft_plan(image_shape[1:], image_shape[1:])
+        cp = template.clean_parameters
+        degrid = grid_parameters.fixed.degrid
+
+        self._gridder = template.gridder.instantiate(
+            command_queue, template.array_parameters, image_parameters, grid_parameters,
+            max_vis, allocator)
+        self._continuum_predict = template.predict.instantiate(
+            command_queue, image_parameters, grid_parameters, max_vis, max_sources, allocator)
+        grid_shape = self._gridder.slots['grid'].shape
+        self._weights = template.weights.instantiate(command_queue, grid_shape, max_vis, allocator)
+        self._weights.robustness = template.weight_parameters.robustness
+        self._grid_to_image = template.grid_image.instantiate_grid_to_image(
+            command_queue, grid_shape, lm_scale, lm_bias, fft_plan, allocator)
+        self._psf_patch = template.psf_patch.instantiate(command_queue, image_shape, allocator)
+        self._noise_est = template.noise_est.instantiate(
+            command_queue, image_shape, cp.border, allocator)
+        self._clean = template.clean.instantiate(command_queue, image_parameters, allocator)
+        self._scale = template.scale.instantiate(command_queue, image_shape, allocator)
+        self._add_image = template.add_image.instantiate(command_queue, image_shape, allocator)
+        self._apply_primary_beam_model = template.apply_primary_beam.instantiate(
+            command_queue, image_shape, 0.0, 0.0, allocator)
+        self._apply_primary_beam_dirty = template.apply_primary_beam.instantiate(
+            command_queue, image_shape, 0.0, np.nan, allocator)
+
+        context = template.context
+        taper1d = accel.DeviceArray(context, (pixels,), image_parameters.fixed.real_dtype)
+        taper1d.set(command_queue, self._gridder.convolve_kernel.taper(pixels))
+        self._grid_to_image.bind(kernel1d=taper1d)
+        self._image_to_grid = None
+        if degrid:
+            self._predict = template.degridder.instantiate(
+                command_queue, template.array_parameters, image_parameters, grid_parameters,
+                max_vis, allocator)
+            untaper1d = accel.DeviceArray(context, (pixels,), image_parameters.fixed.real_dtype)
+            untaper1d.set(command_queue, self._predict.convolve_kernel.taper(pixels))
+            self._image_to_grid = template.grid_image.instantiate_image_to_grid(
+                command_queue, self._predict.slots['grid'].shape, lm_scale, lm_bias, fft_plan,
+                allocator)
+            self._image_to_grid.bind(kernel1d=untaper1d)
+        else:
+            max_components = min(pixels**2, (major - 1) * cp.minor)
+            self._predict = template.predict.instantiate(
+                command_queue, image_parameters, grid_parameters, max_vis, max_components,
+                allocator)
+        self._model_components = {}
+        operations = [
+            ('weights', self._weights), ('gridder', self._gridder), ('predict', self._predict),
+            ('continuum_predict', self._continuum_predict),
+            ('grid_to_image', self._grid_to_image), ('psf_patch', self._psf_patch),
+            ('noise_est', self._noise_est), ('clean', self._clean), ('scale', self._scale),
+            ('add_image', self._add_image),
+            ('apply_primary_beam_model', self._apply_primary_beam_model),
+            ('apply_primary_beam_dirty', self._apply_primary_beam_dirty)]
+        # buffer names of imaging.py:185-209
+        compounds = {
+            'weights': ['predict:weights', 'continuum_predict:weights'],
+            'weights_grid': ['weights:grid', 'gridder:weights_grid'],
+            'uv': ['gridder:uv', 'predict:uv', 'continuum_predict:uv'],
+            'w_plane': ['gridder:w_plane', 'predict:w_plane', 'continuum_predict:w_plane'],
+            'vis': ['gridder:vis', 'predict:vis', 'continuum_predict:vis'],
+            'grid': ['gridder:grid', 'grid_to_image:grid'],
+            'layer': ['grid_to_image:layer'],
+            'dirty': ['grid_to_image:image', 'noise_est:dirty', 'clean:dirty', 'scale:data',
+                      'add_image:dest', 'apply_primary_beam_dirty:data'],
+            'model': ['clean:model', 'apply_primary_beam_model:data', 'add_image:src'],
+            'psf': ['clean:psf', 'psf_patch:psf'],
+            'tile_max': ['clean:tile_max'], 'tile_pos': ['clean:tile_pos'],
+            'peak_value': ['clean:peak_value'], 'peak_pos': ['clean:peak_pos'],
+            'peak_pixel': ['clean:peak_pixel'],
+            'beam_power': ['apply_primary_beam_model:beam_power',
+                           'apply_primary_beam_dirty:beam_power'],
+        }
+        if 'uv' in self._weights.slots:
+            compounds['weights'].insert(0, 'weights:weights')
+            compounds['uv'].insert(0, 'weights:uv')
+        if degrid:
+            operations.append(('image_to_grid', self._image_to_grid))
+            compounds['degrid'] = ['predict:grid', 'image_to_grid:grid']
+            compounds['layer'].append('image_to_grid:layer')
+            compounds['model'].append('image_to_grid:image')
+        super().__init__(command_queue, operations, compounds, allocator=allocator)
+        self._bound = False
+
+    def __call__(self, **kwargs):
+        raise NotImplementedError()
+
+    def ensure_all_bound(self):
+        super().ensure_all_bound()
+        self._bound = True
+
+    def _ready(self):
+        if not self._bound:
+            self.ensure_all_bound()
+
+    # ---- visibilities ---------------------------------------------------------------
+    @property
+    def num_vis(self):
+        return self._gridder.num_vis
+
+    @num_vis.setter
+    def num_vis(self, value):
+        self._gridder.num_vis = value
+        self._predict.num_vis = value
+        self._continuum_predict.num_vis = value
+
+    def _set_buffer(self, name, N, data, columns=None):
+        if len(data) != N:
+            raise ValueError('Lengths do not match')
+        self._ready()
+        device = self.buffer(name)
+        data = np.asarray(data)
+        if columns is None:
+            device.set_region(self.command_queue, data, np.s_[:N], np.s_[:], blocking=True)
+        else:
+            device.set_region(self.command_queue, data, (np.s_[:N], columns), np.s_[:],
+                              blocking=True)
+
+    def clear_weights(self):
+        self._ready()
+        self._weights.clear()
+
+    def grid_weights(self, uv, weights):
+        if 'uv' not in self._weights.slots:
+            return
+        self._set_buffer('uv', len(uv), uv, np.s_[:2])
+        self._set_buffer('weights', len(uv), weights)
+        self._weights.grid(len(uv))
+
+    def finalize_weights(self):
+        self._ready()
+        return self._weights.finalize()
+
+    def clear_grid(self):
+        self._ready()
+        self.buffer('grid').zero(self.command_queue)
+
+    def clear_dirty(self):
+        self._ready()
+        self.buffer('dirty').zero(self.command_queue)
+
+    def clear_model(self):
+        self._ready()
+        self.buffer('model').zero(self.command_queue)
+        self._model_components.clear()
+
+    def set_coordinates(self, coords):
+        """``coords``: structured array with fields ``uv``, ``sub_uv`` (2 x int16 each,
+        adjacent) and ``w_plane`` (imaging.py:294-305)."""
+        N = self.num_vis
+        if len(coords) != N:
+            raise ValueError('Lengths do not match')
+        self._set_buffer('uv', N, _get_uv(coords))
+        self._set_buffer('w_plane', N, np.ascontiguousarray(coords['w_plane']))
+
+    def set_vis(self, vis):
+        self._set_buffer('vis', self.num_vis, vis)
+
+    def set_weights(self, weights):
+        """Statistical weights for prediction."""
+        self._set_buffer('weights', self.num_vis, weights)
+
+    # ---- operations -------------------------------------------------------------------
+    def grid(self):
+        self._ready()
+        self._gridder()
+
+    def predict(self, w):
+        self._ready()
+        if not self.template.fixed_grid_parameters.degrid:
+            self._predict.set_w(w)
+        self._predict()
+
+    def continuum_predict(self, w):
+        self._ready()
+        self._continuum_predict.set_w(w)
+        self._continuum_predict()
+
+    def set_sky_arrays(self, lmn, flux):
+        """Continuum model as arrays (l, m, n-1) / flux[P]; see predict.Predict."""
+        self._ready()
+        self._continuum_predict.set_sky_arrays(lmn, flux)
+
+    def grid_to_image(self, w):
+        self._ready()
+        self._grid_to_image.set_w(w)
+        self._grid_to_image()
+
+    def model_to_grid(self, w):
+        if not self._image_to_grid:
+            raise RuntimeError('Can only use model_to_grid with degridding')
+        self._ready()
+        self._image_to_grid.set_w(w)
+        self._image_to_grid()
+
+    def model_to_predict(self):
+        if self.template.fixed_grid_parameters.degrid:
+            raise RuntimeError('Can only use model_to_predict with direct prediction')
+        self._ready()
+        self._predict.set_sky_image(self._model_components)
+
+    def scale_dirty(self, scale_factor):
+        self._ready()
+        self._scale.set_scale_factor(scale_factor)
+        self._scale()
+
+    def add_model_to_dirty(self):
+        self._ready()
+        self._add_image()
+
+    def apply_primary_beam(self, threshold):
+        """Divide model and dirty images by the primary beam power (imaging.py:362-367)."""
+        self._ready()
+        self._apply_primary_beam_model.threshold = threshold
+        self._apply_primary_beam_model()
+        self._apply_primary_beam_dirty.threshold = threshold
+        self._apply_primary_beam_dirty()
+
+    def dirty_to_psf(self):
+        """Swap the dirty and PSF buffers (imaging.py:370-373)."""
+        self._ready()
+        dirty = self.buffer('dirty')
+        psf = self.buffer('psf')
+        self.bind(dirty=psf, psf=dirty)
+
+    def psf_patch(self):
+        self._ready()
+        cp = self.template.clean_parameters
+        return self._psf_patch(cp.psf_cutoff, cp.psf_limit)
+
+    def noise_est(self):
+        self._ready()
+        return self._noise_est()
+
+    def clean_reset(self):
+        self._ready()
+        self._clean.reset()
+
+    def _record(self, peak_pos, model_pixel):
+        if peak_pos in self._model_components:
+            self._model_components[peak_pos] = self._model_components[peak_pos] + model_pixel
+        else:
+            self._model_components[peak_pos] = model_pixel
+
+    def clean_cycle(self, psf_patch, threshold=0.0):
+        """One minor cycle; returns the peak metric or None (imaging.py:389-396)."""
+        self._ready()
+        peak_value, peak_pos, model_pixel = self._clean(psf_patch, threshold)
+        if peak_pos is not None:
+            self._record(peak_pos, model_pixel)
+        return peak_value
+
+    def clean_cycles(self, psf_patch, threshold, max_cycles):
+        """Up to `max_cycles` minor cycles without host round trips; returns the list of
+        peak metrics (shorter than `max_cycles` iff the threshold was reached)."""
+        self._ready()
+        values = []
+        for peak_value, peak_pos, model_pixel in self._clean.run_cycles(
+                psf_patch, threshold, max_cycles):
+            self._record(peak_pos, model_pixel)
+            values.append(peak_value)
+        return values
+
+    # ---- buffers -----------------------------------------------------------------------
+    def get_buffer(self, name):
+        """Contents of a buffer as a numpy array (imaging.py:399-401)."""
+        self._ready()
+        return self.buffer(name).get(self.command_queue)
+
+    def set_buffer(self, name, data):
+        self._ready()
+        self.buffer(name).set(self.command_queue, data)
+
+    def free_buffer(self, name):
+        if name in self.slots:
+            self.slots[name].bind(None)

@@ -1,0 +1,621 @@
+"""GPU parity tests: the HIP path (through the C ABI and the operator classes)
+against the oracle and the committed golden vectors.  Run with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): bit-exact for index / peak selection;
+norm-wise max|a-b|/max|b| <= 1e-5 for float32 grids and images; the
+reference's own 5e-4-class tolerance for DFT prediction (test_predict.py:92).
+"""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from helpers import context_queue, make_params, relerr
+from oracle import kimg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GRID_TOL = 1e-5
+
+
+def _gridder(c, variant, max_vis=1280):
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    ip, gp, ap = make_params(c)
+    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': variant})
+    fn = template.instantiate(q, ap, ip, gp, max_vis)
+    fn.ensure_all_bound()
+    return fn, q
+
+
+def _run_gridder(fn, q, t):
+    n = len(t['uv'])
+    fn.buffer('grid').zero(q)
+    wg = np.zeros(fn.buffer('weights_grid').shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    fn.buffer('weights_grid').set(q, wg)
+    fn.num_vis = n
+    fn.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+    fn.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+    fn.buffer('vis').set_region(q, t['vis'], np.s_[:n], np.s_[:])
+    fn()
+    return fn.buffer('grid').get(q)
+
+
+@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8'])
+def test_gridder_vs_golden(golden, name, variant):
+    """G2: reference GridderHost output on the test_grid.py track recipe."""
+    c = gi.GRID_CONFIGS[name]
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, variant, max_vis=2048)
+    actual = _run_gridder(fn, q, t)
+    expected = gi.middle(golden('g2_grid_' + name)['grid'], actual.shape)
+    assert relerr(actual, expected) < GRID_TOL
+
+
+@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('P', [1, 2, 3, 4])
+def test_gridder_bruteforce(variant, P):
+    """test_grid.py:91-112 (do_grid) at the reference test's own size (256^2, K=28, 32 planes,
+    1000 vis): float64 brute force as the expectation, norm-wise 1e-5."""
+    c = gi.make_config(256, 0.0001, 0.01, P, 28, 32, grid_cover=180, n_vis=1000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, variant)
+    actual = _run_gridder(fn, q, t)
+    kernel = fn.convolve_kernel.data
+    G = actual.shape[-1]
+    expected = np.zeros(actual.shape, np.complex128)
+    uv_bias = (28 - 1) // 2 - G // 2
+    for i in range(c['n_vis']):
+        k = np.conj(np.outer(kernel[t['w_plane'][i], t['sub_uv'][i, 1], :],
+                             kernel[t['w_plane'][i], t['sub_uv'][i, 0], :]).astype(np.complex128))
+        u = t['uv'][i, 0] - uv_bias
+        v = t['uv'][i, 1] - uv_bias
+        wu = t['uv'][i, 0] + t['weights_grid'].shape[2] // 2
+        wv = t['uv'][i, 1] + t['weights_grid'].shape[1] // 2
+        for j in range(P):
+            expected[j, v:v + 28, u:u + 28] += (t['vis'][i, j].astype(np.complex128)
+                                                * t['weights_grid'][j, wv, wu] * k)
+    assert relerr(actual, expected) < GRID_TOL
+    # and against the float32 oracle
+    G_or = np.zeros(actual.shape, np.complex64)
+    wg = np.zeros(actual.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(kernel, G_or, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(actual, G_or) < GRID_TOL
+
+
+@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+def test_gridder_edge_cases(variant):
+    """Empty input (grid.py:810-811), a single visibility, odd counts, batches that are not a
+    multiple of 64, large jumps between consecutive visibilities, repeated positions."""
+    c = gi.make_config(256, 0.0001, 0.01, 1, 28, 32, grid_cover=180, n_vis=1000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, variant, max_vis=4096)
+    kernel = fn.convolve_kernel.data
+    wg = np.zeros(fn.buffer('grid').shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    rs = np.random.RandomState(5)
+    for n in (0, 1, 2, 63, 65, 129, 777):
+        sel = np.sort(rs.choice(1000, n, replace=False)) if n else np.zeros(0, int)
+        sub = {k: (t[k][sel] if k != 'weights_grid' else t[k]) for k in t}
+        actual = _run_gridder(fn, q, sub) if n else None
+        if n == 0:
+            fn.buffer('grid').zero(q)
+            fn.num_vis = 0
+            fn()
+            assert not np.any(fn.buffer('grid').get(q))
+            continue
+        expected = np.zeros(actual.shape, np.complex64)
+        orc.grid(kernel, expected, wg, sub['uv'], sub['sub_uv'], sub['w_plane'], sub['vis'])
+        assert relerr(actual, expected) < GRID_TOL, n
+    # adversarial: uniformly random positions (no locality) + all at one position
+    n = 3000
+    adv = dict(uv=rs.randint(-90, 90, (n, 2)).astype(np.int16),
+               sub_uv=rs.randint(0, 8, (n, 2)).astype(np.int16),
+               w_plane=rs.randint(0, 32, n).astype(np.int16), weights_grid=t['weights_grid'],
+               vis=(rs.standard_normal((n, 1)) + 1j * rs.standard_normal((n, 1))).astype(np.complex64))
+    adv['uv'][2000:] = adv['uv'][2000]
+    actual = _run_gridder(fn, q, adv)
+    expected = np.zeros(actual.shape, np.complex64)
+    orc.grid(kernel, expected, wg, adv['uv'], adv['sub_uv'], adv['w_plane'], adv['vis'])
+    assert relerr(actual, expected) < GRID_TOL
+    with pytest.raises(ValueError):
+        fn.num_vis = 5000          # grid.py:700-702
+
+
+def test_gridder_too_small_image():
+    """grid.py:759-761."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(256, 0.0001, 0.01, 1, 28, 32)
+    ip, gp, ap = make_params(c, longest_baseline=0.390625 * 120)
+    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed)
+    with pytest.raises(ValueError):
+        template.instantiate(q, ap, ip, gp, 100)
+
+
+@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8'])
+def test_degridder_vs_golden(golden, name):
+    """G3: reference DegridderHost residuals (rtol 1e-5 as test_grid.py:135, plus an absolute
+    floor for values that cancel)."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.GRID_CONFIGS[name]
+    t = gi.grid_track(c)
+    dg = gi.degrid_inputs(c)
+    ip, gp, ap = make_params(c)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn.ensure_all_bound()
+    n = c['n_vis']
+    fn.buffer('grid').set(q, gi.middle(dg['grid'], fn.buffer('grid').shape))
+    fn.num_vis = n
+    fn.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+    fn.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+    fn.buffer('vis').set_region(q, dg['vis'], np.s_[:n], np.s_[:])
+    fn.buffer('weights').set_region(q, dg['weights'], np.s_[:n], np.s_[:])
+    fn()
+    actual = fn.buffer('vis').get(q)[:n]
+    expected = golden('g3_degrid_' + name)['residual']
+    np.testing.assert_allclose(actual, expected, rtol=1e-5, atol=1e-5)
+    fn.num_vis = 0
+    fn()                                      # grid.py:989-990
+
+
+def test_predict_vs_golden(golden):
+    """G4: reference _predict_host (norm-wise: see tests/test_oracle_golden.py::test_g4)."""
+    from katsdpimager_amd import predict
+    ctx, q = context_queue()
+    c = gi.PREDICT_CONFIG
+    g = golden('g4_predict')
+    pi = gi.predict_inputs(c)
+    ip, gp, _ = make_params(c)
+    n = c['n_vis']
+    fn = predict.PredictTemplate(ctx, np.float32, c['P']).instantiate(q, ip, gp, n, 64)
+    fn.ensure_all_bound()
+    fn.num_vis = n
+    fn.buffer('uv').set_region(q, np.concatenate((pi['uv'], pi['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+    fn.buffer('w_plane').set_region(q, pi['w_plane'], np.s_[:n], np.s_[:])
+    fn.buffer('vis').set_region(q, pi['vis'], np.s_[:n], np.s_[:])
+    fn.buffer('weights').set_region(q, pi['weights'], np.s_[:n], np.s_[:])
+    fn.set_sky_image(pi['components'])
+    assert fn.num_sources == len(pi['components'])
+    fn.set_w(pi['w'])
+    fn()
+    actual = fn.buffer('vis').get(q)[:n]
+    pred = pi['vis'] - actual
+    pred_ref = pi['vis'] - g['residual']
+    assert relerr(pred, pred_ref) < 2e-3
+    uv_scale, w_scale, w_bias = g['uv_scale'], g['w_scale'], g['w_bias']
+    u = (pi['uv'].astype(np.float64) * c['oversample'] + pi['sub_uv'] + 0.5) * uv_scale
+    w = pi['w_plane'] * w_scale + w_bias + pi['w']
+    lmn, flux = g['lmn'].astype(np.float64), g['flux'].astype(np.float64)
+    phase = u[:, 0:1] * lmn[:, 0] + u[:, 1:2] * lmn[:, 1] + w[:, None] * lmn[:, 2]
+    exact = (np.exp(-2j * np.pi * phase) @ flux) * pi['weights']
+    assert relerr(pred, exact) < 2e-3
+    with pytest.raises(ValueError):
+        fn.set_sky_arrays(np.zeros((100, 3)), np.zeros((100, c['P'])))   # predict.py:337-338
+
+
+@pytest.mark.parametrize('name', list(gi.IMAGE_CONFIGS))
+def test_grid_image_vs_golden(golden, name):
+    """G5: GridToImageHost / ImageToGridHost incl. accumulation, off-centre lm_bias, w != 0."""
+    from katsdpimager_amd import image
+    ctx, q = context_queue()
+    c = gi.IMAGE_CONFIGS[name]
+    g = golden('g5_image_' + name)
+    ii = gi.image_inputs(c)
+    shape = ii['image_shape']
+    template = image.GridImageTemplate(ctx, np.float32)
+    plan = template.make_fft_plan(shape[1:], shape[1:])
+    g2i = template.instantiate_grid_to_image(q, shape, c['lm_scale'], c['lm_bias'], plan)
+    i2g = template.instantiate_image_to_grid(q, shape, c['lm_scale'], c['lm_bias'], plan)
+    g2i.ensure_all_bound()
+    i2g.bind(layer=g2i.buffer('layer'), kernel1d=g2i.buffer('kernel1d'))
+    i2g.ensure_all_bound()
+    g2i.buffer('kernel1d').set(q, ii['kernel1d'])
+    g2i.buffer('grid').set(q, ii['grid'])
+    i2g.buffer('image').set(q, ii['model'])
+    for wi, w in enumerate(c['ws']):
+        g2i.buffer('image').zero(q)
+        g2i.set_w(w)
+        g2i()
+        g2i()
+        assert relerr(g2i.buffer('image').get(q), g['g2i_w%d' % wi]) < 1e-5
+        i2g.set_w(w)
+        i2g()
+        assert relerr(i2g.buffer('grid').get(q), g['i2g_w%d' % wi]) < 1e-5
+    with pytest.raises(ValueError):
+        template.layer_to_image.instantiate(q, (1, 63, 63), 0.1, 0.0)     # image.py:127-128
+    with pytest.raises(IndexError):
+        g2i._layer_image.set_polarization(shape[0])                      # image.py:149-150
+
+
+def test_grid_to_image_smaller_grid():
+    """The grid may be smaller than the image (grid.py:753-767): zero padding by the
+    quadrant copies (image.py:659-672) must equal the host result on the padded grid."""
+    from katsdpimager_amd import image
+    ctx, q = context_queue()
+    rs = gi.RandomState(3)
+    G, Gg, P = 96, 40, 2
+    small = rs.complex_uniform(-1, 1, (P, Gg, Gg)).astype(np.complex64)
+    k1d = rs.uniform(1.0, 2.0, G).astype(np.float32)
+    lm_scale, lm_bias, w = 0.001, -0.5 * G * 0.001, 37.5
+    template = image.GridImageTemplate(ctx, np.float32)
+    plan = template.make_fft_plan((G, G))
+    g2i = template.instantiate_grid_to_image(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+    g2i.ensure_all_bound()
+    g2i.buffer('kernel1d').set(q, k1d)
+    g2i.buffer('grid').set(q, small)
+    g2i.buffer('image').zero(q)
+    g2i.set_w(w)
+    g2i()
+    full = np.zeros((P, G, G), np.complex64)
+    gi.middle(full, small.shape)[:] = small
+    expected = np.zeros((P, G, G), np.float32)
+    orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, w)
+    assert relerr(g2i.buffer('image').get(q), expected) < 1e-5
+    # and back: image -> smaller grid = centre of the host's full grid
+    i2g = template.instantiate_image_to_grid(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+    i2g.bind(layer=g2i.buffer('layer'), kernel1d=g2i.buffer('kernel1d'))
+    i2g.ensure_all_bound()
+    model = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
+    i2g.buffer('image').set(q, model)
+    i2g.set_w(w)
+    i2g()
+    full_grid, _ = orc.image_to_grid(model, k1d, lm_scale, lm_bias, w)
+    assert relerr(i2g.buffer('grid').get(q), gi.middle(full_grid, small.shape)) < 1e-5
+
+
+def test_image_streams():
+    """Scale / AddImage / ApplyPrimaryBeam known answers (test_image.py:91-162)."""
+    from katsdpimager_amd import image
+    ctx, q = context_queue()
+    shape = (4, 123, 234)
+    rs = np.random.RandomState(1)
+    src = rs.uniform(size=shape).astype(np.float32)
+    fn = image.ScaleTemplate(ctx, np.float32, 4).instantiate(q, shape)
+    fn.ensure_all_bound()
+    fn.buffer('data').set(q, src)
+    sf = np.array([1.2, 2.3, 3.4, -4.5], np.float32)
+    fn.set_scale_factor(sf)
+    fn()
+    np.testing.assert_array_equal(fn.buffer('data').get(q), src * sf[:, None, None])
+
+    add = image.AddImageTemplate(ctx, np.float32, 4).instantiate(q, shape)
+    add.ensure_all_bound()
+    dest = rs.uniform(size=shape).astype(np.float32)
+    add.buffer('src').set(q, src)
+    add.buffer('dest').set(q, dest)
+    add()
+    np.testing.assert_array_equal(add.buffer('dest').get(q), src + dest)
+
+    pb = image.ApplyPrimaryBeamTemplate(ctx, np.float32, 4).instantiate(q, shape, 0.2, 12345.0)
+    pb.ensure_all_bound()
+    beam = rs.uniform(size=shape[1:]).astype(np.float32)
+    pb.buffer('data').set(q, src)
+    pb.buffer('beam_power').set(q, beam)
+    pb()
+    np.testing.assert_array_equal(pb.buffer('data').get(q),
+                                  np.where(beam < 0.2, np.float32(12345.0), src / beam))
+    with pytest.raises(ValueError):
+        image.ScaleTemplate(ctx, np.float32, 3).instantiate(q, shape)    # image.py:342-343
+
+
+def test_grid_weights_known():
+    """test_weight.py:10-57 (exact) incl. garbage beyond num_vis."""
+    from katsdpimager_amd import weight
+    ctx, q = context_queue()
+    shape = (4, 100, 200)
+    uv = np.array([[-10, 5, 0, 0], [23, 17, 0, 0], [-10, 5, 0, 0], [-10, 5, 0, 0],
+                   [-10, 6, 0, 0], [-11, 5, 0, 0]], np.int16)
+    w = np.array([[1.0, 10.0, 100.0, 1000.0], [2.0, 20.0, 200.0, 2000.0],
+                  [4.0, 40.0, 400.0, 4000.0], [8.0, 80.0, 800.0, 8000.0],
+                  [16.0, 160.0, 1600.0, 16000.0], [32.0, 320.0, 3200.0, 32000.0]], np.float32)
+    fn = weight.GridWeightsTemplate(ctx, 4).instantiate(q, shape, 1000)
+    fn.ensure_all_bound()
+    rs = np.random.RandomState(1)
+    uv_full = rs.randint(-40, 40, (1000, 4)).astype(np.int16)
+    uv_full[:6] = uv
+    w_full = rs.uniform(size=(1000, 4)).astype(np.float32)
+    w_full[:6] = w
+    fn.buffer('uv').set(q, uv_full)
+    fn.buffer('weights').set(q, w_full)
+    fn.buffer('grid').zero(q)
+    fn.num_vis = 6
+    fn()
+    expected = np.zeros(shape, np.float32)
+    for i in range(4):
+        expected[i, 55, 90] = 13 * 10 ** i
+        expected[i, 67, 123] = 2 * 10 ** i
+        expected[i, 56, 90] = 16 * 10 ** i
+        expected[i, 55, 89] = 32 * 10 ** i
+    np.testing.assert_array_equal(fn.buffer('grid').get(q), expected)
+    with pytest.raises(ValueError):
+        weight.GridWeightsTemplate(ctx, 4).instantiate(q, (4, 101, 200), 10)   # weight.py:131
+
+
+def test_density_and_mean_weight_known():
+    """test_weight.py:60-118."""
+    from katsdpimager_amd import weight
+    ctx, q = context_queue()
+    rs = np.random.RandomState(1)
+    shape = (4, 50, 107)
+    data = np.zeros(shape, np.float32)
+    expected = np.zeros(shape, np.float32)
+    sum_w = sum_dw = sum_d2w = 0.0
+    for index in rs.choice(data.size, 100, replace=False):
+        w = rs.uniform(low=0.1, high=2.0)
+        d = 1.0 / (2.5 * w + 1.75)
+        data.flat[index] = w
+        expected.flat[index] = d
+        if index < data[0].size:
+            sum_w += w
+            sum_dw += d * w
+            sum_d2w += d ** 2 * w
+    fn = weight.DensityWeightsTemplate(ctx, 4).instantiate(q, shape)
+    fn.ensure_all_bound()
+    fn.a, fn.b = 2.5, 1.75
+    fn.buffer('grid').set(q, data)
+    rms, nrms = fn()
+    np.testing.assert_allclose(fn.buffer('grid').get(q), expected, 1e-5, 1e-5)
+    np.testing.assert_allclose(rms, np.sqrt(sum_d2w) / sum_dw, 1e-6)
+    np.testing.assert_allclose(nrms, np.sqrt(sum_d2w * sum_w) / sum_dw, 1e-6)
+    data = rs.uniform(size=shape).astype(np.float32)
+    mw = weight.MeanWeightTemplate(ctx).instantiate(q, shape)
+    mw.ensure_all_bound()
+    mw.buffer('grid').set(q, data)
+    pol0 = data[0].astype(np.float64)
+    np.testing.assert_allclose(mw(), np.sum(pol0 * pol0) / np.sum(pol0), rtol=1e-5)
+
+
+def test_weights_vs_golden(golden):
+    """G6: compound WeightsHost for natural / uniform / robust weighting."""
+    from katsdpimager_amd import weight
+    ctx, q = context_queue()
+    g = golden('g6_weights')
+    wi = gi.weights_inputs()
+    n = len(wi['uv'])
+    for name, wt in [('natural', weight.WeightType.NATURAL), ('uniform', weight.WeightType.UNIFORM),
+                     ('robust', weight.WeightType.ROBUST)]:
+        fn = weight.WeightsTemplate(ctx, wt, wi['shape'][0]).instantiate(q, wi['shape'], 2048)
+        fn.ensure_all_bound()
+        if wt == weight.WeightType.ROBUST:
+            fn.robustness = wi['robustness']
+        fn.clear()
+        if wt != weight.WeightType.NATURAL:
+            for start in range(0, n, 2048):
+                stop = min(n, start + 2048)
+                m = stop - start
+                fn.buffer('uv').set_region(q, wi['uv'][start:stop], (np.s_[:m], np.s_[:2]), np.s_[:])
+                fn.buffer('weights').set_region(q, wi['weights'][start:stop], np.s_[:m], np.s_[:])
+                fn.grid(m)
+        rms, nrms = fn.finalize()
+        np.testing.assert_allclose(fn.buffer('grid').get(q), g[name + '_grid'], rtol=2e-6, atol=0)
+        np.testing.assert_allclose(nrms, g[name + '_nrms'], rtol=1e-5)
+        if rms is None:
+            assert np.isnan(g[name + '_rms'])
+        else:
+            np.testing.assert_allclose(rms, g[name + '_rms'], rtol=1e-5)
+
+
+def _clean_op(c, ci):
+    from katsdpimager_amd import clean, parameters
+    ctx, q = context_queue()
+    fixed = parameters.FixedImageParameters(list(range(c['P'])), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5,
+                                    pixels=c['pixels'])
+    cp = parameters.CleanParameters(1000, c['loop_gain'], 0.85, 5.0, c['mode'], 0.01, 0.5,
+                                    c['border'])
+    fn = clean.CleanTemplate(ctx, cp, np.float32, c['P']).instantiate(q, ip)
+    fn.ensure_all_bound()
+    fn.buffer('dirty').set(q, ci['dirty'])
+    fn.buffer('psf').set(q, ci['psf'])
+    fn.buffer('model').zero(q)
+    return fn, q
+
+
+@pytest.mark.parametrize('batched', [False, True])
+@pytest.mark.parametrize('name', list(gi.CLEAN_CONFIGS))
+def test_clean_vs_golden(golden, name, batched):
+    """G7: CleanHost component lists -- positions, metric values, component fluxes and the
+    residual image are BIT-EXACT, for the per-cycle API and the device-resident loop."""
+    c = gi.CLEAN_CONFIGS[name]
+    g = golden('g7_clean_' + name)
+    ci = gi.clean_inputs(c)
+    fn, q = _clean_op(c, ci)
+    fn.reset()
+    np.testing.assert_array_equal(fn.buffer('tile_max').get(q), g['tile_max0'])
+    np.testing.assert_array_equal(fn.buffer('tile_pos').get(q), g['tile_pos0'])
+    if batched:
+        out = fn.run_cycles(ci['psf_patch'], c['threshold'], c['cycles'])
+    else:
+        out = []
+        for i in range(c['cycles']):
+            v, p, m = fn(ci['psf_patch'], c['threshold'])
+            if v is None:
+                break
+            out.append((v, p, m))
+    assert len(out) == len(g['values'])
+    np.testing.assert_array_equal(np.array([o[1] for o in out], np.int32), g['pos'])
+    np.testing.assert_array_equal(np.array([o[0] for o in out], np.float32), g['values'])
+    np.testing.assert_array_equal(np.array([o[2] for o in out], np.float32), g['pixels'])
+    np.testing.assert_array_equal(fn.buffer('dirty').get(q), g['dirty_final'])
+    np.testing.assert_array_equal(fn.buffer('model').get(q), g['model_final'])
+
+
+def test_clean_steps_known():
+    """test_clean.py:80-172: _UpdateTiles window semantics, _FindPeak, clipped _SubtractPsf."""
+    from katsdpimager_amd import clean
+    ctx, q = context_queue()
+    image_shape = (4, 567, 456)
+    border_pixels = 65
+    border = border_pixels / image_shape[2]
+    rs = np.random.RandomState(seed=1)
+    fn = clean._UpdateTilesTemplate(ctx, np.float32, 4, clean.CLEAN_I).instantiate(
+        q, image_shape, border)
+    fn.ensure_all_bound()
+    dirty = rs.standard_normal(image_shape).astype(np.float32)
+    fn.buffer('dirty').set(q, dirty)
+    fn.buffer('tile_max').zero(q)
+    fn.buffer('tile_pos').zero(q)
+    fn(135, 161, 385, 450)
+    tile_max = fn.buffer('tile_max').get(q)
+    tile_pos = fn.buffer('tile_pos').get(q)
+    assert tile_max.shape == (14, 11)
+    for y in range(14):
+        for x in range(11):
+            if x < 2 or x >= 10 or y < 3 or y >= 13:
+                assert tile_max[y, x] == 0.0 and not tile_pos[y, x].any()
+            else:
+                y0, x0 = y * 32 + border_pixels, x * 32 + border_pixels
+                y1 = min(y0 + 32, dirty.shape[1] - border_pixels)
+                x1 = min(x0 + 32, dirty.shape[2] - border_pixels)
+                tile = np.abs(dirty[0, y0:y1, x0:x1])
+                pos = np.unravel_index(np.argmax(tile), tile.shape)
+                assert tile[pos] == tile_max[y, x]
+                assert (pos[0] + y0, pos[1] + x0) == tuple(tile_pos[y, x])
+
+    image_shape, tile_shape = (4, 256, 256), (72, 67)
+    fp = clean._FindPeakTemplate(ctx, np.float32, 4).instantiate(q, image_shape, tile_shape)
+    fp.ensure_all_bound()
+    dirty = rs.uniform(1.0, 2.0, image_shape).astype(np.float32)
+    tmax = rs.uniform(1.0, 2.0, tile_shape).astype(np.float32)
+    tmax[40, 3] = tmax[10, 50] = 2.5            # a tie: the first in row-major order wins
+    tpos = np.array([[[y, x] for x in range(67)] for y in range(72)], np.int32)
+    fp.buffer('tile_max').set(q, tmax)
+    fp.buffer('tile_pos').set(q, tpos)
+    fp.buffer('dirty').set(q, dirty)
+    fp()
+    assert fp.buffer('peak_value').get(q)[0] == np.float32(2.5)
+    np.testing.assert_array_equal(fp.buffer('peak_pos').get(q), [10, 50])
+    np.testing.assert_array_equal(fp.buffer('peak_pixel').get(q), dirty[:, 10, 50])
+
+    loop_gain, image_shape, psf_patch, pos = 0.25, (4, 200, 344), (4, 72, 130), (170, 59)
+    dirty = rs.standard_normal(image_shape).astype(np.float32)
+    psf = rs.standard_normal(psf_patch).astype(np.float32)
+    expected = dirty.copy()
+    peak_pixel = dirty[:, pos[0], pos[1]].copy()
+    expected[:, 134:200, 0:124] -= \
+        (np.float32(loop_gain) * peak_pixel)[:, None, None] * psf[:, :66, 6:]
+    psf_full = np.ones(image_shape, np.float32)
+    psf_full[:, 64:136, 107:237] = psf
+    sp = clean._SubtractPsfTemplate(ctx, np.float32, 4).instantiate(
+        q, loop_gain, image_shape, image_shape)
+    sp.ensure_all_bound()
+    sp.buffer('dirty').set(q, dirty)
+    sp.buffer('psf').set(q, psf_full)
+    sp.buffer('peak_pixel').set(q, peak_pixel)
+    sp.buffer('model').zero(q)
+    sp(pos, psf_patch)
+    np.testing.assert_array_equal(sp.buffer('dirty').get(q), expected)
+    model = sp.buffer('model').get(q)
+    np.testing.assert_array_equal(model[:, pos[0], pos[1]], np.float32(loop_gain) * peak_pixel)
+    assert np.count_nonzero(model) == 4
+
+
+def test_psf_patch_and_noise_vs_golden(golden):
+    """G8 + test_clean.py:13-37, 174-200."""
+    from katsdpimager_amd import clean
+    ctx, q = context_queue()
+    g = golden('g8_psfpatch_noise')
+    fn = clean.PsfPatchTemplate(ctx, np.float32, 4).instantiate(q, (4, 206, 304))
+    fn.ensure_all_bound()
+    known = [(4, 1, 1), (4, 206, 304), (4, 205, 303), None, (4, 15, 5)]
+    for i, (psf, thr, lim) in enumerate(gi.psf_patch_cases()):
+        fn.buffer('psf').set(q, psf)
+        box = fn(thr, lim)
+        assert box == tuple(g['patch%d' % i])
+        if known[i]:
+            assert box == known[i]
+    for i, (img, border) in enumerate(gi.noise_cases()):
+        ne = clean.NoiseEstTemplate(ctx, np.float32, img.shape[0]).instantiate(q, img.shape, border)
+        ne.ensure_all_bound()
+        ne.buffer('dirty').set(q, img)
+        assert ne() == g['noise%d' % i]            # exact median, as the host path
+    # odd element count
+    img = np.random.RandomState(4).standard_normal((1, 67, 59)).astype(np.float32)
+    ne = clean.NoiseEstTemplate(ctx, np.float32, 1).instantiate(q, img.shape, 0.1)
+    ne.ensure_all_bound()
+    ne.buffer('dirty').set(q, img)
+    assert ne() == orc.noise_est(img, 0.1)
+    with pytest.raises(ValueError):
+        clean.NoiseEstTemplate(ctx, np.float32, 1).instantiate(q, img.shape, 0.5)
+
+
+@pytest.mark.parametrize('batched', [False, True])
+@pytest.mark.parametrize('name', list(gi.E2E_CONFIGS))
+def test_end_to_end_vs_golden(golden, name, batched):
+    """G9: the whole per-channel loop (weights -> PSF -> 2 major cycles of grid / FFT / CLEAN /
+    degrid-or-predict) on the Imaging facade vs the reference's ImagingHost."""
+    from katsdpimager_amd import imaging, parameters, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS[name]
+    g = golden('g9_e2e_' + name)
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType(c['weight_type']), c['robustness'])
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
+    im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'])
+    im.ensure_all_bound()
+    data = gi.e2e_inputs(c)
+    if batched:
+        # route the minor loop through the device-resident batch API
+        out = run_batched(im, c, data)
+    else:
+        out = gi.run_major_cycle(im, c, data, host=False)
+    G = c['pixels']
+    Gg = out['weights_grid'].shape[-1]
+    np.testing.assert_allclose(out['weights_grid'],
+                               gi.middle(g['weights_grid'], out['weights_grid'].shape),
+                               rtol=1e-5, atol=0)
+    np.testing.assert_allclose(out['weights_nrms'], g['weights_nrms'], rtol=1e-5)
+    np.testing.assert_allclose(out['psf_peak'], g['psf_peak'], rtol=1e-5)
+    assert tuple(out['psf_patch']) == tuple(g['psf_patch'])
+    assert relerr(out['psf_core'], g['psf_core']) < 1e-5
+    assert relerr(out['dirty0'], g['dirty0']) < 2e-5
+    np.testing.assert_allclose(out['noise0'], g['noise0'], rtol=1e-4)
+    np.testing.assert_array_equal(out['n_minor'], g['n_minor'])
+    # first major cycle: identical peak sequence
+    n0 = int(g['n_minor'][0])
+    np.testing.assert_allclose(out['peak_values'][:n0], g['peak_values'][:n0], rtol=1e-4)
+    np.testing.assert_array_equal(out['component_pos'], g['component_pos'])
+    np.testing.assert_allclose(out['component_flux'], g['component_flux'], rtol=2e-4)
+    assert relerr(out['residual_vis'], g['residual_vis']) < (1e-4 if c['degrid'] else 2e-3)
+    assert relerr(out['dirty1'], g['dirty1']) < 2e-4
+    assert relerr(out['dirty_final'], g['dirty_final']) < 2e-4
+    assert relerr(out['model_final'], g['model_final']) < 2e-4
+    assert Gg <= G
+
+
+def run_batched(im, c, data):
+    """run_major_cycle with the minor loop replaced by Imaging.clean_cycles."""
+    class Batched:
+        def __init__(self, im):
+            self._im = im
+            self._queue = []
+
+        def __getattr__(self, name):
+            return getattr(self._im, name)
+
+        @property
+        def num_vis(self):
+            return self._im.num_vis
+
+        @num_vis.setter
+        def num_vis(self, v):
+            self._im.num_vis = v
+
+        def clean_reset(self):
+            self._queue = []
+            self._im.clean_reset()
+
+        def clean_cycle(self, psf_patch, threshold=0.0):
+            if threshold == 0.0:
+                return self._im.clean_cycle(psf_patch, threshold)
+            if not self._queue:
+                vals = self._im.clean_cycles(psf_patch, threshold, c['minor'] - 1)
+                self._queue = list(vals) + [None]
+            return self._queue.pop(0)
+    return gi.run_major_cycle(Batched(im), c, data, host=False)

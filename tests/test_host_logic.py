@@ -1,0 +1,104 @@
+"""CPU-only tests of the product's host-side logic and of the C ABI surface
+(no compute calls: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from helpers import make_params, relerr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from katsdpimager_amd import _lib, build
+    build.build_lib()
+    header = open(os.path.join(ROOT, 'include', 'kimg.h')).read()
+    declared = set(re.findall(r'\b(kimg_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 25
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert declared == set(_lib.PROTOTYPES)
+    lib = _lib.lib()
+    assert lib.kimg_version() == 1
+    assert _lib.error_string(0) == 'success'
+    assert 'unsupported' in _lib.error_string(-10002)
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation happens before any HIP call."""
+    from katsdpimager_amd import _lib
+    lib = _lib.lib()
+    assert lib.kimg_fill(None, 10, 1.0, None) == -10001
+    assert lib.kimg_grid_weights(None, 1, 1, 2, 2, 1, None, None, 0, None) == -10001
+    with pytest.raises(_lib.KimgError):
+        _lib.check(-10001, 'kimg_fill')
+
+
+@pytest.mark.parametrize('name', list(gi.KERNEL_CONFIGS))
+def test_kernel_table_matches_reference(golden, name):
+    """Host-side kernel generation (grid.ConvolutionKernel) vs the reference's table."""
+    from katsdpimager_amd import grid
+    c = gi.KERNEL_CONFIGS[name]
+    ip, gp, _ = make_params(c)
+    g = golden('g1_kernel_' + name)
+    ck = grid.ConvolutionKernel(ip, gp)
+    assert ck.data.shape == g['data'].shape and ck.data.dtype == np.complex64
+    assert ck.beta == g['beta']
+    assert relerr(ck.data, g['data']) < 1e-6
+    np.testing.assert_allclose(ck.taper(c['pixels']), g['taper'], rtol=1e-12)
+
+
+def test_parameters_match_reference_formulas():
+    from katsdpimager_amd import parameters
+    c = gi.KERNEL_CONFIGS['testgrid']
+    ip, gp, _ = make_params(c)
+    assert ip.image_size == pytest.approx(0.0256)
+    assert ip.cell_size == pytest.approx(0.390625)
+    with pytest.raises(ValueError):
+        parameters.ImageParameters(ip.fixed, 1.0, None, 0.01, None, pixel_size=1e-4, pixels=250)
+    assert parameters.is_smooth(4096) and not parameters.is_smooth(4100)
+    with pytest.raises(ValueError):
+        parameters.CleanParameters(10, 0.1, 0.85, 5.0, 0, 1.5, 0.5, 0.02)
+    # automatic sizing (parameters.py:84-110)
+    ap = parameters.ArrayParameters(13.5, 8000.0)
+    auto = parameters.ImageParameters(ip.fixed, 1.0, 5.0, 0.21, ap)
+    assert parameters.is_smooth(auto.pixels) and auto.pixels % 2 == 0
+    assert auto.pixel_size == pytest.approx(0.21 / (2.0 / 3.0 * 5.0 * 8000.0))
+    slices = parameters.w_slices(auto, 1000.0, 0.001, 60, 7.0)
+    assert slices >= 1
+    assert parameters.w_kernel_width(auto, 500.0 / (slices - 0.5), 0.001, 7.0) <= 60
+
+
+def test_extract_sky_image_known():
+    """test_predict.py:107-133 against the product's host code."""
+    from katsdpimager_amd import predict, parameters
+    fixed = parameters.FixedImageParameters([0, 1, 3], np.float64)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=0.00001, pixels=4096)
+    gp = parameters.GridParameters(
+        parameters.FixedGridParameters(7.0, 8, 4, 5.0, 7), w_slices=10, w_planes=100)
+    comps = {(0, 4095): np.array([4.0, 0.0, 0.0]), (1024, 512): np.array([2.5, 1.5, 0.0]),
+             (2048, 2048): np.array([1.0, 2.0, 3.0]), (4095, 0): np.array([5.0, 1.0, 2.0])}
+    lmn, flux = predict.extract_sky_image(ip, gp, comps)
+    np.testing.assert_allclose(lmn[:, 0:2], [[2047e-5, -2048e-5], [-1536e-5, -1024e-5], [0, 0],
+                                             [-2048e-5, 2047e-5]], rtol=1e-6, atol=1e-12)
+    ef = np.array([[4.0, 0, 0], [2.5, 1.5, 0.0], [1, 2, 3], [5, 1, 2]])
+    ef[0] *= np.sinc(0.5 / 8) * np.sinc(2047 / 4096 / 8)
+    ef[1] *= np.sinc(0.25 / 8) * np.sinc(0.375 / 8)
+    ef[3] *= np.sinc(2047 / 4096 / 8) * np.sinc(0.5 / 8)
+    np.testing.assert_allclose(flux, ef)
+    c = gi.PREDICT_CONFIG
+    ip2, gp2, _ = make_params(c)
+    from oracle import kimg_oracle as orc
+    assert predict.uvw_scale_bias(ip2, gp2) == orc.uvw_scale_bias(
+        c['cell_size'], c['wavelength'], c['max_w'], c['w_slices'], c['w_planes'], c['oversample'])
+
+
+def test_float64_rejected():
+    from katsdpimager_amd import types
+    with pytest.raises(ValueError):
+        types.require_float32(np.float64, 'x')
