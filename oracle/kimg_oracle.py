@@ -556,12 +556,20 @@ class Clean:
         return (y0, x0, y1, x1), scale
 
     def __call__(self, psf_patch_, threshold=0.0):
-        """clean.py:1060-1075."""
+        """clean.py:1060-1075.
+
+        Reference quirk, reproduced: ``peak_pos`` is a *view* of ``_tile_pos`` (clean.py:1063),
+        so the position RETURNED at :1075 is read after ``_update_tile`` has rewritten that
+        tile -- it is the tile's new best pixel, not the pixel that was subtracted.  The
+        subtraction itself (and the model image) use the true peak, kept here in
+        ``self.last_pos``.  The reference's GPU path returns the true peak
+        (clean.py:881-891); the HIP path follows that."""
         peak_tile = np.unravel_index(np.argmax(self._tile_max), self._tile_max.shape)
         peak_pos = self._tile_pos[peak_tile]
         peak_value = self._tile_max[peak_tile]
         if peak_value < threshold:
             return None, None, None
+        self.last_pos = (int(peak_pos[0]), int(peak_pos[1]))
         (y0, x0, y1, x1), model_pixel = self._subtract_psf(int(peak_pos[0]), int(peak_pos[1]),
                                                            psf_patch_)
         ts, bp = self.tile_size, self.border_pixels

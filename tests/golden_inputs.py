@@ -337,6 +337,8 @@ def run_major_cycle(im, c, data, host=False):
     def make_dirty(field, full_cycle, capture=None):
         im.clear_dirty()
         if full_cycle and not c['degrid']:
+            if true_components is not None:
+                im._model_components = dict(true_components)
             im.model_to_predict()
         for s, rec in enumerate(slices):
             if len(rec) == 0:
@@ -359,6 +361,22 @@ def run_major_cycle(im, c, data, host=False):
                                                    np.array(im.get_buffer('vis')[:len(chunk)]))
                 im.grid()
             im.grid_to_image(mid_w[s])
+
+    true_components = None
+    if host:
+        # The reference's CleanHost returns an aliased position (clean.py:1063,1075: a view of
+        # _tile_pos that _update_tile rewrites), so ImagingHost._model_components can be keyed
+        # by the wrong pixel.  Keep the positions actually subtracted and hand those to
+        # model_to_predict, which is what the reference's GPU path does (clean.py:881-891).
+        true_components = {}
+        inner = im._clean._subtract_psf
+
+        def recording_subtract(y, x, psf_patch):
+            res = inner(y, x, psf_patch)
+            key = (int(y), int(x))
+            true_components[key] = true_components.get(key, 0) + res[1]
+            return res
+        im._clean._subtract_psf = recording_subtract
 
     im.clear_model()
     im.clear_weights()
@@ -409,7 +427,7 @@ def run_major_cycle(im, c, data, host=False):
         n_minor.append(len(vals))
     out['n_minor'] = np.array(n_minor, np.int64)
     out['peak_values'] = np.concatenate(comps_val)
-    comps = im._model_components
+    comps = true_components if true_components is not None else im._model_components
     keys = sorted(comps.keys())
     out['component_pos'] = np.array(keys, np.int64).reshape(-1, 2)
     out['component_flux'] = np.array([np.asarray(comps[k]) for k in keys], np.float32)

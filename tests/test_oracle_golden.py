@@ -132,7 +132,7 @@ def test_g7_clean(golden, name):
     ch.reset()
     np.testing.assert_array_equal(ch._tile_max, g['tile_max0'])
     np.testing.assert_array_equal(ch._tile_pos, g['tile_pos0'])
-    values, pos, pix = [], [], []
+    values, pos, pix, true_pos = [], [], [], []
     for i in range(c['cycles']):
         v, p, m = ch(ci['psf_patch'], c['threshold'])
         if v is None:
@@ -140,8 +140,11 @@ def test_g7_clean(golden, name):
         values.append(v)
         pos.append(p)
         pix.append(m)
-    # bit-exact: positions, metric values, component fluxes, residual image
+        true_pos.append(ch.last_pos)
+    # bit-exact: positions (returned-with-aliasing and actually subtracted), metric values,
+    # component fluxes, residual image
     np.testing.assert_array_equal(np.array(pos, np.int32), g['pos'])
+    np.testing.assert_array_equal(np.array(true_pos, np.int32), g['true_pos'])
     np.testing.assert_array_equal(np.array(values, np.float32), g['values'])
     np.testing.assert_array_equal(np.array(pix, np.float32), g['pixels'])
     np.testing.assert_array_equal(dirty, g['dirty_final'])
