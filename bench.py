@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Benchmark of the imaging hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): one spectral channel, 4096^2 image, 32 W-planes,
+~50 M synthetic visibilities (tools/synth.py), float32, Stokes I, kernel width 28,
+oversample 8, streamed through Gridder in --vis-block chunks (reference default 1 048 576,
+frontend.py:357) with every input resident in HBM.  One "step" = clear the grid + grid all
+chunks of the channel (the hot loop #1 of frontend.make_dirty, frontend.py:126-139).
+With N > 1 (one process per GPU, torchrun) every rank images its own channel (frequency
+spread +-3 %): the path shards by channel with no data-path collective (weak scaling);
+rank 0 broadcasts the channel-independent tables over RCCL once at start-up.
+
+Prints ONE JSON line on rank 0: metric "Mvis/s gridded", plus `roofline` for the dominant
+kernel (grid_mfma_kernel), `cpu_baseline` (the oracle's single-thread C restatement timed on
+this host) and secondary numbers (CLEAN minor-cycles/s, degrid, FFT).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--vis', type=int, default=50_000_000)
+    p.add_argument('--pixels', type=int, default=4096)
+    p.add_argument('--w-planes', type=int, default=32)
+    p.add_argument('--kernel-width', type=int, default=28)
+    p.add_argument('--polarizations', type=int, default=1)
+    p.add_argument('--vis-block', type=int, default=1048576)
+    p.add_argument('--variant', default='auto', choices=['auto', 'generic', 'mfma'])
+    p.add_argument('--clean-cycles', type=int, default=1000)
+    p.add_argument('--cpu-sample', type=int, default=4_000_000,
+                   help='visibilities gridded by the CPU baseline (0 disables it)')
+    p.add_argument('--no-secondary', action='store_true',
+                   help='skip the CLEAN / degrid / FFT secondary measurements')
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import synth
+    from katsdpimager_amd import accel, grid, image, clean, parameters, _lib
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.gpus != world:
+        raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch with torchrun'.format(
+            args.gpus, world))
+    _lib.lib()      # fail loudly if the HIP extension is missing
+    ctx = accel.Context(local_rank)
+    q = ctx.create_command_queue()
+    dev = ctx.device
+    P, K, W, G = args.polarizations, args.kernel_width, args.w_planes, args.pixels
+
+    # ---- shared tables: computed on rank 0, broadcast over RCCL/xGMI -------
+    t_bcast = 0.0
+    bl = torch.from_numpy(synth.baselines_equatorial()).to(dev) if rank == 0 \
+        else torch.empty((2016, 3), dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(bl, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        assert torch.equal(bl.cpu(), torch.from_numpy(synth.baselines_equatorial()))
+
+    # ---- this rank's channel ------------------------------------------------------------
+    chan_scale = 1.0 if world == 1 else 1.0 + 0.03 * (2.0 * rank / (world - 1) - 1.0)
+    # uv coordinates scale with frequency: keep the footprint inside the grid for every channel
+    cover = 0.30 / (1.03 if world > 1 else 1.0)
+    obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=cover,
+                                 channel_scale=chan_scale, seed=2 + rank)
+    ip, gp, ap = synth.make_parameters(obs, P, K)
+    n_vis = obs.n_vis
+    vb = args.vis_block
+    n_chunks = -(-n_vis // vb)
+    pad = n_chunks * vb - n_vis
+
+    def padded(t):
+        if pad == 0:
+            return t
+        z = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return torch.cat([t, z])
+    uv_all, wp_all, vis_all = padded(obs.uv), padded(obs.w_plane), padded(obs.vis)
+
+    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': args.variant})
+    fn = template.instantiate(q, ap, ip, gp, vb)
+    Gg = fn.slots['grid'].shape[1]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2)
+    wg = accel.DeviceArray(ctx, (P, Gg, Gg), np.float32,
+                           tensor=torch.rand((P, Gg, Gg), generator=gen, device=dev))
+    fn.bind(weights_grid=wg)
+    fn.ensure_all_bound()
+    chunks = []
+    for i in range(n_chunks):
+        s = slice(i * vb, (i + 1) * vb)
+        chunks.append((accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=uv_all[s]),
+                       accel.DeviceArray(ctx, (vb,), np.int16, tensor=wp_all[s]),
+                       accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=vis_all[s]),
+                       min(vb, n_vis - i * vb)))
+    grid_buf = fn.buffer('grid')
+    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        grid_buf.zero(q)                               # imager.clear_grid()
+        if k is not None:
+            ev_start[k].record(q.stream)
+        for uv_c, wp_c, vis_c, n in chunks:
+            fn.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+            fn.num_vis = n
+            fn._run()                                  # imager.grid()
+        if k is not None:
+            ev_stop[k].record(q.stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    ms_per_step = elapsed / args.steps * 1e3
+    mvis = world * n_vis / (elapsed / args.steps) / 1e6
+
+    # ---- roofline of the dominant kernel (gridder), HIP events on the kernel's stream ----
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_start, ev_stop)]))
+    launch_us = kern_ms * 1e3 / n_chunks
+    flop_per_vis = 8.0 * K * K * P               # one complex MAC per tap and polarization
+    achieved_tflops = flop_per_vis * n_vis / (kern_ms * 1e-3) / 1e12
+    bytes_per_vis = 8 + 2 + 8 * P + 4 * P        # uv + w_plane + vis + weight gather
+    roofline = {
+        'kernel': 'grid_mfma_kernel' if args.variant != 'generic' else 'grid_generic_kernel',
+        'bound': 'mfma', 'achieved': round(achieved_tflops, 3), 'peak': FP32_MFMA_PEAK_TFLOPS,
+        'unit': 'TFLOP/s', 'frac': round(achieved_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+        'traffic': None,
+        'flop_per_vis': flop_per_vis, 'avg_launch_us': round(launch_us, 2),
+        'vis_per_launch': vb,
+        'hbm_algorithmic_GBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9, 1),
+        'hbm_frac_of_8TBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+    }
+    traffic_file = os.path.join(ROOT, 'profiles', 'gridder_traffic.json')
+    if os.path.exists(traffic_file):
+        try:
+            roofline['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
+        except Exception:
+            pass
+
+    result = {
+        'metric': 'Mvis/s gridded (4096^2 grid, 32 W-planes)', 'value': round(mvis, 2),
+        'unit': 'Mvis/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'C2: 1 channel per GPU, {0}^2 image, {1} W-planes, {2} vis, '
+                               'K={3}, P={4}, vis_block={5}'.format(G, W, n_vis, K, P, vb),
+                   'grid_size': Gg, 'channels': world, 'parallelism': 'channel-sharded',
+                   'broadcast_ms': round(t_bcast * 1e3, 3)},
+        'roofline': roofline,
+    }
+
+    if rank == 0 and not args.no_secondary:
+        result['secondary'] = secondary(args, ctx, q, obs, ip, gp, ap, fn, chunks)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        result['cpu_baseline'] = cpu_baseline(args, obs, fn, wg, Gg)
+    barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
+    """CLEAN minor-cycles/s (second half of BASELINE's metric), FFT + layer_to_image, degrid."""
+    import torch
+    from katsdpimager_amd import accel, grid, image, clean, parameters
+    out = {}
+    P, G = args.polarizations, args.pixels
+
+    # grid -> image (pad/shift + rocFFT + layer_to_image)
+    template = image.GridImageTemplate(ctx, np.float32)
+    g2i = template.instantiate_grid_to_image(
+        q, gridder.buffer('grid').shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
+        template.make_fft_plan((G, G)))
+    g2i.bind(grid=gridder.buffer('grid'))
+    g2i.ensure_all_bound()
+    g2i.buffer('kernel1d').set(q, gridder.convolve_kernel.taper(G).astype(np.float32))
+    g2i.buffer('image').zero(q)
+    g2i()
+    q.finish()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g2i()
+    q.finish()
+    out['grid_to_image_ms'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+
+    # CLEAN: dirty = 200 point sources (x) PSF + noise, patch from psf_patch
+    dirty = g2i.buffer('image')
+    img = dirty.get(q)
+    peak = img[:, G // 2, G // 2].copy()
+    rs = np.random.RandomState(4)
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
+    psf = np.outer(g1, g1)[None].repeat(P, axis=0).astype(np.float32)
+    psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
+    psf[:, G // 2, G // 2] = 1.0
+    sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
+    for _ in range(200):
+        y, x = rs.randint(100, G - 100, 2)
+        amp = rs.uniform(0.5, 2.0)
+        sky[:, y - 30:y + 31, x - 30:x + 31] += amp * psf[:, G // 2 - 30:G // 2 + 31,
+                                                          G // 2 - 30:G // 2 + 31]
+    cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
+    cl = clean.CleanTemplate(ctx, cp, np.float32, P).instantiate(q, ip)
+    cl.ensure_all_bound()
+    cl.buffer('psf').set(q, psf)
+    pp = clean.PsfPatchTemplate(ctx, np.float32, P).instantiate(q, (P, G, G))
+    pp.bind(psf=cl.buffer('psf'))
+    patch = pp(cp.psf_cutoff, cp.psf_limit)
+    for label in ('batched', 'per_cycle'):
+        cl.buffer('dirty').set(q, sky)
+        cl.buffer('model').zero(q)
+        cl.reset()
+        n = args.clean_cycles if label == 'batched' else min(args.clean_cycles, 200)
+        q.finish()
+        t0 = time.perf_counter()
+        if label == 'batched':
+            done = len(cl.run_cycles(patch, 0.0, n))
+        else:
+            done = 0
+            for _ in range(n):
+                v, p_, m = cl(patch, 0.0)
+                done += v is not None
+        q.finish()
+        out['clean_%s_cycles_per_s' % label] = round(done / (time.perf_counter() - t0), 1)
+    out['clean_psf_patch'] = list(patch)
+
+    # degridder on the first chunk
+    template_d = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed)
+    dg = template_d.instantiate(q, ap, ip, gp, args.vis_block)
+    dg.bind(grid=gridder.buffer('grid'), uv=chunks[0][0], w_plane=chunks[0][1])
+    dg.ensure_all_bound()
+    dg.num_vis = chunks[0][3]
+    dg()
+    q.finish()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dg()
+    q.finish()
+    out['degrid_Mvis_per_s'] = round(3 * chunks[0][3] / (time.perf_counter() - t0) / 1e6, 2)
+    return out
+
+
+def cpu_baseline(args, obs, gridder, wg, Gg):
+    """The oracle's C restatement of the reference's numba `_grid` loop (grid.py:1032-1052),
+    single thread (the reference CPU path is single-threaded), on a bounded sample."""
+    from oracle import kimg_oracle as orc
+    S = min(args.cpu_sample, obs.n_vis)
+    # a sample spread over the whole track set: every (n_vis // S)-block contributes a run
+    runs = 64
+    run_len = S // runs
+    starts = np.linspace(0, obs.n_vis - run_len, runs).astype(np.int64)
+    idx = (starts[:, None] + np.arange(run_len)[None, :]).reshape(-1)
+    import torch
+    sel = torch.from_numpy(idx).to(obs.uv.device)
+    uv = obs.uv[sel].cpu().numpy()
+    wp = obs.w_plane[sel].cpu().numpy()
+    vis = obs.vis[sel].cpu().numpy()
+    kernel = gridder.convolve_kernel.data
+    P = vis.shape[1]
+    g = np.zeros((P, Gg, Gg), np.complex64)
+    wgrid = wg.tensor.cpu().numpy()
+    orc.grid(kernel, g, wgrid, uv[:1000, :2].copy(), uv[:1000, 2:].copy(), wp[:1000], vis[:1000])
+    t0 = time.perf_counter()
+    orc.grid(kernel, g, wgrid, np.ascontiguousarray(uv[:, :2]), np.ascontiguousarray(uv[:, 2:]),
+             wp, vis)
+    dt = time.perf_counter() - t0
+    return {'value': round(len(idx) / dt / 1e6, 4), 'unit': 'Mvis/s', 'cores': 1, 'kind': 'port',
+            'sample': '{} visibilities ({} runs of {} consecutive samples spread over the '
+                      'channel), same grid / kernel table, {:.1f} s'.format(len(idx), runs,
+                                                                            run_len, dt)}
+
+
+if __name__ == '__main__':
+    main()

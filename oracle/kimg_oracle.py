@@ -214,7 +214,7 @@ def build_c(force=False):
     out = os.path.join(_HERE, 'libkimg_oracle.so')
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         subprocess.check_call(
-            ['gcc', '-O2', '-ffp-contract=off', '-fno-fast-math', '-march=x86-64-v2',
+            ['gcc', '-O3', '-ffp-contract=off', '-fno-fast-math', '-march=x86-64-v3',
              '-shared', '-fPIC', '-o', out, src, '-lm'])
     return out
 

@@ -1,0 +1,137 @@
+"""Synthetic observation for benchmarks and full-size tests (no katpoint / casacore).
+
+A MeerKAT-like 64-antenna array (48 antennas in a Gaussian core of sigma 300 m, 16 on three
+spiral arms out to 4 km), earth-rotation synthesis at declination -45 deg over hour angle
++-4 h, all 2016 baselines, baseline-major order as the reference's loaders deliver it
+(loader_ms.py:465-467).  UVW is quantised with the reference preprocessor's rules
+(preprocess.cpp:313-323, 435-507): w<0 flip, u/v scaled to cells and split into cell /
+sub-cell, w_plane = min(trunc(w*w_scale + W/2), slices*W-1).  No compression (worst case).
+
+Everything is generated with torch on the requested device so that a 50 M visibility
+channel takes a second or two on the GPU; the same code runs on the CPU for tests.
+"""
+import math
+
+import numpy as np
+import torch
+
+LATITUDE = math.radians(-30.71)
+DECLINATION = math.radians(-45.0)
+N_ANTENNAS = 64
+LAYOUT_SEED = 20241008
+
+
+def antenna_positions():
+    """ENU positions in metres, float64 [64][3]."""
+    rng = np.random.default_rng(LAYOUT_SEED)
+    core = rng.normal(0.0, 300.0, size=(48, 2))
+    arms = []
+    for k in range(16):
+        arm = k % 3
+        r = 800.0 + (4000.0 - 800.0) * (k // 3 + rng.uniform(0.2, 0.9)) / 6.0
+        theta = 2 * math.pi * arm / 3 + 0.9 * r / 4000.0 + rng.normal(0, 0.05)
+        arms.append([r * math.cos(theta), r * math.sin(theta)])
+    en = np.concatenate([core, np.array(arms)])
+    up = rng.normal(0.0, 3.0, size=(N_ANTENNAS, 1))
+    return np.concatenate([en, up], axis=1)
+
+
+def baselines_equatorial():
+    """Baseline vectors (Lx, Ly, Lz) in the equatorial frame, float64 [2016][3]."""
+    enu = antenna_positions()
+    i, j = np.triu_indices(N_ANTENNAS, 1)
+    d = enu[j] - enu[i]
+    e, n, u = d[:, 0], d[:, 1], d[:, 2]
+    sl, cl = math.sin(LATITUDE), math.cos(LATITUDE)
+    return np.stack([-sl * n + cl * u, e, cl * n + sl * u], axis=1)
+
+
+class Observation:
+    """Quantised visibilities of one channel, resident on `device`.
+
+    Attributes: uv int16 [N][4], w_plane int16 [N], vis complex64 [N][P],
+    weights float32 [N][P]; plus the parameters needed to build matching operators:
+    cell_size, longest_baseline, max_w (metres), wavelength, pixel_size.
+    """
+
+
+def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
+                     wavelength=0.21, cover=0.30, seed=2, device='cpu', w_slices=1,
+                     channel_scale=1.0):
+    """`cover`: longest baseline as a fraction of the grid size in cells (0.30).
+    `channel_scale`: relative frequency of this channel (scales uvw in wavelengths)."""
+    dev = torch.device(device)
+    bl = torch.from_numpy(baselines_equatorial()).to(dev)                 # [B][3] f64
+    nb = bl.shape[0]
+    T = -(-n_vis // nb)
+    ha = torch.linspace(-math.pi / 3, math.pi / 3, T, dtype=torch.float64, device=dev)
+    sh, ch = torch.sin(ha)[None, :], torch.cos(ha)[None, :]
+    sd, cd = math.sin(DECLINATION), math.cos(DECLINATION)
+    lx, ly, lz = bl[:, 0:1], bl[:, 1:2], bl[:, 2:3]
+    u = (sh * lx + ch * ly).reshape(-1)[:n_vis]
+    v = (-sd * ch * lx + sd * sh * ly + cd * lz).reshape(-1)[:n_vis]
+    w = (cd * ch * lx - cd * sh * ly + sd * lz).reshape(-1)[:n_vis]
+    # array-wide scales are taken over the full tracks so that they do not depend on n_vis
+    longest = float(torch.sqrt((bl ** 2).sum(dim=1)).max())
+    max_w = float(torch.sqrt((bl ** 2).sum(dim=1)).max())
+    cell_size = longest / (cover * pixels)            # metres per uv cell at channel_scale 1
+    obs = Observation()
+    obs.wavelength = wavelength / channel_scale
+    obs.cell_size = cell_size / channel_scale
+    obs.longest_baseline = longest
+    obs.max_w = max_w
+    obs.pixels = pixels
+    obs.pixel_size = obs.wavelength / (obs.cell_size * pixels)
+    obs.w_planes = w_planes
+    obs.w_slices = w_slices
+    obs.oversample = oversample
+
+    # preprocess.cpp:435-507 in float32
+    u = u.to(torch.float32)
+    v = v.to(torch.float32)
+    w = w.to(torch.float32)
+    flip = w < 0
+    u = torch.where(flip, -u, u)
+    v = torch.where(flip, -v, v)
+    w = torch.where(flip, -w, w)
+    uv_scale = np.float32(1.0) / np.float32(obs.cell_size)
+    w_scale = np.float32((np.float32(w_slices) - np.float32(0.5)) * np.float32(w_planes)
+                         / np.float32(max_w))
+    u = u * float(uv_scale)
+    v = v * float(uv_scale)
+    wq = torch.trunc(w * float(w_scale) + float(np.float32(w_planes) * np.float32(0.5)))
+    wsp = torch.clamp(wq.to(torch.int32), max=w_slices * w_planes - 1)
+
+    def split(x):
+        xs = torch.floor(x * float(oversample)).to(torch.int32)
+        pix = torch.div(xs, oversample, rounding_mode='floor')
+        return pix, xs - pix * oversample
+
+    pu, su = split(u)
+    pv, sv = split(v)
+    obs.uv = torch.stack([pu, pv, su, sv], dim=1).to(torch.int16).contiguous()
+    obs.w_plane = (wsp % w_planes).to(torch.int16).contiguous()
+    obs.w_slice = torch.div(wsp, w_planes, rounding_mode='floor').to(torch.int16).contiguous()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    re = torch.rand((n_vis, num_polarizations), generator=gen, device=dev) * 2 - 1
+    im = torch.rand((n_vis, num_polarizations), generator=gen, device=dev) * 2 - 1
+    vis = torch.complex(re, im)
+    obs.vis = torch.where(flip[:, None], torch.conj(vis), vis).contiguous()
+    obs.weights = torch.rand((n_vis, num_polarizations), generator=gen, device=dev) * 0.9 + 0.1
+    obs.n_vis = n_vis
+    return obs
+
+
+def make_parameters(obs, num_polarizations=1, kernel_width=28, antialias_width=7.0,
+                    image_oversample=4, degrid=False):
+    """katsdpimager_amd parameter objects matching an :class:`Observation`."""
+    from katsdpimager_amd import parameters
+    fixed_i = parameters.FixedImageParameters(list(range(num_polarizations)), np.float32)
+    ip = parameters.ImageParameters(fixed_i, 1.0, None, obs.wavelength, None,
+                                    pixel_size=obs.pixel_size, pixels=obs.pixels)
+    fixed_g = parameters.FixedGridParameters(antialias_width, obs.oversample, image_oversample,
+                                             obs.max_w, kernel_width, degrid=degrid)
+    gp = parameters.GridParameters(fixed_g, obs.w_slices, obs.w_planes)
+    ap = parameters.ArrayParameters(13.5, obs.longest_baseline)
+    return ip, gp, ap
