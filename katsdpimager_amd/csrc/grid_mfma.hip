@@ -11,18 +11,28 @@
 //    window slides without moving data; cells are flushed with float atomics only when
 //    their mapping changes (the window outran them) and once at the end of the wave's range.
 //  * A visibility's K x K update is a rank-1 outer product a (x) b with
-//    a[j] = vis*wgt*conj(kv[j]), b[k] = conj(ku[k]).  Two visibilities form the K=2
-//    dimension of one MFMA: D[32x32] += A[32x2] * B[2x32]; complex = 4 real MFMAs.
-//    All per-tap arithmetic therefore runs on the matrix pipe; the VALU only prepares
-//    one A and one B element per lane per visibility pair.
-//  * The separable kernel table (W x OV rows, padded to 32 taps) lives in LDS; visibility
-//    records are staged per wave through LDS in batches of 64.
+//    a[j] = vis*wgt*conj(kv[j]), b[k] = conj(ku[k]).  The complex product is folded into ONE
+//    real MFMA per 32x16-cell tile: the MFMA K=2 dimension carries (Re a, Im a) and the N
+//    dimension carries interleaved (re, im) output columns, B = [[ku.re, -ku.im], [ku.im,
+//    ku.re]].  Two tiles cover the 32x32 window: 2 MFMAs per visibility and polarization.
+//    All per-tap arithmetic therefore runs on the matrix pipe; the VALU only prepares one A
+//    and two B elements per lane per visibility.
+//  * The separable kernel table (W x OV rows, padded to 32 taps) lives in LDS.  Visibilities
+//    are loaded 64 at a time (lane i <-> visibility i, coalesced, next batch prefetched),
+//    staged per wave in LDS and read back as broadcasts.  The scalar unit is a scarce
+//    resource (one issue slot shared by a SIMD's waves), so the window test runs once per
+//    group of 8 visibilities on bounds reduced with cross-lane shuffles; the common path
+//    is 8 x (5 LDS reads, ~17 VALU, 2 MFMA) of straight-line code.
+//  * Accumulator columns are (re, im)-interleaved, so a flush writes 128 contiguous bytes
+//    per half-wave -- the shape global float atomics run at full rate for.
 //  * Window slack 32-K lets consecutive visibilities whose footprints differ by a few
 //    cells share accumulators without any flush.
 //
 // Algorithmic work per visibility: 8*K*K*P flop (complex MAC per tap) + 6*K*P (a-vector);
-// executed: 4 MFMA x 2048 MAC per visibility pair per polarization (32x32 window).
+// executed: 2 MFMA x 2048 MAC per visibility per polarization (32x32 window).
 #include "kimg_common.h"
+#include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -30,236 +40,483 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WIN = 32;
 
+// Accumulators of one 32x32 window of complex cells, as two MFMA tiles of 32 rows x 16
+// complex columns with (re, im) interleaved along the MFMA N dimension:
+// tile t, register k, lane l  <->  row (k&3) + 8*(k>>2) + 4*(l>>5),
+//                                  complex column ((l&31)>>1) + 16*t, part l&1 (0 re, 1 im).
 template <int P>
 struct window_acc {
-    f32x16 re[P];
-    f32x16 im[P];
+    f32x16 t0[P];
+    f32x16 t1[P];
 };
 
-// Flush (atomically add and clear) every accumulator cell whose grid mapping differs
-// between window origin (Wu, Wv) and (nWu, nWv); `full` flushes everything.
-template <int P>
-__device__ inline void flush_window(window_acc<P> &acc, float *__restrict__ grid,
-                                    int64_t row_stride, int64_t pol_stride, int Gg,
-                                    int Wu, int Wv, int nWu, int nWv, bool full, int lane)
+// 32-bit mask of the window indices i whose mapping W + ((i - W) & 31) changes when the
+// origin moves from W to nW (all of them when |nW - W| >= 32).
+__device__ inline uint32_t changed_mask(int W, int nW)
 {
-    const int c = lane & 31;
+    const int d = nW - W;
+    if (d == 0)
+        return 0u;
+    if (d >= WIN || d <= -WIN)
+        return 0xffffffffu;
+    // forward move: the d lowest offsets wrap forward; backward: the |d| highest wrap back
+    const uint32_t offsets = d > 0 ? (1u << d) - 1u : ~((1u << (WIN + d)) - 1u);
+    const int rot = W & 31;                         // offset o <-> index (W + o) & 31
+    return rot ? (offsets << rot) | (offsets >> (32 - rot)) : offsets;
+}
+
+// Flush (atomically add and clear) every accumulator cell whose grid mapping differs
+// between window origin (Wu, Wv) and (nWu, nWv); `full` flushes everything.  One wave
+// instruction covers two grid rows x 128 contiguous bytes (16 complex cells), the shape
+// global float atomics run at full rate for.  Registers whose rows and columns are all
+// unaffected are skipped with a scalar test.
+template <int P>
+__device__ __attribute__((always_inline)) inline void flush_window(
+    window_acc<P> &acc, float *__restrict__ grid, int64_t row_stride, int64_t pol_stride,
+    int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane)
+{
+    const uint32_t row_mask = full ? 0xffffffffu : changed_mask(Wv, nWv);
+    const uint32_t col_mask = full ? 0xffffffffu : changed_mask(Wu, nWu);
+    const int part = lane & 1;
+    const int cx0 = (lane & 31) >> 1;
     const int h4 = (lane >> 5) * 4;
-    const int xold = Wu + ((c - Wu) & 31);
-    const int xnew = nWu + ((c - nWu) & 31);
-    const bool col_changed = full || (xold != xnew);
-    const bool x_ok = (unsigned) xold < (unsigned) Gg;
+    const uint32_t lane_rows = row_mask >> h4;      // bit rk <-> this lane's row of register k
+    int xold[2];
+    bool col_changed[2], x_ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int cx = cx0 + 16 * t;
+        xold[t] = Wu + ((cx - Wu) & 31);
+        col_changed[t] = (col_mask >> cx) & 1u;
+        x_ok[t] = (unsigned) xold[t] < (unsigned) Gg;
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int r = (k & 3) + 8 * (k >> 2) + h4;      // MFMA 32x32 C/D row of register k
+        constexpr uint32_t one = 1u;
+        const int rk = (k & 3) + 8 * (k >> 2);          // MFMA 32x32 C/D row of register k
+        if (col_mask == 0 && (row_mask & ((one << rk) | (one << (rk + 4)))) == 0)
+            continue;                                   // uniform: nothing of register k moves
+        const int r = rk + h4;
         const int yold = Wv + ((r - Wv) & 31);
-        const int ynew = nWv + ((r - nWv) & 31);
-        if (col_changed || yold != ynew) {
-            const bool ok = x_ok && (unsigned) yold < (unsigned) Gg;
-            float *cell = grid + 2 * ((int64_t) yold * row_stride + xold);
+        const bool row_changed = (lane_rows >> rk) & 1u;
+        const bool y_ok = (unsigned) yold < (unsigned) Gg;
 #pragma unroll
-            for (int p = 0; p < P; p++) {
-                const float vr = acc.re[p][k], vi = acc.im[p][k];
-                if (ok && (vr != 0.0f || vi != 0.0f)) {
-                    atomicAdd(cell + 2 * p * pol_stride, vr);
-                    atomicAdd(cell + 2 * p * pol_stride + 1, vi);
+        for (int t = 0; t < 2; t++) {
+            if (col_changed[t] || row_changed) {
+                float *cell = grid + 2 * ((int64_t) yold * row_stride + xold[t]) + part;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const float v = t ? acc.t1[p][k] : acc.t0[p][k];
+                    if (x_ok[t] && y_ok && v != 0.0f)
+                        atomicAdd(cell + 2 * p * pol_stride, v);
+                    if (t)
+                        acc.t1[p][k] = 0.0f;
+                    else
+                        acc.t0[p][k] = 0.0f;
                 }
-                acc.re[p][k] = 0.0f;
-                acc.im[p][k] = 0.0f;
             }
         }
     }
 }
 
-template <int P, int NW>
+template <int P>
+struct vis_raw {
+    int2 uv;
+    int wp;
+    float2 v[P];
+    float w[P];
+};
+
+constexpr int GROUP = 8;        // visibilities sharing one window check
+// LDS kernel-table rows hold 32 zero-padded taps.  When the LDS budget allows, each row is
+// stored twice (ROW = 64) so that tap (lane - first_tap) mod 32 is a plain "lane + offset"
+// address; otherwise (ROW = 32) the wrap costs two more VALU operations per address.
+
+// Operands of SUB staged visibilities (LDS reads in flight or landed):
+// c = (Re s, Im s) for lanes 0-31, (Im s, -Re s) for lanes 32-63, so that a = c . kv gives
+// Re(s conj kv) resp. Im(s conj kv); kv = this lane's row tap; b0/b1 = this lane's column
+// tap component (re or im, chosen by the lane's address) for the two tiles.
+template <int P, int SUB>
+struct sub_ops {
+    float2 c[P][SUB];
+    float2 kv[SUB];
+    float b0[SUB], b1[SUB];
+};
+
+// min / max over each aligned group of 8 lanes with DPP (VALU rate, no LDS round trips)
+__device__ inline int group8_min(int v)
+{
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+    return v;
+}
+
+__device__ inline int group8_max(int v)
+{
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+    return v;
+}
+
+template <int P, int NW, int SUB, int ROW>
 __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const float *__restrict__ weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float2 *__restrict__ vis, int64_t num_vis,
-    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_wave)
+    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block,
+    int stagger_pct, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *table = reinterpret_cast<float2 *>(smem);                       // [W*OV][32]
+    float2 *table = reinterpret_cast<float2 *>(smem);                       // [W*OV][ROW]
     const int table_rows = W * OV;
-    unsigned char *rec_base = smem + (size_t) table_rows * WIN * sizeof(float2);
-    const int wave_in_block = threadIdx.x >> 6;
+    unsigned char *rec_base = smem + (size_t) table_rows * ROW * sizeof(float2);
+    // wave index: uniform by construction, but the compiler must be told (readfirstlane),
+    // or every loop below is lowered to divergent (exec-masked) control flow
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int4 *heads = reinterpret_cast<int4 *>(rec_base) + wave_in_block * 64;   // (mu, mv, tu, tv)
-    float2 *samples = reinterpret_cast<float2 *>(rec_base + (size_t) NW * 64 * sizeof(int4))
-                      + wave_in_block * 64 * P;                             // [P][64]
+    // per-wave staging of one batch of 64 visibilities:
+    //   recs[64]       = byte offsets into the table of (row tu, tap (-mu) mod 32) and
+    //                    (row tv, tap (-mv) mod 32)
+    //   samples[P][64] = s = vis * density weight as (Re, Im, Im, -Re)
+    //   origins[64]    = first-tap grid coordinates (mu, mv), used only when a group jumps
+    int2 *recs = reinterpret_cast<int2 *>(rec_base) + wib * 64;
+    float4 *samples = reinterpret_cast<float4 *>(rec_base + (size_t) NW * 64 * sizeof(int2))
+                      + wib * 64 * P;
+    int2 *origins = reinterpret_cast<int2 *>(rec_base + (size_t) NW * 64 * (sizeof(int2) + P * sizeof(float4)))
+                    + wib * 64;
+    const unsigned char *tbytes = smem;
 
-    // Stage the kernel table, zero-padded from K to 32 taps per row.
-    for (int idx = threadIdx.x; idx < table_rows * WIN; idx += NW * 64) {
-        const int row = idx >> 5, t = idx & 31;
+    // This wave's contiguous range.
+    const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
+    int64_t block_end = block_start + vis_per_block;
+    if (block_end > num_vis)
+        block_end = num_vis;
+    const int64_t span = block_end > block_start ? block_end - block_start : 0;
+    const int64_t start = block_start + (span * wib / NW) / 64 * 64;
+    const int64_t end = wib == NW - 1 ? block_end : block_start + (span * (wib + 1) / NW) / 64 * 64;
+    (void) stagger_pct;
+
+    auto load_raw = [&](int64_t b, vis_raw<P> &raw) __attribute__((always_inline)) {
+        int64_t ii = b + lane;
+        ii = ii < end ? ii : end - 1;
+        raw.uv = reinterpret_cast<const int2 *>(uv)[ii];
+        raw.wp = w_plane[ii];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            raw.v[p] = vis[ii * P + p];
+    };
+    const int half = Gg / 2;
+    auto coords_ok = [&](int64_t b, const vis_raw<P> &raw) __attribute__((always_inline)) {
+        const int u = (short) (raw.uv.x & 0xffff), v = (short) (raw.uv.x >> 16);
+        const int su = (short) (raw.uv.y & 0xffff), sv = (short) (raw.uv.y >> 16);
+        return b + lane < end && (unsigned) (u + half) < (unsigned) Gg
+               && (unsigned) (v + half) < (unsigned) Gg && (unsigned) su < (unsigned) OV
+               && (unsigned) sv < (unsigned) OV && (unsigned) raw.wp < (unsigned) W;
+    };
+    auto gather = [&](int64_t b, vis_raw<P> &raw) __attribute__((always_inline)) {
+        const int u = (short) (raw.uv.x & 0xffff), v = (short) (raw.uv.x >> 16);
+        const int64_t wa = coords_ok(b, raw) ? (int64_t) (v + half) * wg_row_stride + (u + half) : 0;
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            raw.w[p] = weights_grid[wa + p * wg_pol_stride];
+    };
+
+    // Two-deep prefetch of the visibility stream: issue the first loads before staging the
+    // kernel table so that their latency hides behind it.
+    vis_raw<P> r0, r1;
+    const bool active = start < end;
+    if (active) {
+        load_raw(start, r0);
+        load_raw(start + 64, r1);
+    }
+
+    // Stage the kernel table: each row zero-padded from K to 32 taps and stored twice.
+    for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
+        const int row = idx / ROW, t = idx & 31;
         table[idx] = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
-
-    const int64_t wave = (int64_t) blockIdx.x * NW + wave_in_block;
-    const int64_t start = wave * vis_per_wave;
-    const int64_t end = start + vis_per_wave < num_vis ? start + vis_per_wave : num_vis;
-    if (start >= end)
+    if (!active)
         return;
+    gather(start, r0);
 
     const int uv_bias = (K - 1) / 2 - Gg / 2;           // grid.py:1038
-    const int half = Gg / 2;
     const int S = WIN - K;                              // window slack
-    const int c = lane & 31, h = lane >> 5;
+    const bool h = lane >= 32;                          // MFMA k index of this lane
+    const int part = lane & 1;                          // 0: real part column, 1: imaginary
+    // B operand: k=0 pairs with Re(a): (ku.re, -ku.im); k=1 with Im(a): (ku.im, ku.re).
+    // Which component a lane needs is folded into its table address, the sign is one VALU op.
+    const bool b_take_im = (h != (part != 0));
+    const float b_sign = (part && !h) ? -1.0f : 1.0f;
+    const int lane_v = (lane & 31) * 8;                                 // row tap, bytes
+    const int lane_u = ((lane & 31) >> 1) * 8 + (b_take_im ? 4 : 0);    // column tap component
+    const int lane_s = h ? 8 : 0;                                       // (Re,Im) or (Im,-Re)
 
     window_acc<P> acc;
 #pragma unroll
     for (int p = 0; p < P; p++)
         for (int k = 0; k < 16; k++) {
-            acc.re[p][k] = 0.0f;
-            acc.im[p][k] = 0.0f;
+            acc.t0[p][k] = 0.0f;
+            acc.t1[p][k] = 0.0f;
         }
     bool have = false;
     int Wu = 0, Wv = 0;
 
-    for (int64_t b = start; b < end; b += 64) {
-        // ---- load a batch of up to 64 visibilities, lane i <-> visibility b+i ----------
-        {
-            const int64_t i = b + lane;
-            const bool valid = i < end;
-            const int64_t ii = valid ? i : end - 1;
-            const int2 packed = reinterpret_cast<const int2 *>(uv)[ii];
-            const int u = (short) (packed.x & 0xffff), v = (short) (packed.x >> 16);
-            const int su = (short) (packed.y & 0xffff), sv = (short) (packed.y >> 16);
-            const int wp = w_plane[ii];
-            const int wu = u + half, wv = v + half;
-            const bool ok = valid && (unsigned) wu < (unsigned) Gg && (unsigned) wv < (unsigned) Gg
-                            && (unsigned) su < (unsigned) OV && (unsigned) sv < (unsigned) OV
-                            && (unsigned) wp < (unsigned) W;
-            int4 head;
-            head.x = u - uv_bias;
-            head.y = v - uv_bias;
-            head.z = ok ? wp * OV + su : 0;
-            head.w = ok ? wp * OV + sv : 0;
-            heads[lane] = head;
-            const int64_t wa = ok ? (int64_t) wv * wg_row_stride + wu : 0;
+    // Move the window so that [lo_u, hi_u] x [lo_v, hi_v] (first-tap coordinates) fits.
+    auto fit_window = [&](int lo_u, int hi_u, int lo_v, int hi_v) __attribute__((always_inline)) {
+        if (!have) {
+            Wu = lo_u - (S - (hi_u - lo_u)) / 2;
+            Wv = lo_v - (S - (hi_v - lo_v)) / 2;
+            have = true;
+            return;
+        }
+        const bool bad_u = lo_u < Wu || hi_u > Wu + S;
+        const bool bad_v = lo_v < Wv || hi_v > Wv + S;
+        if (!(bad_u || bad_v))
+            return;
+        // leave all the slack ahead in the direction of travel (tracks are smooth curves)
+        const int nWu = !bad_u ? Wu : (hi_u > Wu + S ? lo_u : hi_u - S);
+        const int nWv = !bad_v ? Wv : (hi_v > Wv + S ? lo_v : hi_v - S);
+        const bool full = nWu - Wu >= WIN || Wu - nWu >= WIN || nWv - Wv >= WIN || Wv - nWv >= WIN;
+        if (!(dbg & 2))
+            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane);
+        Wu = nWu;
+        Wv = nWv;
+    };
+
+    // LDS byte addresses of this lane's row tap / column tap for a staged record
+    auto addr_v = [&](int ry) __attribute__((always_inline)) {
+        return ROW == 64 ? ry + lane_v : (ry & ~0xff) | ((ry + lane_v) & 0xf8);
+    };
+    auto addr_u = [&](int rx) __attribute__((always_inline)) {
+        return ROW == 64 ? rx + lane_u : (rx & ~0xff) | ((rx + lane_u) & 0xfc);
+    };
+
+    // ---- software-pipeline stages over sub-blocks of SUB staged visibilities ---------------
+    int2 rec[SUB];
+    auto stage_a = [&](int first) __attribute__((always_inline)) {         // record reads
+#pragma unroll
+        for (int t = 0; t < SUB; t++)
+            rec[t] = recs[first + t];
+    };
+    auto stage_b = [&](sub_ops<P, SUB> &o, int first) __attribute__((always_inline)) {     // sample + kernel-table reads
+#pragma unroll
+        for (int t = 0; t < SUB; t++) {
+            const int au = addr_u(rec[t].x);
+            o.kv[t] = *reinterpret_cast<const float2 *>(tbytes + addr_v(rec[t].y));
+            o.b0[t] = *reinterpret_cast<const float *>(tbytes + au);
+            o.b1[t] = *reinterpret_cast<const float *>(tbytes + (ROW == 64 ? au + 128 : au ^ 128));  // column + 16
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                o.c[p][t] = *reinterpret_cast<const float2 *>(
+                    reinterpret_cast<const unsigned char *>(samples + p * 64 + first + t) + lane_s);
+        }
+    };
+    auto mfma_vis = [&](const sub_ops<P, SUB> &o, int t) __attribute__((always_inline)) {
+        const float b0 = o.b0[t] * b_sign;
+        const float b1 = o.b1[t] * b_sign;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            // a = s * conj(kv): lanes 0-31 carry Re(a), lanes 32-63 Im(a)
+            const float a = fmaf(o.c[p][t].x, o.kv[t].x, o.c[p][t].y * o.kv[t].y);
+            acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc.t0[p], 0, 0, 0);
+            acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc.t1[p], 0, 0, 0);
+        }
+    };
+    auto stage_c = [&](const sub_ops<P, SUB> &o) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < SUB; t++)
+            mfma_vis(o, t);
+    };
+    // A group whose visibilities do not share one window position (a jump inside the group):
+    // rolled loop, window positioned per visibility, operands re-read from LDS.  Rare.
+    auto slow_group = [&](int first) __attribute__((always_inline)) {
+        for (int t = 0; t < GROUP; t++) {
+            const int idx = first + t;
+            const int2 org = origins[idx];
+            float2 c[P];
+            bool nz = false;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                float2 s = make_float2(0.0f, 0.0f);
-                if (ok) {
-                    const float wgt = weights_grid[wa + p * wg_pol_stride];
-                    const float2 raw = vis[ii * P + p];
-                    s = make_float2(raw.x * wgt, raw.y * wgt);      // grid.py:1046
-                }
-                samples[p * 64 + lane] = s;
+                c[p] = *reinterpret_cast<const float2 *>(
+                    reinterpret_cast<const unsigned char *>(samples + p * 64 + idx) + lane_s);
+                nz |= (c[p].x != 0.0f) | (c[p].y != 0.0f);
+            }
+            if (!__builtin_amdgcn_readfirstlane((int) nz))
+                continue;
+            fit_window(__builtin_amdgcn_readfirstlane(org.x), __builtin_amdgcn_readfirstlane(org.x),
+                       __builtin_amdgcn_readfirstlane(org.y), __builtin_amdgcn_readfirstlane(org.y));
+            const int2 r = recs[idx];
+            const int au = addr_u(r.x);
+            const float2 kv = *reinterpret_cast<const float2 *>(tbytes + addr_v(r.y));
+            const float b0 = *reinterpret_cast<const float *>(tbytes + au) * b_sign;
+            const float b1 = *reinterpret_cast<const float *>(tbytes + (ROW == 64 ? au + 128 : au ^ 128)) * b_sign;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const float a = fmaf(c[p].x, kv.x, c[p].y * kv.y);
+                acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc.t0[p], 0, 0, 0);
+                acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc.t1[p], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    for (int64_t b = start; b < end; b += 64) {
+        // ---- stage batch b (lane i <-> visibility b + i) and its per-group bounds ----------
+        int gmin_u, gmax_u, gmin_v, gmax_v;
+        {
+            const bool ok = coords_ok(b, r0);
+            const int u = (short) (r0.uv.x & 0xffff), v = (short) (r0.uv.x >> 16);
+            const int su = (short) (r0.uv.y & 0xffff), sv = (short) (r0.uv.y >> 16);
+            const int mu = u - uv_bias, mv = v - uv_bias;
+            // row byte offset (a multiple of ROW * 8) + tap byte offset (< 256)
+            int2 r;
+            r.x = (ok ? (r0.wp * OV + su) * (ROW * 8) : 0) + ((-mu) & 31) * 8;
+            r.y = (ok ? (r0.wp * OV + sv) * (ROW * 8) : 0) + ((-mv) & 31) * 8;
+            recs[lane] = r;
+            origins[lane] = make_int2(mu, mv);
+            bool live = false;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const float2 sp = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
+                                     : make_float2(0.0f, 0.0f);             // grid.py:1046
+                samples[p * 64 + lane] = make_float4(sp.x, sp.y, sp.y, -sp.x);
+                live |= (sp.x != 0.0f) | (sp.y != 0.0f);
+            }
+            // bounds over each aligned group of 8 lanes; dead visibilities do not constrain
+            gmin_u = group8_min(live ? mu : INT_MAX);
+            gmax_u = group8_max(live ? mu : INT_MIN);
+            gmin_v = group8_min(live ? mv : INT_MAX);
+            gmax_v = group8_max(live ? mv : INT_MIN);
+        }
+        // advance the global prefetch pipeline: b+64 gets its (dependent) weight gather,
+        // b+128 its raw loads
+        r0 = r1;
+        if (b + 64 < end)
+            gather(b + 64, r0);
+        if (b + 128 < end)
+            load_raw(b + 128, r1);
+        __builtin_amdgcn_wave_barrier();        // LDS is in-order per wave; just pin the order
 
         const int count = end - b < 64 ? (int) (end - b) : 64;
-        const int npairs = (count + 1) >> 1;
-        for (int q = 0; q < npairs; q++) {
-            // lanes 0-31 take visibility 2q, lanes 32-63 visibility 2q+1
-            const int ri = 2 * q + h;
-            const int4 head = heads[ri];
-            float2 s[P];
-            bool nonzero = false;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                s[p] = samples[p * 64 + ri];
-                nonzero |= (s[p].x != 0.0f) | (s[p].y != 0.0f);
+        const int npairs = (count + 2 * SUB - 1) / (2 * SUB);
+        sub_ops<P, SUB> X, Y;
+        stage_a(0);
+        stage_b(X, 0);
+        stage_a(SUB);
+        __builtin_amdgcn_sched_barrier(0);
+        // Outer loop: decide how the group starting at pair q is handled (this is where the
+        // window moves and cells are flushed).  Inner loop: the hot path, free of any flush
+        // code so that the accumulators stay put in their registers; it runs on through the
+        // following groups for as long as they fit the current window.
+        int q = 0;
+        while (q < npairs) {
+            bool live;
+            {
+                const int first = q * 2 * SUB;
+                const int lo_u = __builtin_amdgcn_readlane(gmin_u, first);
+                const int hi_u = __builtin_amdgcn_readlane(gmax_u, first);
+                const int lo_v = __builtin_amdgcn_readlane(gmin_v, first);
+                const int hi_v = __builtin_amdgcn_readlane(gmax_v, first);
+                const bool any = lo_u <= hi_u;
+                const bool jump = hi_u - lo_u > S || hi_v - lo_v > S;
+                live = any && !jump;
+                if (live)
+                    fit_window(lo_u, hi_u, lo_v, hi_v);     // whole group shares one window
+                else if (any)
+                    slow_group(first);
             }
-            const float2 kv = table[head.w * WIN + ((c - head.y) & 31)];
-            const float2 ku = table[head.z * WIN + ((c - head.x) & 31)];
-            // a = s * conj(kv)
-            float ar[P], ai[P];
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                ar[p] = fmaf(s[p].x, kv.x, s[p].y * kv.y);
-                ai[p] = fmaf(s[p].y, kv.x, -s[p].x * kv.y);
-            }
-            const int muA = __builtin_amdgcn_readfirstlane(head.x);
-            const int mvA = __builtin_amdgcn_readfirstlane(head.y);
-            const int muB = __builtin_amdgcn_readlane(head.x, 32);
-            const int mvB = __builtin_amdgcn_readlane(head.y, 32);
-            const unsigned long long nz = __ballot(nonzero);
-            int pend = ((nz & 0xffffffffull) ? 1 : 0) | ((nz >> 32) ? 2 : 0);
-            while (pend) {
-                const bool first_b = !(pend & 1);
-                const int fmu = first_b ? muB : muA, fmv = first_b ? mvB : mvA;
-                if (!have) {
-                    Wu = fmu - S / 2;
-                    Wv = fmv - S / 2;
-                    have = true;
-                } else if ((unsigned) (fmu - Wu) > (unsigned) S || (unsigned) (fmv - Wv) > (unsigned) S) {
-                    const int nWu = (unsigned) (fmu - Wu) > (unsigned) S ? fmu - S / 2 : Wu;
-                    const int nWv = (unsigned) (fmv - Wv) > (unsigned) S ? fmv - S / 2 : Wv;
-                    const bool full = nWu - Wu >= WIN || Wu - nWu >= WIN
-                                      || nWv - Wv >= WIN || Wv - nWv >= WIN;
-                    flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv,
-                                    full, lane);
-                    Wu = nWu;
-                    Wv = nWv;
+            for (;;) {
+                const int first = q * 2 * SUB;
+                // clamp look-ahead indices at the end of the batch (those operands are unused)
+                const int next = q + 1 < npairs ? first + 2 * SUB : first;
+                stage_b(Y, first + SUB);
+                stage_a(next);
+                __builtin_amdgcn_sched_barrier(0);
+                if (live)
+                    stage_c(X);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_b(X, next);
+                stage_a(next + SUB);
+                __builtin_amdgcn_sched_barrier(0);
+                if (live)
+                    stage_c(Y);
+                __builtin_amdgcn_sched_barrier(0);
+                q++;
+                if (q >= npairs)
+                    break;
+                if ((q * 2 * SUB) % GROUP == 0) {
+                    // peek at the next group: stay in the hot loop only if it needs no flush
+                    const int lo_u = __builtin_amdgcn_readlane(gmin_u, next);
+                    const int hi_u = __builtin_amdgcn_readlane(gmax_u, next);
+                    const int lo_v = __builtin_amdgcn_readlane(gmin_v, next);
+                    const int hi_v = __builtin_amdgcn_readlane(gmax_v, next);
+                    const bool fits = have && lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + S
+                                      && lo_v >= Wv && hi_v <= Wv + S;
+                    if (!fits)
+                        break;
+                    live = true;
                 }
-                int act = first_b ? 2 : 1;
-                if (pend == 3 && (unsigned) (muB - Wu) <= (unsigned) S
-                    && (unsigned) (mvB - Wv) <= (unsigned) S)
-                    act = 3;
-                const bool on = (act >> h) & 1;
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const float xr = on ? ar[p] : 0.0f;
-                    const float xi = on ? ai[p] : 0.0f;
-                    // (xr + i xi) * (ku.x - i ku.y)
-                    acc.re[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, ku.x, acc.re[p], 0, 0, 0);
-                    acc.re[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, ku.y, acc.re[p], 0, 0, 0);
-                    acc.im[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, ku.x, acc.im[p], 0, 0, 0);
-                    acc.im[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(-xr, ku.y, acc.im[p], 0, 0, 0);
-                }
-                pend &= ~act;
             }
         }
         // the next batch overwrites this wave's staging area
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (have)
+    if (have && !(dbg & 1))
         flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane);
 }
 
 template <int P>
 constexpr int waves_per_block()
 {
-    return P == 1 ? 16 : 8;
+    return 8;
 }
 
-size_t lds_bytes(int P, int NW, int W, int OV)
+size_t lds_bytes(int P, int NW, int W, int OV, int row)
 {
-    return (size_t) W * OV * WIN * sizeof(float2) + (size_t) NW * 64 * (sizeof(int4) + P * sizeof(float2));
+    return (size_t) W * OV * row * sizeof(float2)
+           + (size_t) NW * 64 * (sizeof(int2) + P * sizeof(float4) + sizeof(int2));
 }
 
-template <int P>
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <int P, int ROW>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
            int W, int OV, int K, hipStream_t stream)
 {
     constexpr int NW = waves_per_block<P>();
-    const size_t lds = lds_bytes(P, NW, W, OV);
+    constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
+    const size_t lds = lds_bytes(P, NW, W, OV, ROW);
     static bool attr_set = false;
     if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KIMG_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
-    // One resident block per CU; every wave streams a contiguous range, a multiple of 64.
-    const int blocks_max = 256;
-    int64_t vis_per_wave = (num_vis + (int64_t) blocks_max * NW - 1) / ((int64_t) blocks_max * NW);
-    vis_per_wave = (vis_per_wave + 63) / 64 * 64;
-    if (vis_per_wave < 64)
-        vis_per_wave = 64;
-    const int64_t nwaves = (num_vis + vis_per_wave - 1) / vis_per_wave;
-    const int blocks = (int) ((nwaves + NW - 1) / NW);
-    grid_mfma_kernel<P, NW><<<blocks, NW * 64, lds, stream>>>(
+    static int dbg = -1, blocks_max_env = 0;
+    if (dbg < 0) {
+        const char *e = getenv("KIMG_GRID_DEBUG");      // timing experiments only
+        dbg = e ? atoi(e) : 0;
+        const char *b = getenv("KIMG_GRID_BLOCKS");
+        blocks_max_env = b ? atoi(b) : 0;
+    }
+    // 8-wave blocks, as many resident per CU as the LDS (kernel table + staging) allows;
+    // every block streams a contiguous span (a multiple of 64).
+    const int per_cu = lds <= LDS_LIMIT / 2 ? 2 : 1;
+    const int blocks_max = blocks_max_env > 0 ? blocks_max_env : 256 * per_cu;
+    int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
+    vis_per_block = (vis_per_block + 63) / 64 * 64;
+    if (vis_per_block < 64 * NW)
+        vis_per_block = 64 * NW;
+    const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
+    grid_mfma_kernel<P, NW, SUB, ROW><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, K, vis_per_wave);
+        num_vis, kern, W, OV, K, vis_per_block, 0, dbg);
     return kimg_launch_status();
 }
 
@@ -269,8 +526,7 @@ bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_wi
 {
     if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
         return false;
-    const int NW = P == 1 ? 16 : 8;
-    return lds_bytes(P, NW, w_planes, oversample) <= 160 * 1024;
+    return lds_bytes(P, 8, w_planes, oversample, 32) <= LDS_LIMIT;
 }
 
 size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P)
@@ -288,7 +544,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 {
     (void) workspace;
     (void) workspace_bytes;
-#define LAUNCH(PP) return launch<PP>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
+    const bool doubled = lds_bytes(P, 8, w_planes, oversample, 64) <= LDS_LIMIT;
+#define LAUNCH(PP) if (doubled) return launch<PP, 64>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
+        weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream); \
+    return launch<PP, 32>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
         weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
     switch (P) {
