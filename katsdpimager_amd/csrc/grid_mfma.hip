@@ -233,10 +233,24 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         load_raw(start + 64, r1);
     }
 
-    // Stage the kernel table: each row zero-padded from K to 32 taps and stored twice.
-    for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
-        const int row = idx / ROW, t = idx & 31;
-        table[idx] = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
+    // Stage the kernel table: each row zero-padded from K to 32 taps (and stored twice when
+    // ROW == 64).  Two taps (16 bytes) per thread and iteration when K is even.
+    if ((K & 1) == 0) {
+        const float4 *kern2 = reinterpret_cast<const float4 *>(kern);
+        float4 *table2 = reinterpret_cast<float4 *>(smem);
+        for (int idx = threadIdx.x; idx < table_rows * 16; idx += NW * 64) {
+            const int row = idx >> 4, t2 = idx & 15;
+            const float4 v = 2 * t2 < K ? kern2[((int64_t) row * K >> 1) + t2]
+                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            table2[row * (ROW / 2) + t2] = v;
+            if (ROW == 64)
+                table2[row * (ROW / 2) + 16 + t2] = v;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
+            const int row = idx / ROW, t = idx & 31;
+            table[idx] = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
+        }
     }
     __syncthreads();
     if (!active)
@@ -482,13 +496,12 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int ROW>
+template <int P, int ROW, int NW>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
            int W, int OV, int K, hipStream_t stream)
 {
-    constexpr int NW = waves_per_block<P>();
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
     const size_t lds = lds_bytes(P, NW, W, OV, ROW);
     static bool attr_set = false;
@@ -544,11 +557,25 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 {
     (void) workspace;
     (void) workspace_bytes;
-    const bool doubled = lds_bytes(P, 8, w_planes, oversample, 64) <= LDS_LIMIT;
-#define LAUNCH(PP) if (doubled) return launch<PP, 64>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
+    const bool doubled = lds_bytes(P, P == 1 ? 12 : 8, w_planes, oversample, 64) <= LDS_LIMIT;
+    static int nw_env = -1;
+    if (nw_env < 0) {
+        const char *e = getenv("KIMG_GRID_WAVES");
+        nw_env = e ? atoi(e) : 0;
+    }
+    // P = 1: 156 VGPRs -> 3 waves per SIMD; 12-wave blocks, one per CU (LDS-bound)
+    if (P == 1 && doubled && nw_env != 8) {
+#define LAUNCH_NW(NWV) return launch<1, 64, NWV>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
+        weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
+        if (nw_env == 4) LAUNCH_NW(4);
+        LAUNCH_NW(12);
+#undef LAUNCH_NW
+    }
+#define LAUNCH(PP) if (doubled) return launch<PP, 64, 8>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
         weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream); \
-    return launch<PP, 32>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
+    return launch<PP, 32, 8>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
         weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
     switch (P) {
