@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void subtract_psf_kernel(
 // ---- device-resident minor cycles ------------------------------------------------------
 struct clean_state {
     int count;          // cycles completed
-    int done;           // threshold reached
+    int done;           // threshold reached (or `limit` cycles done)
+    int limit;          // maximum number of cycles for this call
     int pos_y, pos_x;
     float scale[4];     // loop_gain * pixel at the current peak
 };
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
     int t = peak_tile(tile_max, num_tiles, value);
     if (threadIdx.x != 0)
         return;
-    if (t < 0 || value < threshold) {           // clean.py:1065-1066
+    if (t < 0 || value < threshold || state->count >= state->limit) {   // clean.py:1065-1066
         state->done = 1;
         return;
     }
@@ -462,6 +463,97 @@ extern "C" size_t kimg_clean_state_bytes(int num_polarizations)
     return sizeof(clean_state);
 }
 
+namespace {
+
+__global__ void init_state_kernel(clean_state *state, int limit)
+{
+    state->limit = limit;
+}
+
+struct cycle_args {
+    float *dirty, *model;
+    int64_t row_stride, pol_stride;
+    int width, height, P;
+    const float *psf;
+    int64_t psf_row_stride, psf_pol_stride;
+    int psf_width, psf_height, patch_width, patch_height, border, mode;
+    float loop_gain, threshold;
+    float *tile_max;
+    int32_t *tile_pos;
+    int tiles_x, tiles_y;
+    clean_state *state;
+    float *log;
+};
+
+// One minor cycle = two dependent launches (peak + threshold test, then subtract + tile update).
+int enqueue_cycle(const cycle_args &a, hipStream_t s)
+{
+    dim3 g(kimg_divup(a.patch_width, TILE) + 1, kimg_divup(a.patch_height, TILE) + 1);
+    const int num_tiles = a.tiles_x * a.tiles_y;
+    if (a.mode == KIMG_CLEAN_I) {
+        cycle_find_peak_kernel<KIMG_CLEAN_I><<<1, 1024, 0, s>>>(
+            a.dirty, a.model, a.row_stride, a.pol_stride, a.P, a.tile_max, a.tile_pos, num_tiles,
+            a.loop_gain, a.threshold, a.state, a.log);
+        cycle_subtract_update_kernel<KIMG_CLEAN_I><<<g, 256, 0, s>>>(
+            a.dirty, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf, a.psf_row_stride,
+            a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width, a.patch_height, a.border,
+            a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y, a.state);
+    } else {
+        cycle_find_peak_kernel<KIMG_CLEAN_SUMSQ><<<1, 1024, 0, s>>>(
+            a.dirty, a.model, a.row_stride, a.pol_stride, a.P, a.tile_max, a.tile_pos, num_tiles,
+            a.loop_gain, a.threshold, a.state, a.log);
+        cycle_subtract_update_kernel<KIMG_CLEAN_SUMSQ><<<g, 256, 0, s>>>(
+            a.dirty, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf, a.psf_row_stride,
+            a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width, a.patch_height, a.border,
+            a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y, a.state);
+    }
+    return kimg_launch_status();
+}
+
+// hipGraph of GRAPH_CYCLES minor cycles, cached per argument set: the minor-cycle loop is
+// launch-bound, and replaying a captured graph costs far less host time than 2 launches
+// per cycle.  The device-side `limit` makes surplus cycles of the last replay no-ops.
+constexpr int GRAPH_CYCLES = 64;
+constexpr int GRAPH_CACHE = 4;
+
+struct graph_entry {
+    bool valid;
+    cycle_args args;
+    hipGraphExec_t exec;
+};
+graph_entry graph_cache[GRAPH_CACHE];
+int graph_next = 0;
+
+hipGraphExec_t cycles_graph(const cycle_args &a, hipStream_t s)
+{
+    for (int i = 0; i < GRAPH_CACHE; i++)
+        if (graph_cache[i].valid && memcmp(&graph_cache[i].args, &a, sizeof(a)) == 0)
+            return graph_cache[i].exec;
+    hipGraph_t graph;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+        return nullptr;
+    int rc = 0;
+    for (int i = 0; i < GRAPH_CYCLES && rc == 0; i++)
+        rc = enqueue_cycle(a, s);
+    if (hipStreamEndCapture(s, &graph) != hipSuccess || rc != 0)
+        return nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void) hipGraphDestroy(graph);
+    if (e != hipSuccess)
+        return nullptr;
+    graph_entry &slot = graph_cache[graph_next];
+    graph_next = (graph_next + 1) % GRAPH_CACHE;
+    if (slot.valid)
+        (void) hipGraphExecDestroy(slot.exec);
+    slot.valid = true;
+    slot.args = a;
+    slot.exec = exec;
+    return exec;
+}
+
+} // namespace
+
 extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                                  int64_t pol_stride, int width, int height, int num_polarizations,
                                  const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
@@ -477,29 +569,31 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(state, 0, sizeof(clean_state), s));
-    clean_state *st = static_cast<clean_state *>(state);
-    dim3 g(kimg_divup(patch_width, TILE) + 1, kimg_divup(patch_height, TILE) + 1);
-    const int num_tiles = tiles_x * tiles_y;
-    for (int i = 0; i < max_cycles; i++) {
-        if (mode == KIMG_CLEAN_I) {
-            cycle_find_peak_kernel<KIMG_CLEAN_I><<<1, 1024, 0, s>>>(
-                dirty, model, row_stride, pol_stride, num_polarizations, tile_max, tile_pos,
-                num_tiles, loop_gain, threshold, st, log);
-            cycle_subtract_update_kernel<KIMG_CLEAN_I><<<g, 256, 0, s>>>(
-                dirty, row_stride, pol_stride, width, height, num_polarizations, psf,
-                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
-                border, tile_max, tile_pos, tiles_x, tiles_y, st);
-        } else {
-            cycle_find_peak_kernel<KIMG_CLEAN_SUMSQ><<<1, 1024, 0, s>>>(
-                dirty, model, row_stride, pol_stride, num_polarizations, tile_max, tile_pos,
-                num_tiles, loop_gain, threshold, st, log);
-            cycle_subtract_update_kernel<KIMG_CLEAN_SUMSQ><<<g, 256, 0, s>>>(
-                dirty, row_stride, pol_stride, width, height, num_polarizations, psf,
-                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
-                border, tile_max, tile_pos, tiles_x, tiles_y, st);
+    init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(state), max_cycles);
+    cycle_args a;
+    memset(&a, 0, sizeof(a));       // padding bytes take part in the cache key comparison
+    a.dirty = dirty; a.model = model; a.row_stride = row_stride; a.pol_stride = pol_stride;
+    a.width = width; a.height = height; a.P = num_polarizations; a.psf = psf;
+    a.psf_row_stride = psf_row_stride; a.psf_pol_stride = psf_pol_stride;
+    a.psf_width = psf_width; a.psf_height = psf_height; a.patch_width = patch_width;
+    a.patch_height = patch_height; a.border = border; a.mode = mode; a.loop_gain = loop_gain;
+    a.threshold = threshold; a.tile_max = tile_max; a.tile_pos = tile_pos; a.tiles_x = tiles_x;
+    a.tiles_y = tiles_y; a.state = static_cast<clean_state *>(state); a.log = log;
+    int done = 0;
+    if (max_cycles >= GRAPH_CYCLES / 2) {
+        hipGraphExec_t exec = cycles_graph(a, s);
+        if (exec) {
+            for (; done < max_cycles; done += GRAPH_CYCLES)
+                KIMG_HIP(hipGraphLaunch(exec, s));
+            return 0;
         }
     }
-    return kimg_launch_status();
+    for (; done < max_cycles; done++) {
+        int rc = enqueue_cycle(a, s);
+        if (rc)
+            return rc;
+    }
+    return 0;
 }
 
 extern "C" int kimg_psf_patch(const float *psf, int64_t row_stride, int64_t pol_stride,
