@@ -58,7 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
     import synth
-    from katsdpimager_amd import accel, grid, image, clean, parameters, _lib
+    from katsdpimager_amd import accel, grid, image, clean, parameters, parallel, _lib
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -78,18 +78,19 @@ def main():
 
     # ---- shared tables: computed on rank 0, broadcast over RCCL/xGMI -------
     t_bcast = 0.0
-    bl = torch.from_numpy(synth.baselines_equatorial()).to(dev) if rank == 0 \
-        else torch.empty((2016, 3), dtype=torch.float64, device=dev)
+    shared = {'baselines': torch.from_numpy(synth.baselines_equatorial()).to(dev) if rank == 0
+              else torch.empty((2016, 3), dtype=torch.float64, device=dev)}
     if world > 1:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(bl, src=0)
+        parallel.broadcast_shared(shared, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-        assert torch.equal(bl.cpu(), torch.from_numpy(synth.baselines_equatorial()))
+        assert torch.equal(shared['baselines'].cpu(), torch.from_numpy(synth.baselines_equatorial()))
 
-    # ---- this rank's channel ------------------------------------------------------------
-    chan_scale = 1.0 if world == 1 else 1.0 + 0.03 * (2.0 * rank / (world - 1) - 1.0)
+    # ---- this rank's channel (channel c -> rank c mod world; one channel per GPU here) ----
+    channel = parallel.assign_channels(world, world, rank)[0]
+    chan_scale = parallel.channel_frequency_scale(channel, world)
     # uv coordinates scale with frequency: keep the footprint inside the grid for every channel
     cover = 0.30 / (1.03 if world > 1 else 1.0)
     obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=cover,
@@ -153,11 +154,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = parallel.max_over_ranks(t1 - t0, dev)
     ms_per_step = elapsed / args.steps * 1e3
     mvis = world * n_vis / (elapsed / args.steps) / 1e6
 

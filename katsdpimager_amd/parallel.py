@@ -1,0 +1,66 @@
+"""Channel-sharded multi-GPU execution (new relative to the reference, which is single
+device and loops over channels serially, frontend.py:749-767).
+
+Spectral channels are independent (own kernel table, visibilities, weights, PSF, images,
+CLEAN loop), so the path shards with no data-path collective: channel c runs on rank
+c mod world_size, one process per GPU.  The only collectives are a start-up broadcast of
+channel-independent tables from the loading rank (RCCL over xGMI on GPUs; gloo in CPU
+tests) and small reductions/gathers of per-channel statistics and timings.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size), (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def assign_channels(num_channels, world_size, rank):
+    """Channels imaged by `rank`: c with c mod world_size == rank."""
+    if not 0 <= rank < world_size:
+        raise ValueError('rank {} outside world of {}'.format(rank, world_size))
+    return list(range(rank, num_channels, world_size))
+
+
+def channel_frequency_scale(channel, num_channels, spread=0.03):
+    """Relative frequency of a channel in a band of +-spread around 1 (uvw in wavelengths
+    scales with it); 1.0 for a single channel."""
+    if num_channels <= 1:
+        return 1.0
+    return 1.0 + spread * (2.0 * channel / (num_channels - 1) - 1.0)
+
+
+def broadcast_shared(tensors, src=0):
+    """Broadcast channel-independent tables (dict name -> tensor, allocated with the right
+    shape/dtype on every rank) from `src`, in place.  No-op for a single process."""
+    rank, size = world()
+    if size == 1:
+        return tensors
+    for name in sorted(tensors):
+        dist.broadcast(tensors[name], src=src)
+    return tensors
+
+
+def max_over_ranks(value, device='cpu'):
+    """Maximum of a Python float over all ranks (timings)."""
+    rank, size = world()
+    if size == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def gather_stats(values, device='cpu'):
+    """All-gather a fixed-length list of floats (per-channel statistics such as noise, peak,
+    minor cycles); returns a [world_size][len(values)] tensor on every rank."""
+    rank, size = world()
+    t = torch.tensor([values], dtype=torch.float64, device=device)
+    if size == 1:
+        return t
+    out = [torch.empty_like(t) for _ in range(size)]
+    dist.all_gather(out, t)
+    return torch.cat(out, dim=0)

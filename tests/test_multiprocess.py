@@ -1,0 +1,108 @@
+"""world_size-2 tests of the channel-sharding layer on the gloo backend (CPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from katsdpimager_amd import parallel
+        import synth
+        assert parallel.world() == (rank, world_size)
+        # 1. channel assignment partitions the channels
+        mine = parallel.assign_channels(5, world_size, rank)
+        # 2. shared tables: only rank 0 computes them, everybody ends up with the same bytes
+        ref = torch.from_numpy(synth.baselines_equatorial())
+        tables = {'baselines': ref.clone() if rank == 0 else torch.zeros_like(ref),
+                  'taper': torch.arange(16, dtype=torch.float32) if rank == 0
+                  else torch.empty(16, dtype=torch.float32)}
+        parallel.broadcast_shared(tables, src=0)
+        assert torch.equal(tables['baselines'], ref)
+        assert torch.equal(tables['taper'], torch.arange(16, dtype=torch.float32))
+        # 3. every rank builds its own channel from the shared table: different channels,
+        #    deterministic per channel
+        obs = synth.make_observation(256, 4096, 8, device='cpu', seed=2 + mine[0],
+                                     channel_scale=parallel.channel_frequency_scale(mine[0], 5))
+        checksum = float(obs.uv.to(torch.float64).abs().sum())
+        # 4. timing reduction and statistics gather
+        slowest = parallel.max_over_ranks(1.0 + rank)
+        stats = parallel.gather_stats([float(rank), checksum, float(len(mine))])
+        np.save(os.path.join(result_dir, 'rank%d.npy' % rank),
+                np.array([slowest, checksum, len(mine)] + stats.flatten().tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_channel_sharding_world2(tmp_path):
+    world_size = 2
+    mp.spawn(_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
+    r = [np.load(os.path.join(str(tmp_path), 'rank%d.npy' % i)) for i in range(world_size)]
+    assert r[0][0] == r[1][0] == 2.0                        # max over ranks
+    assert r[0][1] != r[1][1]                               # different channels
+    assert r[0][2] + r[1][2] == 5                           # all channels covered once
+    np.testing.assert_array_equal(r[0][3:], r[1][3:])       # identical gathered stats
+    stats = r[0][3:].reshape(world_size, 3)
+    np.testing.assert_array_equal(stats[:, 0], [0.0, 1.0])
+    assert stats[0, 1] == r[0][1] and stats[1, 1] == r[1][1]
+
+
+def test_sharding_helpers_single_process():
+    sys.path.insert(0, ROOT)
+    from katsdpimager_amd import parallel
+    assert parallel.world() == (0, 1)
+    assert parallel.assign_channels(8, 8, 3) == [3]
+    assert parallel.assign_channels(3, 8, 5) == []
+    covered = sorted(c for r in range(4) for c in parallel.assign_channels(10, 4, r))
+    assert covered == list(range(10))
+    with pytest.raises(ValueError):
+        parallel.assign_channels(4, 2, 2)
+    assert parallel.channel_frequency_scale(0, 1) == 1.0
+    assert parallel.channel_frequency_scale(0, 8) == pytest.approx(0.97)
+    assert parallel.channel_frequency_scale(7, 8) == pytest.approx(1.03)
+    assert parallel.max_over_ranks(3.5) == 3.5
+    assert parallel.gather_stats([1.0, 2.0]).tolist() == [[1.0, 2.0]]
+    t = {'x': torch.ones(3)}
+    assert parallel.broadcast_shared(t) is t
+
+
+def test_synthetic_observation_matches_oracle_quantisation():
+    """tools/synth.py quantises with torch; the oracle restates preprocess.cpp with numpy."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import synth
+    from oracle import kimg_oracle as orc
+    obs = synth.make_observation(512, 20000, 16, device='cpu')
+    # rebuild float uvw in cells the way synth does, then quantise with the oracle
+    bl = torch.from_numpy(synth.baselines_equatorial())
+    assert obs.uv.shape == (20000, 4) and obs.uv.dtype == torch.int16
+    uv = obs.uv.numpy()
+    assert uv[:, 2:].min() >= 0 and uv[:, 2:].max() < 8
+    assert obs.w_plane.min() >= 8 and obs.w_plane.max() < 16      # w >= 0 after the flip, 1 slice
+    assert np.abs(uv[:, :2]).max() <= int(0.30 * 512) + 1
+    # the oracle's splitter agrees with torch's on the same float32 inputs
+    x = (np.random.RandomState(0).uniform(-150, 150, 5000)).astype(np.float32)
+    pix, sub = orc.subpixel_coord(x, 8)
+    xs = torch.floor(torch.from_numpy(x) * 8.0).to(torch.int32)
+    tp = torch.div(xs, 8, rounding_mode='floor')
+    np.testing.assert_array_equal(pix, tp.numpy())
+    np.testing.assert_array_equal(sub, (xs - tp * 8).numpy())
+    assert bl.shape == (2016, 3)
