@@ -141,7 +141,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
         step()
