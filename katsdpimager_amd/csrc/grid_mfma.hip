@@ -329,21 +329,25 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                     reinterpret_cast<const unsigned char *>(samples + p * 64 + first + t) + lane_s);
         }
     };
-    auto mfma_vis = [&](const sub_ops<P, SUB> &o, int t) __attribute__((always_inline)) {
-        const float b0 = o.b0[t] * b_sign;
-        const float b1 = o.b1[t] * b_sign;
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            // a = s * conj(kv): lanes 0-31 carry Re(a), lanes 32-63 Im(a)
-            const float a = fmaf(o.c[p][t].x, o.kv[t].x, o.c[p][t].y * o.kv[t].y);
-            acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc.t0[p], 0, 0, 0);
-            acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc.t1[p], 0, 0, 0);
-        }
-    };
     auto stage_c = [&](const sub_ops<P, SUB> &o) __attribute__((always_inline)) {
+        // all operands first, then the MFMAs back to back (no VALU -> MFMA wait states)
+        float a[P][SUB], b0[SUB], b1[SUB];
+#pragma unroll
+        for (int t = 0; t < SUB; t++) {
+            b0[t] = o.b0[t] * b_sign;
+            b1[t] = o.b1[t] * b_sign;
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                a[p][t] = fmaf(o.c[p][t].x, o.kv[t].x, o.c[p][t].y * o.kv[t].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < SUB; t++)
-            mfma_vis(o, t);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b0[t], acc.t0[p], 0, 0, 0);
+                acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b1[t], acc.t1[p], 0, 0, 0);
+            }
     };
     // A group whose visibilities do not share one window position (a jump inside the group):
     // rolled loop, window positioned per visibility, operands re-read from LDS.  Rare.
