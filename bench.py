@@ -269,19 +269,29 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
         out['clean_%s_cycles_per_s' % label] = round(done / (time.perf_counter() - t0), 1)
     out['clean_psf_patch'] = list(patch)
 
-    # degridder on the first chunk
+    # degridder over every chunk of the channel (hot loop of the 2nd+ major cycles with --degrid,
+    # frontend.py:128-139): vis -= weights * degrid(model grid)
     template_d = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed)
     dg = template_d.instantiate(q, ap, ip, gp, args.vis_block)
-    dg.bind(grid=gridder.buffer('grid'), uv=chunks[0][0], w_plane=chunks[0][1])
+    dg.bind(grid=gridder.buffer('grid'))
+    wts = accel.DeviceArray(ctx, (args.vis_block, P), np.float32,
+                            tensor=torch.ones((args.vis_block, P), device=ctx.device))
+    dg.bind(weights=wts)
     dg.ensure_all_bound()
-    dg.num_vis = chunks[0][3]
-    dg()
+
+    def degrid_all():
+        for uv_c, wp_c, vis_c, n in chunks:
+            dg.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+            dg.num_vis = n
+            dg._run()
+    degrid_all()
     q.finish()
     t0 = time.perf_counter()
-    for _ in range(3):
-        dg()
+    for _ in range(2):
+        degrid_all()
     q.finish()
-    out['degrid_Mvis_per_s'] = round(3 * chunks[0][3] / (time.perf_counter() - t0) / 1e6, 2)
+    total = sum(c[3] for c in chunks)
+    out['degrid_Mvis_per_s'] = round(2 * total / (time.perf_counter() - t0) / 1e6, 2)
     return out
 
 

@@ -1,0 +1,333 @@
+// MFMA window degridder for gfx950 (CDNA4).
+//
+// Replaces Degridder.static_run / degrid.mako:77-199 of the reference for kernel widths <= 32.
+// Same result as DegridderHost/_degrid (grid.py:1138-1154):
+//     vis[r][p] -= weights[r][p] * sum_{j,k} kern[w][sv][j] * kern[w][su][k] * grid[p][v0+j][u0+k].
+//
+// Mirror image of the MFMA gridder (grid_mfma.hip): a wave keeps a moving 32x32 window of the
+// grid in registers -- here as the MFMA *A operand* -- and contracts it with the separable
+// kernel of 16 visibilities at a time:
+//   step 1 (matrix pipe): T[x][b] = sum_y G[y][x] * kv_b[y]          32 MFMA (one per window row)
+//        A[i = x][k] = (Re, Im) of G[y][x]   (lane = window column: row loads are coalesced)
+//        B[k][n = 2b + part] = [[kv.re, kv.im], [-kv.im, kv.re]]      (re/im interleaved outputs)
+//   step 2 (VALU): vis_b = sum_x ku_b[x] * T[x][b], 16 complex MACs per lane + one cross-half add.
+// Window cell (y, x) <-> grid point (Wv + ((y-Wv)&31), Wu + ((x-Wu)&31)); when the window moves
+// only the cells whose mapping changed are re-read.  Every visibility owns its output columns,
+// so a visibility that does not fit the current window is simply masked and handled in a later
+// pass of the same 16-group (no cross-talk).
+// The kernel table lives in LDS with rows of 32 zero-padded taps stored twice (so "tap
+// (index - first_tap) mod 32" is an immediate offset) and a row stride of 65 taps (so that the
+// per-visibility gathers of different table rows fall on different banks).
+//
+// Algorithmic work per visibility: 8*K*K*P flop; executed 2 MFMA x 4096 flop per polarization.
+#include "kimg_common.h"
+#include <limits.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WIN = 32;
+constexpr int ROW_BYTES = 65 * 8;       // 64 taps (32 stored twice) + 1 pad tap
+constexpr int BATCH = 16;               // visibilities per MFMA pass (N = 32 = 16 x (re, im))
+
+__device__ inline uint32_t changed_mask(int W, int nW)
+{
+    const int d = nW - W;
+    if (d == 0)
+        return 0u;
+    if (d >= WIN || d <= -WIN)
+        return 0xffffffffu;
+    const uint32_t offsets = d > 0 ? (1u << d) - 1u : ~((1u << (WIN + d)) - 1u);
+    const int rot = W & 31;
+    return rot ? (offsets << rot) | (offsets >> (32 - rot)) : offsets;
+}
+
+// min / max over each aligned group of 16 lanes (one DPP row)
+__device__ inline int row16_min(int v)
+{
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));    // row_mirror
+    return v;
+}
+
+__device__ inline int row16_max(int v)
+{
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+template <int P>
+struct window_regs {
+    float g[P][WIN];        // g[p][y]: (lane < 32 ? Re : Im) of G[p][row y][column lane & 31]
+};
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
+    const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
+    const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
+    const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
+    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const unsigned char *tbytes = smem;
+    const int table_rows = W * OV;
+    unsigned char *rec_base = smem + (size_t) table_rows * ROW_BYTES;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // per-wave staging of 64 visibilities: (table offset for kv, for ku, mu, mv); mu = INT_MIN
+    // marks a visibility to skip
+    int4 *recs = reinterpret_cast<int4 *>(rec_base) + wib * 64;
+
+    // Stage the kernel table: rows zero-padded to 32 taps, stored twice, stride 65 taps.
+    for (int idx = threadIdx.x; idx < table_rows * 64; idx += NW * 64) {
+        const int row = idx >> 6, t = idx & 31;
+        const float2 v = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
+        *reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + (idx & 63) * 8) = v;
+    }
+    __syncthreads();
+
+    const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
+    int64_t block_end = block_start + vis_per_block;
+    if (block_end > num_vis)
+        block_end = num_vis;
+    const int64_t span = block_end > block_start ? block_end - block_start : 0;
+    const int64_t start = block_start + (span * wib / NW) / 64 * 64;
+    const int64_t end = wib == NW - 1 ? block_end : block_start + (span * (wib + 1) / NW) / 64 * 64;
+    if (start >= end)
+        return;
+
+    const int uv_bias = (K - 1) / 2 - Gg / 2;           // grid.py:1141
+    const int half = Gg / 2;
+    const int S = WIN - K;
+    const bool h = lane >= 32;
+    const int x_lane = lane & 31;                       // window column held by this lane
+    const int part = lane & 1;                          // output column parity: 0 re, 1 im
+    const int b_lane = (lane & 31) >> 1;                // visibility of the 16-group served
+    // B operand (k = h): part 0 -> (kv.re, -kv.im), part 1 -> (kv.im, kv.re)
+    const bool b_take_im = (h != (part != 0));
+    const float b_sign = (h && !part) ? -1.0f : 1.0f;
+    const int b_comp = b_take_im ? 4 : 0;
+    // step 2: own column holds T_part, the neighbour lane T_(1-part):
+    // part 0: sum += ku.re*Tr - ku.im*Ti ; part 1: sum += ku.re*Ti + ku.im*Tr
+    const float o_sign = part ? 1.0f : -1.0f;
+    const int h32 = h ? 32 : 0;                         // rows of C held by this half: r_k + 4h
+
+    window_regs<P> win;
+#pragma unroll
+    for (int p = 0; p < P; p++)
+#pragma unroll
+        for (int y = 0; y < WIN; y++)
+            win.g[p][y] = 0.0f;
+    bool have = false;
+    int Wu = 0, Wv = 0;
+
+    // (Re-)load the window cells whose mapping changes when the origin moves to (nWu, nWv).
+    auto load_window = [&](int nWu, int nWv) __attribute__((always_inline)) {
+        const uint32_t row_mask = have ? changed_mask(Wv, nWv) : 0xffffffffu;
+        const uint32_t col_mask = have ? changed_mask(Wu, nWu) : 0xffffffffu;
+        const int gx = nWu + ((x_lane - nWu) & 31);
+        const bool col_changed = (col_mask >> x_lane) & 1u;
+        const bool x_ok = (unsigned) gx < (unsigned) Gg;
+#pragma unroll
+        for (int y = 0; y < WIN; y++) {
+            const bool row_changed = (row_mask >> y) & 1u;          // uniform
+            if (!row_changed && col_mask == 0)
+                continue;
+            const int gy = nWv + ((y - nWv) & 31);                  // uniform
+            const bool y_ok = (unsigned) gy < (unsigned) Gg;
+            if (row_changed || col_changed) {
+                const float *cell = grid + 2 * ((int64_t) gy * row_stride + gx) + (h ? 1 : 0);
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    win.g[p][y] = (x_ok && y_ok) ? cell[2 * p * pol_stride] : 0.0f;
+            }
+        }
+        Wu = nWu;
+        Wv = nWv;
+        have = true;
+    };
+
+    for (int64_t b0 = start; b0 < end; b0 += 64) {
+        // ---- stage 64 visibilities (lane i <-> visibility b0 + i) ---------------------------
+        int gmin_u, gmax_u, gmin_v, gmax_v;
+        {
+            const int64_t i = b0 + lane;
+            const int64_t ii = i < end ? i : end - 1;
+            const int2 packed = reinterpret_cast<const int2 *>(uv)[ii];
+            const int u = (short) (packed.x & 0xffff), v = (short) (packed.x >> 16);
+            const int su = (short) (packed.y & 0xffff), sv = (short) (packed.y >> 16);
+            const int wp = w_plane[ii];
+            const bool ok = i < end && (unsigned) (u + half) < (unsigned) Gg
+                            && (unsigned) (v + half) < (unsigned) Gg && (unsigned) su < (unsigned) OV
+                            && (unsigned) sv < (unsigned) OV && (unsigned) wp < (unsigned) W;
+            const int mu = u - uv_bias, mv = v - uv_bias;
+            int4 r;
+            r.x = ok ? (wp * OV + sv) * ROW_BYTES + ((-mv) & 31) * 8 : 0;
+            r.y = ok ? (wp * OV + su) * ROW_BYTES + ((-mu) & 31) * 8 : 0;
+            r.z = ok ? mu : INT_MIN;
+            r.w = mv;
+            recs[lane] = r;
+            gmin_u = row16_min(ok ? mu : INT_MAX);
+            gmax_u = row16_max(ok ? mu : INT_MIN);
+            gmin_v = row16_min(ok ? mv : INT_MAX);
+            gmax_v = row16_max(ok ? mv : INT_MIN);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        const int count = end - b0 < 64 ? (int) (end - b0) : 64;
+        for (int g = 0; g * BATCH < count; g++) {
+            const int first = g * BATCH;
+            const int lo_u = __builtin_amdgcn_readlane(gmin_u, first);
+            const int hi_u = __builtin_amdgcn_readlane(gmax_u, first);
+            const int lo_v = __builtin_amdgcn_readlane(gmin_v, first);
+            const int hi_v = __builtin_amdgcn_readlane(gmax_v, first);
+            if (lo_u > hi_u)
+                continue;                               // nothing to do in this group
+            const int4 rec = recs[first + b_lane];      // this lane's visibility of the group
+            const int mu = rec.z, mv = rec.w;
+            const bool mine = mu != INT_MIN;
+            unsigned long long pending = __ballot(mine);
+            const bool whole = hi_u - lo_u <= S && hi_v - lo_v <= S;
+            while (pending) {
+                // ---- choose / move the window ------------------------------------------------
+                // the whole group when it fits one window position, else the first pending
+                // visibility; all slack is left ahead in the direction of travel
+                int lu = lo_u, hu = hi_u, lv = lo_v, hv = hi_v;
+                if (!whole) {
+                    const int src = __builtin_ctzll(pending);
+                    lu = hu = __builtin_amdgcn_readlane(mu, src);
+                    lv = hv = __builtin_amdgcn_readlane(mv, src);
+                }
+                auto place = [&](int lo, int hi, int cur) __attribute__((always_inline)) {
+                    if (!have)
+                        return lo - (S - (hi - lo)) / 2;
+                    if (lo >= cur && hi <= cur + S)
+                        return cur;
+                    return hi > cur + S ? lo : hi - S;
+                };
+                const int nWu = place(lu, hu, Wu);
+                const int nWv = place(lv, hv, Wv);
+                if (!have || nWu != Wu || nWv != Wv)
+                    load_window(nWu, nWv);
+                const bool fit = mine && (unsigned) (mu - Wu) <= (unsigned) S
+                                 && (unsigned) (mv - Wv) <= (unsigned) S;
+                const unsigned long long done = __ballot(fit) & pending;
+                pending &= ~done;
+                const bool active = (done >> lane) & 1ull;
+
+                // ---- step 1: T[x][n] = sum_y G[y][x] * B_y[n] ---------------------------------
+                f32x16 acc[P];
+#pragma unroll
+                for (int p = 0; p < P; p++)
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        acc[p][k] = 0.0f;
+                const unsigned char *pv = tbytes + rec.x + b_comp;
+#pragma unroll
+                for (int y = 0; y < WIN; y++) {
+                    const float bv = *reinterpret_cast<const float *>(pv + 8 * y) * b_sign;
+#pragma unroll
+                    for (int p = 0; p < P; p++)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
+                }
+                // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
+                const unsigned char *pu = tbytes + rec.y + h32;
+                float sum[P];
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    sum[p] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int rk = (k & 3) + 8 * (k >> 2);
+                    const float2 ku = *reinterpret_cast<const float2 *>(pu + 8 * rk);
+                    const float kis = ku.y * o_sign;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const float own = acc[p][k];
+                        const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+                            __builtin_bit_cast(int, own), 0xB1, 0xf, 0xf, true));
+                        sum[p] = fmaf(ku.x, own, sum[p]);
+                        sum[p] = fmaf(kis, other, sum[p]);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    sum[p] += __shfl_xor(sum[p], 32, WAVE);
+                // ---- write back: lanes 0-31 hold (vis b, part) -----------------------------------
+                if (active && !h) {
+                    const int64_t r = b0 + first + b_lane;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        float *out = vis + (r * P + p) * 2 + part;
+                        *out = *out - weights[r * P + p] * sum[p];      // grid.py:1154
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+size_t lds_bytes(int NW, int W, int OV)
+{
+    return (size_t) W * OV * ROW_BYTES + (size_t) NW * 64 * sizeof(int4);
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <int P, int NW>
+int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
+           const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
+           const float2 *kern, int W, int OV, int K, hipStream_t stream)
+{
+    const size_t lds = lds_bytes(NW, W, OV);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
+        attr_set = true;
+    }
+    const int blocks_max = 256;
+    int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
+    vis_per_block = (vis_per_block + 63) / 64 * 64;
+    if (vis_per_block < 64 * NW)
+        vis_per_block = 64 * NW;
+    const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
+    degrid_mfma_kernel<P, NW><<<blocks, NW * 64, lds, stream>>>(
+        grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, K,
+        vis_per_block);
+    return kimg_launch_status();
+}
+
+} // namespace
+
+bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
+{
+    if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
+        return false;
+    return lds_bytes(8, w_planes, oversample) <= LDS_LIMIT;
+}
+
+int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
+                     int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
+                     const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
+                     int w_planes, int oversample, int kernel_width, hipStream_t stream)
+{
+#define LAUNCH(PP, NWV) return launch<PP, NWV>((const float *) grid, grid_row_stride, \
+        grid_pol_stride, grid_size, uv, w_plane, weights, (float *) vis, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
+    switch (P) {
+    case 1: LAUNCH(1, 12);
+    case 2: LAUNCH(2, 8);
+    case 3: LAUNCH(3, 8);
+    case 4: LAUNCH(4, 8);
+    }
+#undef LAUNCH
+    return KIMG_EUNSUPPORTED;
+}

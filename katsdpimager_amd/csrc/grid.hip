@@ -6,6 +6,7 @@
 // (grid_mfma.hip) does not cover: every tap is a global float atomic, so it runs at the
 // chip's atomic rate (~1.3 TB/s of added bytes), not at the FMA rate.
 #include "kimg_common.h"
+#include <stdlib.h>
 
 int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
                    int P, const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
@@ -14,6 +15,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    void *workspace, size_t workspace_bytes, hipStream_t stream);
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P);
+int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
+                     int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
+                     const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
+                     int w_planes, int oversample, int kernel_width, hipStream_t stream);
+bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 
 namespace {
 
@@ -288,6 +294,16 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
     if (num_vis == 0)
         return 0;                                               // grid.py:989-990
     hipStream_t s = (hipStream_t) stream;
+    static int force_generic = -1;
+    if (force_generic < 0) {
+        const char *e = getenv("KIMG_DEGRID_VARIANT");      // "generic": A/B tests only
+        force_generic = e && e[0] == 'g';
+    }
+    if (!force_generic
+        && kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample, kernel_width))
+        return kimg_degrid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
+                                num_polarizations, uv, w_plane, weights, vis, num_vis,
+                                convolve_kernel, w_planes, oversample, kernel_width, s);
     int blocks = kimg_divup(num_vis, 4);
     if (blocks > 16384)
         blocks = 16384;

@@ -162,6 +162,45 @@ def test_degridder_vs_golden(golden, name):
     fn()                                      # grid.py:989-990
 
 
+@pytest.mark.parametrize('P', [1, 2, 3, 4])
+def test_degridder_adversarial(P):
+    """Uniformly random positions (every 16-group needs several window passes), repeated
+    positions, ragged counts and zero visibilities, against the oracle."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(256, 0.0001, 0.01, P, 28, 32, grid_cover=180, n_vis=1000)
+    ip, gp, ap = make_params(c)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 4096)
+    fn.ensure_all_bound()
+    G = fn.buffer('grid').shape[-1]
+    rs = gi.RandomState(7)
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    fn.buffer('grid').set(q, gdata)
+    kernel = fn.convolve_kernel.data
+    for n in (0, 1, 15, 17, 64, 1000, 3001):
+        uv = np.concatenate([rs.randint(-90, 90, (n, 2)), rs.randint(0, 8, (n, 2))],
+                            axis=1).astype(np.int16)
+        if n > 600:
+            uv[500:600] = uv[500]
+        wp = rs.randint(0, 32, n).astype(np.int16)
+        vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+        w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
+        fn.num_vis = n
+        if n:
+            fn.buffer('uv').set_region(q, uv, np.s_[:n], np.s_[:])
+            fn.buffer('w_plane').set_region(q, wp, np.s_[:n], np.s_[:])
+            fn.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+            fn.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+        fn()
+        if n == 0:
+            continue
+        expected = vis.copy()
+        orc.degrid(kernel, gdata, np.ascontiguousarray(uv[:, :2]), np.ascontiguousarray(uv[:, 2:]),
+                   wp, w, expected)
+        actual = fn.buffer('vis').get(q)[:n]
+        np.testing.assert_allclose(actual, expected, rtol=1e-5, atol=2e-5)
+
+
 def test_predict_vs_golden(golden):
     """G4: reference _predict_host (norm-wise: see tests/test_oracle_golden.py::test_g4)."""
     from katsdpimager_amd import predict
