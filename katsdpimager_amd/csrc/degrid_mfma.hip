@@ -28,7 +28,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WIN = 32;
-constexpr int ROW_BYTES = 65 * 8;       // 64 taps (32 stored twice) + 1 pad tap
+// LDS table rows: TAPS = 64 (32 zero-padded taps stored twice: the tap index needs no wrap) when
+// the table fits, else TAPS = 32 (wrap = 2 more VALU per read); one pad tap per row either way.
+template <int TAPS>
+constexpr int row_bytes() { return (TAPS + 1) * 8; }
 constexpr int BATCH = 16;               // visibilities per MFMA pass (N = 32 = 16 x (re, im))
 
 __device__ inline uint32_t changed_mask(int W, int nW)
@@ -67,14 +70,15 @@ struct window_regs {
     float g[P][WIN];        // g[p][y]: (lane < 32 ? Re : Im) of G[p][row y][column lane & 31]
 };
 
-template <int P, int NW>
+template <int P, int NW, int TAPS>
 __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
-    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block)
+    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block, int p_total)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = smem;
     const int table_rows = W * OV;
     unsigned char *rec_base = smem + (size_t) table_rows * ROW_BYTES;
@@ -85,10 +89,10 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     int4 *recs = reinterpret_cast<int4 *>(rec_base) + wib * 64;
 
     // Stage the kernel table: rows zero-padded to 32 taps, stored twice, stride 65 taps.
-    for (int idx = threadIdx.x; idx < table_rows * 64; idx += NW * 64) {
-        const int row = idx >> 6, t = idx & 31;
+    for (int idx = threadIdx.x; idx < table_rows * TAPS; idx += NW * 64) {
+        const int row = idx / TAPS, t = idx & 31;
         const float2 v = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
-        *reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + (idx & 63) * 8) = v;
+        *reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + (idx % TAPS) * 8) = v;
     }
     __syncthreads();
 
@@ -168,8 +172,15 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                             && (unsigned) sv < (unsigned) OV && (unsigned) wp < (unsigned) W;
             const int mu = u - uv_bias, mv = v - uv_bias;
             int4 r;
-            r.x = ok ? (wp * OV + sv) * ROW_BYTES + ((-mv) & 31) * 8 : 0;
-            r.y = ok ? (wp * OV + su) * ROW_BYTES + ((-mu) & 31) * 8 : 0;
+            // TAPS == 64: byte address of tap ((-m) & 31) of the row; TAPS == 32: row number in
+            // the high half and the tap offset in the low byte (wrapped at read time)
+            if (TAPS == 64) {
+                r.x = ok ? (wp * OV + sv) * ROW_BYTES + ((-mv) & 31) * 8 : 0;
+                r.y = ok ? (wp * OV + su) * ROW_BYTES + ((-mu) & 31) * 8 : 0;
+            } else {
+                r.x = ok ? ((wp * OV + sv) << 16) | (((-mv) & 31) * 8) : 0;
+                r.y = ok ? ((wp * OV + su) << 16) | (((-mu) & 31) * 8) : 0;
+            }
             r.z = ok ? mu : INT_MIN;
             r.w = mv;
             recs[lane] = r;
@@ -228,16 +239,21 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
 #pragma unroll
                     for (int k = 0; k < 16; k++)
                         acc[p][k] = 0.0f;
-                const unsigned char *pv = tbytes + rec.x + b_comp;
+                const unsigned char *pv = tbytes + (TAPS == 64 ? rec.x : (rec.x >> 16) * ROW_BYTES)
+                                          + b_comp;
+                const int off_v = rec.x & 0xff;
 #pragma unroll
                 for (int y = 0; y < WIN; y++) {
-                    const float bv = *reinterpret_cast<const float *>(pv + 8 * y) * b_sign;
+                    const float bv = *reinterpret_cast<const float *>(
+                        TAPS == 64 ? pv + 8 * y : pv + ((off_v + 8 * y) & 0xf8)) * b_sign;
 #pragma unroll
                     for (int p = 0; p < P; p++)
                         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
                 }
                 // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
-                const unsigned char *pu = tbytes + rec.y + h32;
+                const unsigned char *pu = tbytes + (TAPS == 64 ? rec.y + h32
+                                                               : (rec.y >> 16) * ROW_BYTES);
+                const int off_u = (rec.y & 0xff) + h32;
                 float sum[P];
 #pragma unroll
                 for (int p = 0; p < P; p++)
@@ -245,7 +261,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int rk = (k & 3) + 8 * (k >> 2);
-                    const float2 ku = *reinterpret_cast<const float2 *>(pu + 8 * rk);
+                    const float2 ku = *reinterpret_cast<const float2 *>(
+                        TAPS == 64 ? pu + 8 * rk : pu + ((off_u + 8 * rk) & 0xf8));
                     const float kis = ku.y * o_sign;
 #pragma unroll
                     for (int p = 0; p < P; p++) {
@@ -264,8 +281,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                     const int64_t r = b0 + first + b_lane;
 #pragma unroll
                     for (int p = 0; p < P; p++) {
-                        float *out = vis + (r * P + p) * 2 + part;
-                        *out = *out - weights[r * P + p] * sum[p];      // grid.py:1154
+                        float *out = vis + (r * p_total + p) * 2 + part;
+                        *out = *out - weights[r * p_total + p] * sum[p];    // grid.py:1154
                     }
                 }
             }
@@ -274,22 +291,22 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     }
 }
 
-size_t lds_bytes(int NW, int W, int OV)
+size_t lds_bytes(int NW, int W, int OV, int taps)
 {
-    return (size_t) W * OV * ROW_BYTES + (size_t) NW * 64 * sizeof(int4);
+    return (size_t) W * OV * (taps + 1) * 8 + (size_t) NW * 64 * sizeof(int4);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int NW>
+template <int P, int NW, int TAPS>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
-           const float2 *kern, int W, int OV, int K, hipStream_t stream)
+           const float2 *kern, int W, int OV, int K, int p_total, hipStream_t stream)
 {
-    const size_t lds = lds_bytes(NW, W, OV);
+    const size_t lds = lds_bytes(NW, W, OV, TAPS);
     static bool attr_set = false;
     if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW>),
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -299,9 +316,9 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    degrid_mfma_kernel<P, NW><<<blocks, NW * 64, lds, stream>>>(
+    degrid_mfma_kernel<P, NW, TAPS><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, K,
-        vis_per_block);
+        vis_per_block, p_total);
     return kimg_launch_status();
 }
 
@@ -311,7 +328,7 @@ bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_
 {
     if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
         return false;
-    return lds_bytes(8, w_planes, oversample) <= LDS_LIMIT;
+    return lds_bytes(12, w_planes, oversample, 32) <= LDS_LIMIT;
 }
 
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
@@ -319,15 +336,23 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
                      int w_planes, int oversample, int kernel_width, hipStream_t stream)
 {
-#define LAUNCH(PP, NWV) return launch<PP, NWV>((const float *) grid, grid_row_stride, \
-        grid_pol_stride, grid_size, uv, w_plane, weights, (float *) vis, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
-    switch (P) {
-    case 1: LAUNCH(1, 12);
-    case 2: LAUNCH(2, 8);
-    case 3: LAUNCH(3, 8);
-    case 4: LAUNCH(4, 8);
-    }
+    // instantiated for 1 and 2 polarizations; 3 or 4 run as 2 + 1 / 2 + 2 (register budget)
+    for (int p0 = 0; p0 < P; p0 += 2) {
+        const int pn = P - p0 >= 2 ? 2 : 1;
+        const float *g = (const float *) grid + 2 * p0 * grid_pol_stride;
+        int rc;
+#define LAUNCH(PP, NWV, TAPSV) rc = launch<PP, NWV, TAPSV>(g, grid_row_stride, grid_pol_stride, \
+        grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, P, stream)
+        const bool doubled = lds_bytes(12, w_planes, oversample, 64) <= LDS_LIMIT;
+        if (pn == 1) {
+            if (doubled) LAUNCH(1, 12, 64); else LAUNCH(1, 12, 32);
+        } else {
+            if (doubled) LAUNCH(2, 8, 64); else LAUNCH(2, 8, 32);
+        }
 #undef LAUNCH
-    return KIMG_EUNSUPPORTED;
+        if (rc)
+            return rc;
+    }
+    return 0;
 }

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float2 *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block,
-    int stagger_pct, int dbg)
+    int p_total, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *table = reinterpret_cast<float2 *>(smem);                       // [W*OV][ROW]
@@ -197,7 +197,6 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int64_t span = block_end > block_start ? block_end - block_start : 0;
     const int64_t start = block_start + (span * wib / NW) / 64 * 64;
     const int64_t end = wib == NW - 1 ? block_end : block_start + (span * (wib + 1) / NW) / 64 * 64;
-    (void) stagger_pct;
 
     auto load_raw = [&](int64_t b, vis_raw<P> &raw) __attribute__((always_inline)) {
         int64_t ii = b + lane;
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         raw.wp = w_plane[ii];
 #pragma unroll
         for (int p = 0; p < P; p++)
-            raw.v[p] = vis[ii * P + p];
+            raw.v[p] = vis[ii * p_total + p];
     };
     const int half = Gg / 2;
     auto coords_ok = [&](int64_t b, const vis_raw<P> &raw) __attribute__((always_inline)) {
@@ -504,7 +503,7 @@ template <int P, int ROW, int NW>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
-           int W, int OV, int K, hipStream_t stream)
+           int W, int OV, int K, int p_total, hipStream_t stream)
 {
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
     const size_t lds = lds_bytes(P, NW, W, OV, ROW);
@@ -533,17 +532,19 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
     grid_mfma_kernel<P, NW, SUB, ROW><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, K, vis_per_block, 0, dbg);
+        num_vis, kern, W, OV, K, vis_per_block, p_total, dbg);
     return kimg_launch_status();
 }
 
 } // namespace
 
+// The kernels are instantiated for 1 and 2 polarizations (32 accumulator registers each keep
+// two waves per SIMD without spills); 3 or 4 polarizations run as 2 + 1 / 2 + 2.
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
     if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
         return false;
-    return lds_bytes(P, 8, w_planes, oversample, 32) <= LDS_LIMIT;
+    return lds_bytes(P > 1 ? 2 : 1, 8, w_planes, oversample, 32) <= LDS_LIMIT;
 }
 
 size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P)
@@ -561,33 +562,38 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 {
     (void) workspace;
     (void) workspace_bytes;
-    const bool doubled = lds_bytes(P, P == 1 ? 12 : 8, w_planes, oversample, 64) <= LDS_LIMIT;
     static int nw_env = -1;
     if (nw_env < 0) {
-        const char *e = getenv("KIMG_GRID_WAVES");
+        const char *e = getenv("KIMG_GRID_WAVES");      // timing experiments only
         nw_env = e ? atoi(e) : 0;
     }
-    // P = 1: 156 VGPRs -> 3 waves per SIMD; 12-wave blocks, one per CU (LDS-bound)
-    if (P == 1 && doubled && nw_env != 8) {
-#define LAUNCH_NW(NWV) return launch<1, 64, NWV>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
-        weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
-        if (nw_env == 4) LAUNCH_NW(4);
-        LAUNCH_NW(12);
-#undef LAUNCH_NW
-    }
-#define LAUNCH(PP) if (doubled) return launch<PP, 64, 8>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
-        weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream); \
-    return launch<PP, 32, 8>((float *) grid, grid_row_stride, grid_pol_stride, grid_size, \
-        weights_grid, wg_row_stride, wg_pol_stride, uv, w_plane, (const float2 *) vis, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, stream)
-    switch (P) {
-    case 1: LAUNCH(1);
-    case 2: LAUNCH(2);
-    case 3: LAUNCH(3);
-    case 4: LAUNCH(4);
-    }
+    for (int p0 = 0; p0 < P; p0 += 2) {
+        const int pn = P - p0 >= 2 ? 2 : 1;
+        float *g = (float *) grid + 2 * p0 * grid_pol_stride;
+        const float *wg = weights_grid + p0 * wg_pol_stride;
+        const float2 *v = (const float2 *) vis + p0;
+        const float2 *kern = (const float2 *) convolve_kernel;
+        int rc;
+#define LAUNCH(PP, ROWV, NWV) rc = launch<PP, ROWV, NWV>(g, grid_row_stride, grid_pol_stride, \
+        grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
+        oversample, kernel_width, P, stream)
+        if (pn == 1) {
+            // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
+            if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
+                LAUNCH(1, 64, 12);
+            else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                LAUNCH(1, 64, 8);
+            else
+                LAUNCH(1, 32, 8);
+        } else {
+            if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                LAUNCH(2, 64, 8);
+            else
+                LAUNCH(2, 32, 8);
+        }
 #undef LAUNCH
-    return KIMG_EUNSUPPORTED;
+        if (rc)
+            return rc;
+    }
+    return 0;
 }

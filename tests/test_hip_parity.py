@@ -85,6 +85,19 @@ def test_gridder_bruteforce(variant, P):
     assert relerr(actual, G_or) < GRID_TOL
 
 
+def test_gridder_64_planes():
+    """64 W-planes: the doubled LDS table does not fit, single-row variant (config 4)."""
+    c = gi.make_config(256, 0.0001, 0.01, 2, 28, 64, grid_cover=180, n_vis=1000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'mfma')
+    actual = _run_gridder(fn, q, t)
+    expected = np.zeros(actual.shape, np.complex64)
+    wg = np.zeros(actual.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(fn.convolve_kernel.data, expected, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(actual, expected) < GRID_TOL
+
+
 @pytest.mark.parametrize('variant', ['generic', 'mfma'])
 def test_gridder_edge_cases(variant):
     """Empty input (grid.py:810-811), a single visibility, odd counts, batches that are not a
@@ -162,13 +175,14 @@ def test_degridder_vs_golden(golden, name):
     fn()                                      # grid.py:989-990
 
 
-@pytest.mark.parametrize('P', [1, 2, 3, 4])
-def test_degridder_adversarial(P):
+@pytest.mark.parametrize('P,W', [(1, 32), (2, 32), (3, 32), (4, 32), (1, 64), (4, 64)])
+def test_degridder_adversarial(P, W):
     """Uniformly random positions (every 16-group needs several window passes), repeated
-    positions, ragged counts and zero visibilities, against the oracle."""
+    positions, ragged counts and zero visibilities, against the oracle.  W = 64 planes does not
+    fit the doubled LDS table and takes the single-row (wrapping) variant."""
     from katsdpimager_amd import grid
     ctx, q = context_queue()
-    c = gi.make_config(256, 0.0001, 0.01, P, 28, 32, grid_cover=180, n_vis=1000)
+    c = gi.make_config(256, 0.0001, 0.01, P, 28, W, grid_cover=180, n_vis=1000)
     ip, gp, ap = make_params(c)
     fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 4096)
     fn.ensure_all_bound()
@@ -182,7 +196,7 @@ def test_degridder_adversarial(P):
                             axis=1).astype(np.int16)
         if n > 600:
             uv[500:600] = uv[500]
-        wp = rs.randint(0, 32, n).astype(np.int16)
+        wp = rs.randint(0, W, n).astype(np.int16)
         vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
         w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
         fn.num_vis = n
