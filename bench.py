@@ -48,6 +48,8 @@ def parse_args():
     p.add_argument('--clean-cycles', type=int, default=1000)
     p.add_argument('--cpu-sample', type=int, default=4_000_000,
                    help='visibilities gridded by the CPU baseline (0 disables it)')
+    p.add_argument('--major-loop', action='store_true',
+                   help='also time the full major-cycle loop (BASELINE config 5)')
     p.add_argument('--no-secondary', action='store_true',
                    help='skip the CLEAN / degrid / FFT secondary measurements')
     return p.parse_args()
@@ -193,10 +195,38 @@ def main():
         'roofline': roofline,
     }
 
-    if rank == 0 and not args.no_secondary:
-        result['secondary'] = secondary(args, ctx, q, obs, ip, gp, ap, fn, chunks)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         result['cpu_baseline'] = cpu_baseline(args, obs, fn, wg, Gg)
+    if rank == 0 and not args.no_secondary:
+        sec = secondary(args, ctx, q, obs, ip, gp, ap, fn, chunks)
+        # all chunks of the channel resident and gridded by ONE launch (what a resident
+        # visibility store, SURVEY 8f-2, buys over vis_block-sized launches)
+        big = template.instantiate(q, ap, ip, gp, n_chunks * vb)
+        big.bind(grid=grid_buf, weights_grid=wg,
+                 uv=accel.DeviceArray(ctx, (n_chunks * vb, 4), np.int16, tensor=uv_all),
+                 w_plane=accel.DeviceArray(ctx, (n_chunks * vb,), np.int16, tensor=wp_all),
+                 vis=accel.DeviceArray(ctx, (n_chunks * vb, P), np.complex64, tensor=vis_all))
+        big.num_vis = n_vis
+        big._run()
+        q.finish()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            big._run()
+        q.finish()
+        sec['grid_single_launch_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+        if args.major_loop:
+            # PSF pass grids the weights as visibilities (frontend.py:511)
+            wt_all = padded(obs.weights)
+            psf_all = torch.complex(wt_all, torch.zeros_like(wt_all))
+            obs.vis.copy_(torch.where(torch.isfinite(obs.vis.real), obs.vis, torch.zeros_like(obs.vis)))
+            chunks_dev = []
+            for i in range(n_chunks):
+                sl = slice(i * vb, (i + 1) * vb)
+                wt_c = accel.DeviceArray(ctx, (vb, P), np.float32, tensor=wt_all[sl])
+                wt_c.psf_vis = accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=psf_all[sl])
+                chunks_dev.append((chunks[i][0], chunks[i][1], chunks[i][2], wt_c, chunks[i][3]))
+            sec['major_cycle_loop'] = major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev)
+        result['secondary'] = sec
     barrier()
     if rank == 0:
         print(json.dumps(result))
@@ -292,6 +322,78 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     q.finish()
     total = sum(c[3] for c in chunks)
     out['degrid_Mvis_per_s'] = round(2 * total / (time.perf_counter() - t0) / 1e6, 2)
+    return out
+
+
+def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
+    """BASELINE config 5: the per-channel loop of frontend.process_channel (frontend.py:465-585)
+    on the Imaging facade with every chunk resident in HBM: robust weights -> PSF -> 2 major
+    cycles of { grid -> FFT -> noise estimate -> CLEAN minor cycles -> degrid + regrid }.
+    Returns wall-clock seconds per stage (queue drained after each stage)."""
+    import torch
+    from katsdpimager_amd import accel, imaging, parameters, weight
+    P, G = args.polarizations, args.pixels
+    import synth
+    ipd, gpd, apd = synth.make_parameters(obs, P, args.kernel_width, degrid=True)
+    cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
+    wparm = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
+    template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
+    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2)
+    im.ensure_all_bound()
+    times = {}
+
+    def timed(name, fn):
+        q.finish()
+        t0 = time.perf_counter()
+        out = fn()
+        q.finish()
+        times[name] = times.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    def make_weights():
+        im.clear_weights()
+        for uv_c, wp_c, vis_c, wt_c, n in chunks_dev:
+            im.bind(uv=uv_c, weights=wt_c)
+            im._weights.grid(n)
+        return im.finalize_weights()
+
+    def grid_pass(field, predict):
+        im.clear_grid()
+        for uv_c, wp_c, vis_c, wt_c, n in chunks_dev:
+            im.bind_chunk(n, uv_c, wp_c, vis_c if field == 'vis' else wt_c.psf_vis, wt_c)
+            if predict:
+                im.predict(0.0)
+            im.grid()
+
+    timed('weights', make_weights)
+    im.clear_dirty()
+    timed('grid_psf', lambda: grid_pass('weights', False))
+    timed('fft', lambda: im.grid_to_image(0.0))
+    dirty = im.get_buffer('dirty')
+    scale = np.reciprocal(dirty[:, G // 2, G // 2])
+    im.scale_dirty(scale)
+    im.dirty_to_psf()
+    patch = timed('psf_patch', im.psf_patch)
+    im.clear_model()
+    minor = 0
+    for major in range(2):
+        im.clear_dirty()
+        if major:
+            timed('model_to_grid', lambda: im.model_to_grid(0.0))
+        timed('degrid_grid' if major else 'grid', lambda: grid_pass('vis', major > 0))
+        timed('fft', lambda: im.grid_to_image(0.0))
+        im.scale_dirty(scale)
+        noise = timed('noise_est', im.noise_est)
+        im.clean_reset()
+        peak = im.clean_cycle(patch)
+        thr = max(float(noise) * 5.0, 0.15 * float(peak))
+        vals = timed('clean', lambda: im.clean_cycles(patch, thr, args.clean_cycles - 1))
+        minor += 1 + len(vals)
+    total = sum(times.values())
+    out = {k + '_s': round(v, 4) for k, v in times.items()}
+    out['total_s'] = round(total, 4)
+    out['minor_cycles'] = minor
+    out['psf_patch'] = list(patch)
     return out
 
 

@@ -231,6 +231,16 @@ class Imaging(accel.OperationSequence):
     def set_vis(self, vis):
         self._set_buffer('vis', self.num_vis, vis)
 
+    def bind_chunk(self, num_vis, uv, w_plane, vis, weights=None):
+        """Use visibilities that are already resident in HBM (DeviceArrays of the slot shapes)
+        instead of copying a host chunk: the zero-copy counterpart of ``num_vis = n;
+        set_coordinates(); set_vis(); set_weights()`` for a device-resident visibility store."""
+        self._ready()
+        self.num_vis = num_vis
+        self.bind(uv=uv, w_plane=w_plane, vis=vis)
+        if weights is not None:
+            self.bind(weights=weights)
+
     def set_weights(self, weights):
         """Statistical weights for prediction."""
         self._set_buffer('weights', self.num_vis, weights)
