@@ -102,6 +102,39 @@ int kimg_density_weights(double *sums, float *grid, int64_t row_stride, int64_t 
                          void *stream);
 int kimg_fill(float *data, int64_t count, float value, void *stream);
 
+/* ---- visibility preprocessing: preprocess.cpp:390-513 (visibility_collector<P>::add_impl2) and
+ * :334-372 (compress); the reference runs these on host cores (OpenMP) behind
+ * preprocess.VisibilityCollector.add (preprocess.py:117-150).
+ *   kimg_preprocess_convert: one channel, one buffer of num_vis inputs.  Per visibility: drop if any
+ *       input weight is 0; xvis = M vis, xweights = 1/(|M|^2 (1/|w|)) with MulZ products; M =
+ *       mueller_stokes [P][Q] when the feed angles are NULL, else mueller_stokes [P][4] x
+ *       diag(RR, RL, conj RL, conj RR) x mueller_circular [4][Q] (:244-258); w<0 flip + conjugate;
+ *       vis *= weight; non-finite -> 0; quantise (subpixel_coord :313-323, w :501-506).
+ *       The two matrices are HOST pointers (interleaved re, im float32); everything else is device.
+ *       Outputs: key int16 [N][6] = (u, v, sub_u, sub_v, w_plane, w_slice), out_weights float32 [N][P],
+ *       out_vis complex64 [N][P]; dropped inputs give an all-zero record.
+ *   kimg_preprocess_compress: skip records with weights[0] == 0, sum runs of adjacent equal keys
+ *       left to right in float32, then order the results by w_slice keeping arrival order inside a
+ *       slice.  Outputs are in the gridder's layout: out_uv int16 [M][4] = (u, v, sub_u, sub_v),
+ *       out_w_plane int16 [M], out_weights [M][P], out_vis [M][P], and counts uint64 [w_slices]
+ *       (device) = run length per slice, M = sum(counts).  Output arrays need room for N records.
+ *       workspace: kimg_preprocess_workspace_bytes(N, P) bytes of device memory.
+ *   kimg_real_to_complex: dst[i] = (src[i], 0): feeds weights as visibilities for the PSF pass
+ *       (frontend.py:511) from a device-resident store.
+ */
+int kimg_preprocess_convert(int num_polarizations, int num_input_polarizations, int64_t num_vis,
+                            const float *uvw, const float *weights, const void *vis,
+                            const float *feed_angle1, const float *feed_angle2,
+                            const float *mueller_stokes_host, const float *mueller_circular_host,
+                            float max_w, int w_slices, int w_planes, int oversample, float cell_size,
+                            int16_t *key, float *out_weights, void *out_vis, void *stream);
+size_t kimg_preprocess_workspace_bytes(int64_t num_vis, int num_polarizations);
+int kimg_preprocess_compress(int num_polarizations, int64_t num_vis, int w_slices,
+                             const int16_t *key, const float *weights, const void *vis,
+                             int16_t *out_uv, int16_t *out_w_plane, float *out_weights, void *out_vis,
+                             uint64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+int kimg_real_to_complex(void *dst, const float *src, int64_t count, void *stream);
+
 /* ---- grid <-> image: image.py:649-673 GridToImage._run, :716-740 ImageToGrid._run,
  * :153-180 _LayerImage._run + layer_to_image.mako / image_to_layer.mako.
  *   kimg_grid_to_layer: zero the GxG layer and copy the centred Gg x Gg grid of one

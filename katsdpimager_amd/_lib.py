@@ -29,6 +29,10 @@ PROTOTYPES = {
     'kimg_mean_weight': (c_int, [P, P, L, I, I, P]),
     'kimg_density_weights': (c_int, [P, P, L, L, I, I, I, F, F, P]),
     'kimg_fill': (c_int, [P, L, F, P]),
+    'kimg_preprocess_convert': (c_int, [I, I, L, P, P, P, P, P, P, P, F, I, I, I, F, P, P, P, P]),
+    'kimg_preprocess_workspace_bytes': (ctypes.c_size_t, [L, I]),
+    'kimg_preprocess_compress': (c_int, [I, L, I, P, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
+    'kimg_real_to_complex': (c_int, [P, P, L, P]),
     'kimg_grid_to_layer': (c_int, [P, I, P, L, I, P]),
     'kimg_layer_to_grid': (c_int, [P, L, I, P, I, P]),
     'kimg_layer_to_image': (c_int, [P, L, P, I, P, F, F, F, P]),

@@ -33,7 +33,7 @@ def torch_dtype(dtype):
             np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
             np.dtype(np.uint32): torch.int32, np.dtype(np.float32): torch.float32,
             np.dtype(np.float64): torch.float64, np.dtype(np.complex64): torch.complex64,
-            np.dtype(np.uint8): torch.uint8,
+            np.dtype(np.uint8): torch.uint8, np.dtype(np.int64): torch.int64,
         }
     return _TORCH_DTYPES[np.dtype(dtype)]
 

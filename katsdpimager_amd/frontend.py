@@ -1,0 +1,143 @@
+"""The numerical part of the per-channel driver: imaging weights, PSF, and the major /
+minor cycle loop, reading visibilities from a (device-resident) reader.
+
+Mirrors ``make_weights`` (frontend.py:86-106), ``make_dirty`` (:110-142) and the loop of
+``process_channel`` (:465-585) of the reference.  Everything the reference's driver does around
+that loop — dataset loading, FITS output, restoring beam, progress bars, statistics — is
+outside the hot path and is not reproduced.
+
+A reader with ``iter_slice_device`` (``preprocess.VisibilityReaderDevice``) is consumed
+zero-copy: the visibilities stay in HBM for all major cycles.  Any other reader with the
+reference's ``iter_slice`` works through the façade's host setters.
+"""
+import numpy as np
+
+from . import clean, weight
+
+
+def _device_reader(reader):
+    return hasattr(reader, 'iter_slice_device')
+
+
+def make_weights(reader, rel_channel, imager, weight_type, vis_block):
+    """frontend.py:86-106.  Returns (noise, normalized_noise) of ``finalize_weights``."""
+    imager.clear_weights()
+    if weight_type != weight.WeightType.NATURAL:
+        for w_slice in range(reader.num_w_slices(rel_channel)):
+            if _device_reader(reader):
+                for chunk in reader.iter_slice_device(rel_channel, w_slice, vis_block):
+                    imager.grid_weights_device(chunk)
+            else:
+                for chunk in reader.iter_slice(rel_channel, w_slice, vis_block):
+                    imager.grid_weights(chunk.uv, chunk.weights)
+    return imager.finalize_weights()
+
+
+def make_dirty(reader, rel_channel, field, imager, mid_w, vis_block, degrid,
+               full_cycle=False, subtract_model=False):
+    """frontend.py:110-142: grid (after optional model subtraction) every W-slice of the
+    channel and accumulate the slices' images into ``dirty``."""
+    imager.clear_dirty()
+    if full_cycle and not degrid:
+        imager.model_to_predict()
+    for w_slice in range(reader.num_w_slices(rel_channel)):
+        if reader.len(rel_channel, w_slice) == 0:
+            continue
+        if full_cycle and degrid:
+            imager.model_to_grid(mid_w[w_slice])
+        imager.clear_grid()
+        if _device_reader(reader):
+            for chunk in reader.iter_slice_device(rel_channel, w_slice, vis_block):
+                imager.set_chunk_device(chunk, field)
+                if subtract_model:
+                    imager.continuum_predict(mid_w[w_slice])
+                if full_cycle:
+                    imager.predict(mid_w[w_slice])
+                imager.grid()
+        else:
+            for chunk in reader.iter_slice(rel_channel, w_slice, vis_block):
+                imager.num_vis = len(chunk.uv)
+                imager.set_coordinates(chunk)
+                v = np.ascontiguousarray(chunk[field])
+                imager.set_vis(v.astype(np.complex64) if field == 'weights' else v)
+                if full_cycle or subtract_model:
+                    imager.set_weights(np.ascontiguousarray(chunk.weights))
+                if subtract_model:
+                    imager.continuum_predict(mid_w[w_slice])
+                if full_cycle:
+                    imager.predict(mid_w[w_slice])
+                imager.grid()
+        imager.grid_to_image(mid_w[w_slice])
+
+
+def slice_mid_w(image_p, grid_p):
+    """Central w (in wavelengths) of each W-slice, frontend.py:508-509."""
+    slice_w_step = float(grid_p.fixed.max_w / image_p.wavelength / (grid_p.w_slices - 0.5))
+    return np.arange(grid_p.w_slices) * slice_w_step
+
+
+def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type,
+                    vis_block, major, degrid, subtract_model=False, batched_clean=True):
+    """The loop of frontend.process_channel (frontend.py:497-585) from "Compute imaging
+    weights" to the end of the last major cycle.
+
+    Returns a dict: ``weights_noise``, ``normalized_noise``, ``psf_patch``, ``scale``,
+    ``noise`` (last estimate), ``major``, ``minor``, ``peaks`` (first peak metric of every
+    major cycle), or None when the channel has no usable data (frontend.py:524-527).  The
+    images stay in the imager's ``dirty`` (residual), ``model`` and ``psf`` buffers.
+
+    ``batched_clean`` runs the minor cycles of one major cycle with ``Imaging.clean_cycles``
+    (no host round trip per cycle); the result is identical to the per-cycle loop.
+    """
+    if not any(reader.len(rel_channel, s) for s in range(reader.num_w_slices(rel_channel))):
+        return None
+    num_pols = len(image_p.fixed.polarizations)
+    imager.clear_model()
+    weights_noise, normalized_noise = make_weights(reader, rel_channel, imager, weight_type,
+                                                   vis_block)
+    mid_w = slice_mid_w(image_p, grid_p)
+    make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
+    dirty = imager.buffer('dirty')
+    centre = dirty.shape[1] // 2
+    psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
+    dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
+    if np.any(psf_peak == 0):
+        return None
+    scale = np.reciprocal(psf_peak)
+    imager.scale_dirty(scale)
+    imager.dirty_to_psf()
+    psf_patch = imager.psf_patch()
+    out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
+               psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
+               peaks=[], noise=None)
+    for i in range(major):
+        make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
+                   i != 0, subtract_model)
+        imager.scale_dirty(scale)
+        out['major'] += 1
+        noise = imager.noise_est()
+        out['noise'] = noise
+        imager.clean_reset()
+        peak_value = imager.clean_cycle(psf_patch)
+        out['peaks'].append(peak_value)
+        peak_power = clean.metric_to_power(clean_p.mode, peak_value)
+        noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
+                                                              num_pols)
+        mgain_threshold = (1.0 - clean_p.major_gain) * peak_power
+        threshold = max(noise_threshold, mgain_threshold)
+        if peak_power <= threshold:
+            break
+        threshold_metric = clean.power_to_metric(clean_p.mode, threshold)
+        if batched_clean:
+            values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1)
+            # the reference counts the cycle that found the peak below threshold too (:579-582)
+            out['minor'] += len(values) + (1 if len(values) < clean_p.minor - 1 else 0)
+        else:
+            for _ in range(clean_p.minor - 1):
+                value = imager.clean_cycle(psf_patch, threshold_metric)
+                out['minor'] += 1
+                if value is None:
+                    break
+        if i == major - 1:
+            out['noise'] = imager.noise_est()
+    return out

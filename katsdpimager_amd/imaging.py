@@ -156,6 +156,7 @@ class Imaging(accel.OperationSequence):
             compounds['model'].append('image_to_grid:image')
         super().__init__(command_queue, operations, compounds, allocator=allocator)
         self._bound = False
+        self._own = {}
 
     def __call__(self, **kwargs):
         raise NotImplementedError()
@@ -183,6 +184,7 @@ class Imaging(accel.OperationSequence):
         if len(data) != N:
             raise ValueError('Lengths do not match')
         self._ready()
+        self._restore_own(name)
         device = self.buffer(name)
         data = np.asarray(data)
         if columns is None:
@@ -234,12 +236,56 @@ class Imaging(accel.OperationSequence):
     def bind_chunk(self, num_vis, uv, w_plane, vis, weights=None):
         """Use visibilities that are already resident in HBM (DeviceArrays of the slot shapes)
         instead of copying a host chunk: the zero-copy counterpart of ``num_vis = n;
-        set_coordinates(); set_vis(); set_weights()`` for a device-resident visibility store."""
+        set_coordinates(); set_vis(); set_weights()``.  ``vis`` is modified in place by
+        ``predict``; see :meth:`set_chunk_device` for a store that must stay intact."""
         self._ready()
+        self._keep_own('uv', 'w_plane', 'vis', 'weights')
         self.num_vis = num_vis
         self.bind(uv=uv, w_plane=w_plane, vis=vis)
         if weights is not None:
             self.bind(weights=weights)
+
+    def _keep_own(self, *names):
+        """Remember the façade's own buffers before external ones are bound over them."""
+        for name in names:
+            if name not in self._own:
+                self._own[name] = self.buffer(name)
+
+    def _restore_own(self, name):
+        if name in self._own and self.buffer(name) is not self._own[name]:
+            self.bind(**{name: self._own[name]})
+
+    def set_chunk_device(self, chunk, field='vis'):
+        """Device-resident counterpart of the per-chunk part of frontend.make_dirty
+        (frontend.py:129-134): ``num_vis = len(chunk); set_coordinates(chunk);
+        set_vis(chunk[field]); set_weights(chunk.weights)`` for a
+        :class:`preprocess.DeviceChunk`.  Coordinates and weights are bound zero-copy; the
+        visibilities are copied (device to device) into the façade's own buffer because
+        ``predict`` subtracts the model in place and the store must keep the originals."""
+        if field not in ('vis', 'weights'):
+            raise ValueError('field must be vis or weights')
+        self._ready()
+        self._keep_own('uv', 'w_plane', 'weights')
+        self._restore_own('vis')
+        n = chunk.num_vis
+        self.num_vis = n
+        self.bind(uv=chunk.uv, w_plane=chunk.w_plane, weights=chunk.weights)
+        own_vis = self.buffer('vis')
+        if field == 'vis':
+            chunk.vis.copy_region(self.command_queue, own_vis, np.s_[:n], np.s_[:n])
+        else:
+            from ._lib import lib, check
+            check(lib().kimg_real_to_complex(own_vis.ptr, chunk.weights.ptr, n * own_vis.shape[1],
+                                             self.command_queue.handle), 'kimg_real_to_complex')
+
+    def grid_weights_device(self, chunk):
+        """``grid_weights(chunk.uv, chunk.weights)`` (frontend.py:96) without the host copy."""
+        if 'uv' not in self._weights.slots:
+            return
+        self._ready()
+        self._keep_own('uv', 'weights')
+        self.bind(uv=chunk.uv, weights=chunk.weights)
+        self._weights.grid(chunk.num_vis)
 
     def set_weights(self, weights):
         """Statistical weights for prediction."""

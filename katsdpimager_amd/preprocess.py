@@ -1,0 +1,318 @@
+"""Visibility preprocessing and the device-resident visibility store.
+
+Mirror of ``katsdpimager.preprocess`` (preprocess.py:73-420) with the C++ collector
+(preprocess.cpp) replaced by HIP kernels and the HDF5 / in-memory stores replaced by a
+store that keeps every preprocessed visibility of the channels being imaged in HBM:
+
+* :class:`VisibilityCollectorDevice` — ``add(uvw, weights, vis, feed_angle1, feed_angle2,
+  mueller_stokes, mueller_circular)``, ``close()``, ``reader()``, ``num_input``,
+  ``num_output`` as ``VisibilityCollector`` (preprocess.py:73-156).  Inputs may be numpy
+  arrays (uploaded once per call) or :class:`accel.DeviceArray`.
+* :class:`VisibilityReaderDevice` — ``num_channels``, ``num_w_slices(channel)``,
+  ``len(channel, w_slice)``, ``iter_slice(channel, w_slice, block_size)`` yielding host
+  record arrays in the reference's store dtype (so frontend.make_weights / make_dirty run
+  on it unchanged) and ``iter_slice_device`` yielding zero-copy :class:`DeviceChunk` views
+  for ``Imaging.set_chunk_device`` / ``Imaging.grid_weights_device``.
+
+Layout in HBM, per (channel, w_slice): ``uv`` int16 [N][4] = (u, v, sub_u, sub_v),
+``w_plane`` int16 [N], ``weights`` float32 [N][P], ``vis`` complex64 [N][P] (22 B per
+visibility at P=1, 58 B at P=4) — exactly the arrays the gridder, degridder, predictor and
+weight kernels consume, so a major cycle touches no host memory.
+"""
+import ctypes
+
+import numpy as np
+
+from . import accel
+from ._lib import lib, check
+
+
+def make_store_dtype(num_polarizations):
+    """Record type yielded by ``iter_slice``: the fields and offsets of the reference's
+    ``_make_dtype`` applied to ``vis_t<P>`` (preprocess.py:42-56, preprocess.cpp:39-52)."""
+    P = num_polarizations
+    return np.dtype(dict(
+        names=['uv', 'sub_uv', 'w_plane', 'weights', 'vis'],
+        formats=[('i2', (2,)), ('i2', (2,)), 'i2', ('f4', (P,)), ('c8', (P,))],
+        offsets=[0, 4, 8, 12, 12 + 4 * P], itemsize=12 + 12 * P))
+
+
+class DeviceChunk:
+    """A block of one (channel, w_slice) in HBM.  The arrays are views of the store with
+    ``block_size`` rows of which the first ``num_vis`` are valid."""
+
+    def __init__(self, num_vis, uv, w_plane, weights, vis):
+        self.num_vis = num_vis
+        self.uv = uv
+        self.w_plane = w_plane
+        self.weights = weights
+        self.vis = vis
+
+    def __len__(self):
+        return self.num_vis
+
+
+class _SliceStore:
+    """Growable structure-of-arrays for one (channel, w_slice).  ``slack`` rows beyond the
+    data are always allocated so that a full-size block view can start at any row."""
+
+    def __init__(self, context, command_queue, num_polarizations, slack):
+        self.context = context
+        self.queue = command_queue
+        self.P = num_polarizations
+        self.slack = slack
+        self.length = 0
+        self.capacity = 0
+        self.arrays = None
+
+    def _allocate(self, rows):
+        P = self.P
+        arrays = dict(
+            uv=accel.DeviceArray(self.context, (rows, 4), np.int16),
+            w_plane=accel.DeviceArray(self.context, (rows,), np.int16),
+            weights=accel.DeviceArray(self.context, (rows, P), np.float32),
+            vis=accel.DeviceArray(self.context, (rows, P), np.complex64))
+        for a in arrays.values():
+            a.zero(self.queue)       # the slack rows are read (and masked) by full-block views
+        return arrays
+
+    def reserve(self, extra):
+        need = self.length + extra + self.slack
+        if need <= self.capacity:
+            return
+        rows = max(need, 2 * self.capacity)
+        arrays = self._allocate(rows)
+        if self.arrays is not None and self.length:
+            for name, old in self.arrays.items():
+                old.copy_region(self.queue, arrays[name], np.s_[:self.length], np.s_[:self.length])
+        self.arrays = arrays
+        self.capacity = rows
+
+    def append(self, src, start, count):
+        """Copy ``count`` rows starting at ``start`` from the dict of arrays ``src``."""
+        self.reserve(count)
+        for name, dst in self.arrays.items():
+            src[name].copy_region(self.queue, dst, np.s_[start:start + count],
+                                  np.s_[self.length:self.length + count])
+        self.length += count
+
+    def view(self, start, rows):
+        out = {}
+        for name, a in self.arrays.items():
+            t = a.tensor[start:start + rows]
+            out[name] = accel.DeviceArray(self.context, tuple(t.shape), a.dtype, tensor=t)
+        return out
+
+
+def _to_device(context, queue, ary, dtype, shape_tail=None):
+    if ary is None:
+        return None
+    if isinstance(ary, accel.DeviceArray):
+        if ary.dtype != np.dtype(dtype):
+            raise TypeError('device input must have dtype {}'.format(np.dtype(dtype)))
+        return ary
+    host = np.require(np.asarray(ary), dtype, 'C')
+    dev = accel.DeviceArray(context, host.shape, dtype)
+    dev.set(queue, host)
+    return dev
+
+
+class VisibilityCollectorDevice:
+    """Preprocess visibilities on the GPU and keep them there (preprocess.py:73-156,
+    preprocess.cpp:390-513).
+
+    Parameters
+    ----------
+    command_queue : :class:`accel.CommandQueue`
+    image_parameters, grid_parameters : lists, one entry per channel
+        (``cell_size``; ``fixed.max_w``, ``w_slices``, ``w_planes``, ``fixed.oversample``)
+    buffer_size : int
+        Visibilities converted and compressed together (merging never crosses a buffer,
+        preprocess.cpp:431-509); also the largest block ``iter_slice_device`` can serve.
+    """
+
+    def __init__(self, command_queue, image_parameters, grid_parameters, buffer_size):
+        if len(image_parameters) != len(grid_parameters):
+            raise ValueError('Inconsistent lengths of image_parameters and grid_parameters')
+        if buffer_size <= 0:
+            raise ValueError('buffer_size must be positive')
+        self.queue = command_queue
+        self.context = command_queue.context
+        self.image_parameters = list(image_parameters)
+        self.grid_parameters = list(grid_parameters)
+        self.buffer_size = int(buffer_size)
+        self.num_polarizations = P = len(image_parameters[0].fixed.polarizations)
+        for ip in image_parameters:
+            if len(ip.fixed.polarizations) != P:
+                raise ValueError('all channels must have the same polarizations')
+        self.store_dtype = make_store_dtype(P)
+        self.num_input = 0
+        self.num_output = 0
+        self._closed = False
+        self._stores = [
+            [_SliceStore(self.context, self.queue, P, self.buffer_size)
+             for _ in range(gp.w_slices)]
+            for gp in self.grid_parameters]
+        self._lib = lib()
+        B = self.buffer_size
+        ctx = self.context
+        self._key = accel.DeviceArray(ctx, (B, 6), np.int16)
+        self._cw = accel.DeviceArray(ctx, (B, P), np.float32)
+        self._cvis = accel.DeviceArray(ctx, (B, P), np.complex64)
+        self._out = dict(
+            uv=accel.DeviceArray(ctx, (B, 4), np.int16),
+            w_plane=accel.DeviceArray(ctx, (B,), np.int16),
+            weights=accel.DeviceArray(ctx, (B, P), np.float32),
+            vis=accel.DeviceArray(ctx, (B, P), np.complex64))
+        max_slices = max(gp.w_slices for gp in self.grid_parameters)
+        self._counts = accel.DeviceArray(ctx, (max_slices,), np.int64)
+        self._ws_bytes = int(self._lib.kimg_preprocess_workspace_bytes(B, P))
+        if self._ws_bytes == 0:
+            raise ValueError('unsupported buffer_size / polarizations')
+        self._ws = accel.DeviceArray(ctx, (self._ws_bytes,), np.uint8)
+
+    @property
+    def num_channels(self):
+        return len(self.image_parameters)
+
+    def _matrix(self, m, shape):
+        if m is None:
+            return None
+        m = np.ascontiguousarray(np.asarray(m), np.complex64)
+        if m.shape != shape:
+            raise ValueError('matrix has shape {}, expected {}'.format(m.shape, shape))
+        return m
+
+    def add(self, uvw, weights, vis, feed_angle1, feed_angle2, mueller_stokes, mueller_circular):
+        """Add N visibilities of every channel (preprocess.py:117-150).
+
+        uvw: N x 3 float32 metres; weights: C x N x Q float32; vis: C x N x Q complex64;
+        feed_angle1/2: N float32 radians or None; mueller_stokes: P x Q (no feed angles) or
+        P x 4; mueller_circular: 4 x Q or None.
+        """
+        if self._closed:
+            raise RuntimeError('collector is closed')
+        if (feed_angle1 is None) != (feed_angle2 is None) or \
+                (feed_angle1 is None) != (mueller_circular is None):
+            raise ValueError('feed angles and mueller_circular must be given together')
+        P = self.num_polarizations
+        d_uvw = _to_device(self.context, self.queue, uvw, np.float32)
+        d_weights = _to_device(self.context, self.queue, weights, np.float32)
+        d_vis = _to_device(self.context, self.queue, vis, np.complex64)
+        d_fa1 = _to_device(self.context, self.queue, feed_angle1, np.float32)
+        d_fa2 = _to_device(self.context, self.queue, feed_angle2, np.float32)
+        if len(d_uvw.shape) != 2 or d_uvw.shape[1] != 3:
+            raise ValueError('Array has incorrect size')
+        N = d_uvw.shape[0]
+        C = self.num_channels
+        if len(d_vis.shape) != 3:
+            raise ValueError('Array has incorrect number of dimensions')
+        Q = d_vis.shape[2]
+        if Q < 1 or Q > 4:
+            raise ValueError('only 4 input polarizations are supported')
+        if d_vis.shape != (C, N, Q) or d_weights.shape != (C, N, Q):
+            raise ValueError('Array has incorrect size')
+        if d_fa1 is not None and (d_fa1.shape != (N,) or d_fa2.shape != (N,)):
+            raise ValueError('Array has incorrect size')
+        stokes = self._matrix(mueller_stokes, (P, 4) if d_fa1 is not None else (P, Q))
+        circular = self._matrix(mueller_circular, (4, Q))
+        stream = self.queue.handle
+        f32 = np.dtype(np.float32).itemsize
+        for ch in range(C):
+            gp = self.grid_parameters[ch]
+            cell = float(self.image_parameters[ch].cell_size)
+            stores = self._stores[ch]
+            for i0 in range(0, N, self.buffer_size):
+                n = min(N, i0 + self.buffer_size) - i0
+                row = (ch * N + i0) * Q
+                check(self._lib.kimg_preprocess_convert(
+                    P, Q, n, d_uvw.ptr + i0 * 3 * f32, d_weights.ptr + row * f32,
+                    d_vis.ptr + row * 2 * f32,
+                    d_fa1.ptr + i0 * f32 if d_fa1 is not None else None,
+                    d_fa2.ptr + i0 * f32 if d_fa2 is not None else None,
+                    stokes.ctypes.data, circular.ctypes.data if circular is not None else None,
+                    float(gp.fixed.max_w), gp.w_slices, gp.w_planes, gp.fixed.oversample, cell,
+                    self._key.ptr, self._cw.ptr, self._cvis.ptr, stream), 'kimg_preprocess_convert')
+                check(self._lib.kimg_preprocess_compress(
+                    P, n, gp.w_slices, self._key.ptr, self._cw.ptr, self._cvis.ptr,
+                    self._out['uv'].ptr, self._out['w_plane'].ptr, self._out['weights'].ptr,
+                    self._out['vis'].ptr, self._counts.ptr, self._ws.ptr, self._ws_bytes, stream),
+                    'kimg_preprocess_compress')
+                counts = self._counts.get(self.queue)[:gp.w_slices]      # synchronises
+                pos = 0
+                for s, c in enumerate(counts):
+                    c = int(c)
+                    if c:
+                        stores[s].append(self._out, pos, c)
+                        pos += c
+                self.num_output += pos
+        self.num_input += C * N
+        # the staging arrays of this call may be freed once the stream has consumed them
+        self.queue.finish()
+
+    def close(self):
+        self._closed = True
+
+    def reader(self):
+        """Only after :meth:`close` (preprocess.py:152-156)."""
+        if not self._closed:
+            raise RuntimeError('reader() may only be called after close()')
+        return VisibilityReaderDevice(self)
+
+    def nbytes(self):
+        """HBM held by the stored visibilities (excluding slack)."""
+        return sum(s.length for ch in self._stores for s in ch) * self.store_dtype.itemsize
+
+
+class VisibilityReaderDevice:
+    """Reader over a closed :class:`VisibilityCollectorDevice` (preprocess.py:277-420)."""
+
+    def __init__(self, collector):
+        self.collector = collector
+        self._stores = collector._stores
+        self.store_dtype = collector.store_dtype
+
+    @property
+    def num_channels(self):
+        return len(self._stores)
+
+    def num_w_slices(self, channel):
+        return len(self._stores[channel])
+
+    def len(self, channel, w_slice):
+        return self._stores[channel][w_slice].length
+
+    def iter_slice_device(self, channel, w_slice, block_size=None):
+        """Yield :class:`DeviceChunk` views of ``block_size`` rows (the last one partly
+        valid).  ``block_size`` defaults to, and may not exceed, the collector's buffer size."""
+        store = self._stores[channel][w_slice]
+        if block_size is None:
+            block_size = self.collector.buffer_size
+        if block_size <= 0 or block_size > store.slack:
+            raise ValueError('block_size must be in 1..{}'.format(store.slack))
+        for start in range(0, store.length, block_size):
+            v = store.view(start, block_size)
+            yield DeviceChunk(min(block_size, store.length - start), v['uv'], v['w_plane'],
+                              v['weights'], v['vis'])
+
+    def iter_slice(self, channel, w_slice, block_size=None):
+        """Yield host record arrays (fields uv, sub_uv, w_plane, weights, vis) like
+        VisibilityReaderMem.iter_slice (preprocess.py:398-403)."""
+        store = self._stores[channel][w_slice]
+        queue = self.collector.queue
+        if block_size is None:
+            block_size = self.collector.buffer_size
+        for start in range(0, store.length, block_size):
+            n = min(block_size, store.length - start)
+            v = store.view(start, n)
+            rec = np.rec.recarray((n,), self.store_dtype)
+            uv = v['uv'].get(queue)
+            rec.uv = uv[:, 0:2]
+            rec.sub_uv = uv[:, 2:4]
+            rec.w_plane = v['w_plane'].get(queue)
+            rec.weights = v['weights'].get(queue)
+            rec.vis = v['vis'].get(queue)
+            yield rec
+
+    def close(self):
+        pass

@@ -243,3 +243,181 @@ void oracle_update_tiles(const float *image, int P, int H, int W, int border, in
             tile_pos[2 * (ty * tiles_x + tx) + 1] = best1;
         }
 }
+
+/* ------------------------------------------------------------------------
+ * Visibility preprocessing, preprocess.cpp:313-372 and :390-513.
+ *
+ * The reference's _preprocess extension needs Eigen3 and cannot be built in
+ * this image; this restates its arithmetic.  Pinned by the known-answer
+ * vectors of test_preprocess.py:76-136 (tests/test_oracle_known_answers.py).
+ * One deliberate choice where the reference leaves the order to Eigen's
+ * unroller: the Mueller products are summed in index order.
+ * ---------------------------------------------------------------------- */
+typedef struct {            /* channel_config, preprocess.cpp:54-61 */
+    float max_w;
+    int32_t w_slices, w_planes, oversample;
+    float cell_size;
+} pp_config;
+
+static inline c64 mulz_c(c64 a, c64 b)        /* MulZ<complex<float>>::operator*, mulz.h:37-40 */
+{
+    c64 z = {0.0f, 0.0f};
+    int a_nz = (a.re != 0.0f) || (a.im != 0.0f);
+    int b_nz = (b.re != 0.0f) || (b.im != 0.0f);
+    return (a_nz && b_nz) ? c64_mul(a, b) : z;
+}
+
+static inline float mulz_f(float a, float b)
+{
+    return (a != 0.0f && b != 0.0f) ? a * b : 0.0f;
+}
+
+static void pp_subpixel(float x, int32_t oversample, int16_t *pixel, int16_t *sub)   /* :313-323 */
+{
+    int32_t xs = (int32_t) floorf(x * (float) oversample);
+    int32_t p = xs / oversample, s = xs % oversample;
+    if (s < 0) { p--; s += oversample; }
+    *pixel = (int16_t) p;
+    *sub = (int16_t) s;
+}
+
+/* Per-visibility conversion of add_impl2 (:435-507) for one channel.
+ * uvw [n][3]; weights, vis [n][Q]; feed angles [n] or NULL (then `stokes` is the P x Q matrix
+ * used directly, :198-205); otherwise stokes is P x 4 and circular 4 x Q (:216-258).
+ * Outputs: key [n][6] = (u, v, sub_u, sub_v, w_plane, w_slice); out_w [n][P]; out_vis [n][P].
+ * Flagged inputs give an all-zero record (:446-454). */
+void oracle_pp_convert(int P, int Q, long n, const float *uvw, const float *weights, const c64 *vis,
+                       const float *fa1, const float *fa2, const c64 *stokes, const c64 *circular,
+                       const pp_config *conf, int16_t *key, float *out_w, c64 *out_vis)
+{
+    const float uv_scale = 1.0f / conf->cell_size;                                       /* :428 */
+    const float w_scale = (conf->w_slices - 0.5f) * conf->w_planes / conf->max_w;        /* :429 */
+    const int max_slice_plane = conf->w_slices * conf->w_planes - 1;                     /* :430 */
+    for (long i = 0; i < n; i++) {
+        const float *wi = weights + i * Q;
+        const c64 *vi = vis + i * Q;
+        int flagged = 0;
+        for (int q = 0; q < Q; q++)
+            if (wi[q] == 0.0f) flagged = 1;
+        if (flagged) {
+            memset(key + 6 * i, 0, 6 * sizeof(int16_t));
+            memset(out_w + i * P, 0, P * sizeof(float));
+            memset(out_vis + i * P, 0, P * sizeof(c64));
+            continue;
+        }
+        c64 M[4][4];
+        if (!fa1) {
+            for (int p = 0; p < P; p++)
+                for (int q = 0; q < Q; q++) M[p][q] = stokes[p * Q + q];
+        } else {                                                                         /* :244-258 */
+            c64 r1 = {cosf(fa1[i]), sinf(fa1[i])}, r2 = {cosf(fa2[i]), sinf(fa2[i])};
+            c64 r2c = {r2.re, -r2.im};
+            c64 rr = c64_mul(r1, r2c), rl = c64_mul(r1, r2);
+            c64 scale[4] = {rr, rl, {rl.re, -rl.im}, {rr.re, -rr.im}};
+            c64 mu[4][4];
+            for (int k = 0; k < 4; k++)
+                for (int q = 0; q < Q; q++) mu[k][q] = c64_mul(circular[k * Q + q], scale[k]);
+            for (int p = 0; p < P; p++)
+                for (int q = 0; q < Q; q++) {
+                    c64 acc = {0.0f, 0.0f};
+                    for (int k = 0; k < 4; k++) {
+                        c64 t = c64_mul(stokes[p * 4 + k], mu[k][q]);
+                        acc.re += t.re;
+                        acc.im += t.im;
+                    }
+                    M[p][q] = acc;
+                }
+        }
+        c64 xvis[4];
+        float xw[4];
+        for (int p = 0; p < P; p++) {
+            c64 acc = {0.0f, 0.0f};
+            float var = 0.0f;
+            for (int q = 0; q < Q; q++) {
+                c64 t = mulz_c(M[p][q], vi[q]);                                          /* :456 */
+                acc.re += t.re;
+                acc.im += t.im;
+                float m2 = M[p][q].re * M[p][q].re + M[p][q].im * M[p][q].im;            /* cwiseAbs2 */
+                var += mulz_f(m2, 1.0f / fabsf(wi[q]));                                  /* :468-471 */
+            }
+            xvis[p] = acc;
+            xw[p] = 1.0f / var;
+        }
+        float u = uvw[3 * i], v = uvw[3 * i + 1], w = uvw[3 * i + 2];
+        if (w < 0.0f) {                                                                  /* :476-482 */
+            u = -u; v = -v; w = -w;
+            for (int p = 0; p < P; p++) xvis[p].im = -xvis[p].im;
+        }
+        for (int p = 0; p < P; p++) {                                                    /* :483-496 */
+            float weight = xw[p];
+            c64 s = {xvis[p].re * weight, xvis[p].im * weight};
+            if (!isfinite(s.re) || !isfinite(s.im)) {
+                s.re = s.im = 0.0f;
+                weight = 0.0f;
+            }
+            out_vis[i * P + p] = s;
+            out_w[i * P + p] = weight;
+        }
+        u = u * uv_scale;
+        v = v * uv_scale;
+        w = truncf(w * w_scale + conf->w_planes * 0.5f);                                 /* :501 */
+        int wsp = (int) w;
+        if (wsp > max_slice_plane) wsp = max_slice_plane;
+        int16_t *k = key + 6 * i;
+        pp_subpixel(u, conf->oversample, &k[0], &k[2]);
+        pp_subpixel(v, conf->oversample, &k[1], &k[3]);
+        k[4] = (int16_t) (wsp % conf->w_planes);
+        k[5] = (int16_t) (wsp / conf->w_planes);
+    }
+}
+
+/* compress (:334-372): drop flagged (weights[0] == 0), merge adjacent equal keys with sequential
+ * float32 sums, stable bucket sort by w_slice.  counts[w_slices] receives the run length per slice;
+ * returns the number of output records (written to out_* in slice order). */
+long oracle_pp_compress(int P, long n, int w_slices, const int16_t *key, const float *w, const c64 *vis,
+                        int16_t *out_key, float *out_w, c64 *out_vis, long *counts,
+                        int16_t *tmp_key, float *tmp_w, c64 *tmp_vis)
+{
+    long out_pos = 0, i = 0;
+    for (int s = 0; s < w_slices; s++) counts[s] = 0;
+    while (i < n && w[i * P] == 0.0f) i++;
+    if (i == n) return 0;
+    int16_t last_key[6];
+    float last_w[4];
+    c64 last_vis[4];
+    memcpy(last_key, key + 6 * i, sizeof(last_key));
+    memcpy(last_w, w + i * P, P * sizeof(float));
+    memcpy(last_vis, vis + i * P, P * sizeof(c64));
+    for (i++; i <= n; i++) {
+        int end = (i == n);
+        if (!end && w[i * P] == 0.0f) continue;
+        if (!end && memcmp(key + 6 * i, last_key, sizeof(last_key)) == 0) {
+            for (int p = 0; p < P; p++) {
+                last_vis[p].re += vis[i * P + p].re;
+                last_vis[p].im += vis[i * P + p].im;
+            }
+            for (int p = 0; p < P; p++) last_w[p] += w[i * P + p];
+        } else {
+            counts[last_key[5]]++;
+            memcpy(tmp_key + 6 * out_pos, last_key, sizeof(last_key));
+            memcpy(tmp_w + out_pos * P, last_w, P * sizeof(float));
+            memcpy(tmp_vis + out_pos * P, last_vis, P * sizeof(c64));
+            out_pos++;
+            if (!end) {
+                memcpy(last_key, key + 6 * i, sizeof(last_key));
+                memcpy(last_w, w + i * P, P * sizeof(float));
+                memcpy(last_vis, vis + i * P, P * sizeof(c64));
+            }
+        }
+    }
+    long start[1024];
+    long sum = 0;
+    for (int s = 0; s < w_slices; s++) { start[s] = sum; sum += counts[s]; }
+    for (long j = 0; j < out_pos; j++) {
+        long d = start[tmp_key[6 * j + 5]]++;
+        memcpy(out_key + 6 * d, tmp_key + 6 * j, 6 * sizeof(int16_t));
+        memcpy(out_w + d * P, tmp_w + j * P, P * sizeof(float));
+        memcpy(out_vis + d * P, tmp_vis + j * P, P * sizeof(c64));
+    }
+    return out_pos;
+}

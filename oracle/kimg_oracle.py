@@ -237,6 +237,107 @@ def _c(a, dtype):
 
 
 # --------------------------------------------------------------------------
+# preprocess.cpp:390-513 + preprocess.py:73-310   visibility collector
+# --------------------------------------------------------------------------
+PP_CONFIG_DTYPE = np.dtype([('max_w', 'f4'), ('w_slices', 'i4'), ('w_planes', 'i4'),
+                            ('oversample', 'i4'), ('cell_size', 'f4')])
+
+
+def preprocess_convert(uvw, weights, vis, feed_angle1, feed_angle2, mueller_stokes, mueller_circular,
+                       config, num_polarizations):
+    """One channel of add_impl2 (preprocess.cpp:435-507) through the C restatement.
+    Returns (key int16 [n][6] = u, v, sub_u, sub_v, w_plane, w_slice; weights [n][P]; vis [n][P])."""
+    P = num_polarizations
+    uvw = _c(uvw, np.float32)
+    weights = _c(weights, np.float32)
+    vis = _c(vis, np.complex64)
+    n, Q = vis.shape
+    stokes = _c(np.asarray(mueller_stokes), np.complex64)
+    conf = np.zeros(1, PP_CONFIG_DTYPE)
+    for k in PP_CONFIG_DTYPE.names:
+        conf[k] = config[k]
+    key = np.zeros((n, 6), np.int16)
+    out_w = np.zeros((n, P), np.float32)
+    out_vis = np.zeros((n, P), np.complex64)
+    if feed_angle1 is None:
+        assert stokes.shape == (P, Q)
+        fa1 = fa2 = circ = None
+    else:
+        fa1 = _c(feed_angle1, np.float32)
+        fa2 = _c(feed_angle2, np.float32)
+        circ = _c(np.asarray(mueller_circular), np.complex64)
+        assert stokes.shape == (P, 4) and circ.shape == (4, Q)
+    clib().oracle_pp_convert(
+        ctypes.c_int(P), ctypes.c_int(Q), ctypes.c_long(n), _p(uvw), _p(weights), _p(vis),
+        _p(fa1) if fa1 is not None else None, _p(fa2) if fa2 is not None else None,
+        _p(stokes), _p(circ) if circ is not None else None, _p(conf), _p(key), _p(out_w), _p(out_vis))
+    return key, out_w, out_vis
+
+
+def preprocess_compress(key, weights, vis, w_slices):
+    """compress (preprocess.cpp:334-372): returns (key, weights, vis, counts per w_slice), the
+    records ordered by w_slice with arrival order kept inside a slice."""
+    n, P = weights.shape
+    out_key = np.zeros_like(key)
+    out_w = np.zeros_like(weights)
+    out_vis = np.zeros_like(vis)
+    tmp = (np.zeros_like(key), np.zeros_like(weights), np.zeros_like(vis))
+    counts = np.zeros(max(w_slices, 1), np.int64)
+    lib = clib()
+    lib.oracle_pp_compress.restype = ctypes.c_long
+    m = lib.oracle_pp_compress(
+        ctypes.c_int(P), ctypes.c_long(n), ctypes.c_int(w_slices), _p(key), _p(weights), _p(vis),
+        _p(out_key), _p(out_w), _p(out_vis), _p(counts), _p(tmp[0]), _p(tmp[1]), _p(tmp[2]))
+    return out_key[:m], out_w[:m], out_vis[:m], counts
+
+
+class VisibilityCollector:
+    """preprocess.py:73-150 + VisibilityCollectorMem (:257-274): per channel and per buffer of
+    `buffer_size` inputs, convert -> compress -> append each w_slice run to datasets[channel][slice].
+
+    `configs` is a sequence of dicts/records with the fields of PP_CONFIG_DTYPE."""
+
+    def __init__(self, configs, num_polarizations, buffer_size):
+        self.configs = list(configs)
+        self.P = num_polarizations
+        self.buffer_size = buffer_size
+        self.num_input = 0
+        self.num_output = 0
+        self.datasets = [[[] for _ in range(int(c['w_slices']))] for c in self.configs]
+
+    def add(self, uvw, weights, vis, feed_angle1, feed_angle2, mueller_stokes, mueller_circular):
+        N = len(uvw)
+        for ch, conf in enumerate(self.configs):
+            for i0 in range(0, N, self.buffer_size):
+                i1 = min(N, i0 + self.buffer_size)
+                fa1 = None if feed_angle1 is None else feed_angle1[i0:i1]
+                fa2 = None if feed_angle2 is None else feed_angle2[i0:i1]
+                key, w, v = preprocess_convert(uvw[i0:i1], weights[ch, i0:i1], vis[ch, i0:i1], fa1, fa2,
+                                               mueller_stokes, mueller_circular, conf, self.P)
+                key, w, v, counts = preprocess_compress(key, w, v, int(conf['w_slices']))
+                pos = 0
+                for s, c in enumerate(counts):
+                    if c:
+                        sl = slice(pos, pos + c)
+                        self.datasets[ch][s].append(dict(
+                            uv=key[sl, 0:2].copy(), sub_uv=key[sl, 2:4].copy(),
+                            w_plane=key[sl, 4].copy(), weights=w[sl].copy(), vis=v[sl].copy()))
+                        pos += c
+                self.num_output += pos
+        self.num_input += len(self.configs) * N
+
+    def slice_arrays(self, channel, w_slice):
+        """All records of one (channel, w_slice) concatenated, as a dict of arrays."""
+        parts = self.datasets[channel][w_slice]
+        names = ('uv', 'sub_uv', 'w_plane', 'weights', 'vis')
+        if not parts:
+            return dict(uv=np.zeros((0, 2), np.int16), sub_uv=np.zeros((0, 2), np.int16),
+                        w_plane=np.zeros(0, np.int16), weights=np.zeros((0, self.P), np.float32),
+                        vis=np.zeros((0, self.P), np.complex64))
+        return {k: np.concatenate([p[k] for p in parts]) for k in names}
+
+
+# --------------------------------------------------------------------------
 # grid.py:1032-1052 / 1138-1154   gridding and degridding
 # --------------------------------------------------------------------------
 def grid_py(kernel, grid, weights_grid, uv, sub_uv, w_plane, vis):

@@ -271,10 +271,9 @@ def make_records(P, uv, sub_uv, w_plane, weights, vis):
     return rec.view(np.recarray)
 
 
-def e2e_inputs(c, seed=11):
-    """Synthetic observation: random-walk uvw tracks (metres), point sources,
-    quantised and compressed with the restated preprocessor rules."""
-    from oracle import kimg_oracle as orc
+def e2e_raw(c, seed=11):
+    """Synthetic observation before preprocessing: random-walk uvw tracks (metres, float32
+    [N][3]), point-source visibilities (complex128 [N]) and weights (float32 [N][1])."""
     rs = np.random.RandomState(seed)
     n = c['n_vis']
     ntracks = 60
@@ -306,6 +305,13 @@ def e2e_inputs(c, seed=11):
                                               + uvw_wl[:, 2] * (nn - 1)))
     vis += 0.02 * (rs.standard_normal(len(uvw)) + 1j * rs.standard_normal(len(uvw)))
     weights = rs.uniform(0.5, 1.5, (len(uvw), 1)).astype(np.float32)
+    return uvw, vis, weights
+
+
+def e2e_inputs(c, seed=11):
+    """:func:`e2e_raw` quantised and compressed with the restated preprocessor rules."""
+    from oracle import kimg_oracle as orc
+    uvw, vis, weights = e2e_raw(c, seed)
     rec = orc.quantise_uvw(uvw, vis[:, None].astype(np.complex64), weights, c['cell_size'],
                            c['max_w'], c['w_slices'], c['w_planes'], c['oversample'])
     rec = orc.compress(rec)

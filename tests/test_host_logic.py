@@ -102,3 +102,42 @@ def test_float64_rejected():
     from katsdpimager_amd import types
     with pytest.raises(ValueError):
         types.require_float32(np.float64, 'x')
+
+
+def test_store_dtype_layout():
+    """The record type of VisibilityReaderDevice.iter_slice has the reference's field offsets
+    (vis_t<P> without w_slice, preprocess.cpp:39-52 + preprocess.py:42-56)."""
+    from katsdpimager_amd import preprocess
+    for P in (1, 2, 4):
+        dt = preprocess.make_store_dtype(P)
+        assert dt.names == ('uv', 'sub_uv', 'w_plane', 'weights', 'vis')
+        assert [dt.fields[n][1] for n in dt.names] == [0, 4, 8, 12, 12 + 4 * P]
+        assert dt.itemsize == 12 + 12 * P
+        assert dt['weights'].shape == (P,) and dt['vis'].base == np.complex64
+
+
+def test_preprocess_argument_validation():
+    """Bad arguments are refused before anything touches the device."""
+    from katsdpimager_amd import _lib
+    L = _lib.lib()
+    m = np.identity(4, np.complex64)
+    ok = dict(P=4, Q=4, n=0)
+    assert L.kimg_preprocess_convert(4, 4, 0, None, None, None, None, None, m.ctypes.data, None,
+                                     400.0, 1, 128, 8, 1.0, None, None, None, None) == 0
+    bad = [
+        (5, 4, 0, 400.0, 1, 128, 8, 1.0), (4, 0, 0, 400.0, 1, 128, 8, 1.0),
+        (4, 4, -1, 400.0, 1, 128, 8, 1.0), (4, 4, 0, 0.0, 1, 128, 8, 1.0),
+        (4, 4, 0, 400.0, 0, 128, 8, 1.0), (4, 4, 0, 400.0, 1, 40000, 8, 1.0),
+        (4, 4, 0, 400.0, 1, 128, 0, 1.0), (4, 4, 0, 400.0, 1, 128, 8, 0.0)]
+    for P, Q, n, max_w, ws, wp, ov, cell in bad:
+        assert L.kimg_preprocess_convert(P, Q, n, None, None, None, None, None, m.ctypes.data, None,
+                                         max_w, ws, wp, ov, cell, None, None, None, None) == -10001
+    # feed angles without mueller_circular
+    assert L.kimg_preprocess_convert(4, 4, 0, None, None, None, 8, 8, m.ctypes.data, None,
+                                     400.0, 1, 128, 8, 1.0, None, None, None, None) == -10001
+    assert L.kimg_preprocess_compress(5, 0, 1, None, None, None, None, None, None, None, 8,
+                                      None, 0, None) == -10001
+    assert L.kimg_preprocess_compress(1, 10, 1, None, None, None, None, None, None, None, 8,
+                                      None, 0, None) == -10001
+    assert L.kimg_real_to_complex(None, None, -1, None) == -10001
+    assert L.kimg_real_to_complex(None, None, 0, None) == 0

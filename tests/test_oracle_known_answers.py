@@ -3,6 +3,7 @@ against the oracle.  CPU only.  Citations: katsdpimager/test/*.py."""
 import math
 
 import numpy as np
+import pytest
 
 import golden_inputs as gi
 from oracle import kimg_oracle as orc
@@ -193,3 +194,144 @@ def test_preprocess_known():
         np.testing.assert_array_equal(rec['w_plane'], e['w_plane'])
         np.testing.assert_allclose(rec['weights'], e['weights'], rtol=1e-6)
         np.testing.assert_allclose(rec['vis'], np.array(e['vis']), rtol=1e-5)
+
+
+def _known_preprocess_inputs():
+    uvw = np.array([[12.1, 2.3, 4.7], [12.102, 2.299, 4.6], [-5.2, -10.6, 7.2], [-1.0, 2.0, 3.0]],
+                   np.float32)
+    weights = np.array([[[1.3, 0.6, 1.2, 0.1], [1.1, 1.2, 1.3, 1.4], [0.5, 0.6, 0.7, 0.8],
+                         [1.0, 0.0, 1.0, 1.0]],
+                        [[0.2, 2.4, 1.2, 2.6], [2.8, 2.6, 2.4, 2.2], [1.6, 1.4, 1.2, 1.0],
+                         [2.0, 2.0, 0.0, 2.0]]], np.float32)
+    vis = np.array([[[0.5 - 2.3j, 0.1 + 4.2j, 0.0 - 3j, 1.5 + 0j],
+                     [1.2 + 3.4j, 5.6 + 7.8j, 9.0 + 1.2j, 3.4 + 5.6j],
+                     [1.5 + 1.3j, 1.1 + 2.7j, 1.0 - 2j, 2.5 + 1j], [10.0, 10.0, 10.0, 10.0]],
+                    [[3.0 + 0j, 0.0 - 6j, 0.2 + 8.4j, 1.0 - 4.6j],
+                     [6.8 + 11.2j, 18.0 + 2.4j, 11.2 + 15.6j, 2.4 + 6.8j],
+                     [3.0 + 2j, 2.0 - 4j, 2.2 + 5.4j, 3.0 + 2.6j], [20.0, 20.0, 20.0, 20.0]]],
+                   np.complex64)
+    expected = [
+        dict(uv=[[96, 18], [-42, -85]], sub_uv=[[6, 3], [3, 1]], w_plane=[64, 65],
+             weights=[[2.4, 1.8, 2.5, 1.5], [0.5, 0.6, 0.7, 0.8]],
+             vis=[[1.97 + 0.75j, 6.78 + 11.88j, 11.7 - 2.04j, 4.91 + 7.84j],
+                  [0.75 + 0.65j, 0.66 + 1.62j, 0.7 - 1.4j, 2.0 + 0.8j]]),
+        dict(uv=[[387, 73], [387, 73], [-167, -340]], sub_uv=[[1, 4], [2, 4], [4, 6]],
+             w_plane=[64, 64, 65],
+             weights=[[0.2, 2.4, 1.2, 2.6], [2.8, 2.6, 2.4, 2.2], [1.6, 1.4, 1.2, 1.0]],
+             vis=[[0.6 + 0.0j, 0.0 - 14.4j, 0.24 + 10.08j, 2.6 - 11.96j],
+                  [19.04 + 31.36j, 46.8 + 6.24j, 26.88 + 37.44j, 5.28 + 14.96j],
+                  [4.8 + 3.2j, 2.8 - 5.6j, 2.64 + 6.48j, 3.0 + 2.6j]])]
+    configs = []
+    for wavelength in [0.25, 0.125]:
+        pixel_size = 1.0 / (4096.0 * wavelength)
+        configs.append(dict(max_w=400.0, w_slices=1, w_planes=128, oversample=8,
+                            cell_size=wavelength / (pixel_size * 2048)))
+    return uvw, weights, vis, configs, expected
+
+
+@pytest.mark.parametrize('use_feed_angles', [False, True])
+def test_preprocess_collector_known(use_feed_angles):
+    """BaseTestVisibilityCollector._test_impl (test_preprocess.py:76-136) on the collector
+    restatement, with and without (trivial) feed angles, buffer of 64."""
+    uvw, weights, vis, configs, expected = _known_preprocess_inputs()
+    ident = np.identity(4, np.complex64)
+    fa = np.zeros(4, np.float32) if use_feed_angles else None
+    coll = orc.VisibilityCollector(configs, 4, 64)
+    coll.add(uvw, weights, vis, fa, fa, ident, ident if use_feed_angles else None)
+    assert coll.num_input == 8 and coll.num_output == 5
+    for ch, e in enumerate(expected):
+        rec = coll.slice_arrays(ch, 0)
+        np.testing.assert_array_equal(rec['uv'], e['uv'])
+        np.testing.assert_array_equal(rec['sub_uv'], e['sub_uv'])
+        np.testing.assert_array_equal(rec['w_plane'], e['w_plane'])
+        np.testing.assert_allclose(rec['weights'], e['weights'], rtol=1e-6)
+        np.testing.assert_allclose(rec['vis'], np.array(e['vis']), rtol=1e-5)
+
+
+def test_preprocess_collector_empty():
+    """test_preprocess.py:71-74."""
+    _, _, _, configs, _ = _known_preprocess_inputs()
+    coll = orc.VisibilityCollector(configs, 4, 2)
+    for ch in range(2):
+        assert len(coll.slice_arrays(ch, 0)['uv']) == 0
+
+
+def test_preprocess_c_vs_numpy():
+    """The C collector restatement against the numpy restatement (identity Mueller), bit for bit,
+    on clustered coordinates with flags, NaNs, negative w and several w-slices."""
+    rng = np.random.default_rng(11)
+    n, P = 4000, 2
+    base = rng.uniform(-300, 300, (n // 8, 3)).astype(np.float32)
+    uvw = (np.repeat(base, 8, axis=0) + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    weights = rng.uniform(0.5, 2, (1, n, P)).astype(np.float32)
+    weights[0, rng.random(n) < 0.1, 0] = 0
+    weights[0, rng.random(n) < 0.05, 1] = 0
+    vis = (rng.normal(size=(1, n, P)) + 1j * rng.normal(size=(1, n, P))).astype(np.complex64)
+    vis[0, rng.random(n) < 0.02, 1] = np.nan
+    vis[0, rng.random(n) < 0.02, 0] = np.nan
+    conf = dict(max_w=320.0, w_slices=5, w_planes=16, oversample=8, cell_size=1.7)
+    coll = orc.VisibilityCollector([conf], P, n)
+    coll.add(uvw, weights, vis, None, None, np.identity(P, np.complex64), None)
+    rec = orc.quantise_uvw(uvw, vis[0], weights[0], conf['cell_size'], conf['max_w'], 5, 16, 8)
+    keep = rec['weights'][:, 0] != 0          # compress() drops records whose first weight is 0
+    rec = orc.compress({k: v[keep] for k, v in rec.items()})
+    total = 0
+    for s in range(5):
+        got = coll.slice_arrays(0, s)
+        sel = rec['w_slice'] == s
+        total += sel.sum()
+        for k in ('uv', 'sub_uv', 'w_plane'):
+            np.testing.assert_array_equal(got[k], rec[k][sel])
+        np.testing.assert_array_equal(got['weights'], rec['weights'][sel])
+        np.testing.assert_array_equal(got['vis'].view(np.float32), rec['vis'][sel].view(np.float32))
+    assert total == coll.num_output and 0 < total < n
+
+
+def test_preprocess_mueller_float64():
+    """Full Mueller path (parallactic rotation, P=4 from Q=4 and P=1 from Q=2) against a direct
+    float64 evaluation of the formulas in preprocess.cpp:244-258,456-471."""
+    rng = np.random.default_rng(12)
+    n = 500
+    uvw = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+    conf = dict(max_w=120.0, w_slices=2, w_planes=8, oversample=8, cell_size=2.0)
+    for P, Q in [(4, 4), (1, 2), (2, 4)]:
+        weights = rng.uniform(0.5, 2, (n, Q)).astype(np.float32)
+        vis = (rng.normal(size=(n, Q)) + 1j * rng.normal(size=(n, Q))).astype(np.complex64)
+        stokes = (rng.normal(size=(P, 4)) + 1j * rng.normal(size=(P, 4))).astype(np.complex64)
+        circ = (rng.normal(size=(4, Q)) + 1j * rng.normal(size=(4, Q))).astype(np.complex64)
+        fa1 = rng.uniform(-3, 3, n).astype(np.float32)
+        fa2 = rng.uniform(-3, 3, n).astype(np.float32)
+        key, w, v = orc.preprocess_convert(uvw, weights, vis, fa1, fa2, stokes, circ, conf, P)
+        r1 = np.exp(1j * fa1.astype(np.float64))
+        r2 = np.exp(1j * fa2.astype(np.float64))
+        rr, rl = r1 * np.conj(r2), r1 * r2
+        scale = np.stack([rr, rl, np.conj(rl), np.conj(rr)], axis=1)          # n x 4
+        M = np.einsum('pk,nk,kq->npq', stokes.astype(np.complex128), scale, circ.astype(np.complex128))
+        xvis = np.einsum('npq,nq->np', M, vis.astype(np.complex128))
+        xw = 1.0 / np.einsum('npq,nq->np', np.abs(M) ** 2, 1.0 / weights.astype(np.float64))
+        xvis = np.where(uvw[:, 2:3] < 0, np.conj(xvis), xvis) * xw
+        np.testing.assert_allclose(w, xw, rtol=2e-5)
+        assert np.max(np.abs(v - xvis)) <= 2e-5 * np.max(np.abs(xvis))
+    # simple generator: the matrix is used as is
+    stokes = (rng.normal(size=(2, 3)) + 1j * rng.normal(size=(2, 3))).astype(np.complex64)
+    weights = rng.uniform(0.5, 2, (n, 3)).astype(np.float32)
+    vis = (rng.normal(size=(n, 3)) + 1j * rng.normal(size=(n, 3))).astype(np.complex64)
+    key, w, v = orc.preprocess_convert(uvw, weights, vis, None, None, stokes, None, conf, 2)
+    xvis = vis.astype(np.complex128) @ stokes.astype(np.complex128).T
+    xw = 1.0 / ((1.0 / weights.astype(np.float64)) @ (np.abs(stokes.astype(np.complex128)) ** 2).T)
+    xvis = np.where(uvw[:, 2:3] < 0, np.conj(xvis), xvis) * xw
+    assert np.max(np.abs(v - xvis)) <= 2e-5 * np.max(np.abs(xvis))
+    np.testing.assert_allclose(w, xw, rtol=2e-5)
+
+
+def test_preprocess_buffer_boundary():
+    """Merging never crosses a buffer boundary and each buffer emits its slices in order
+    (preprocess.cpp:431-509): two equal records split over two buffers stay separate."""
+    uvw = np.array([[10.0, 10.0, 1.0]] * 4, np.float32)
+    weights = np.ones((1, 4, 1), np.float32)
+    vis = np.ones((1, 4, 1), np.complex64)
+    conf = dict(max_w=100.0, w_slices=1, w_planes=4, oversample=8, cell_size=1.0)
+    for cap, lens in [(4, [4.0]), (2, [2.0, 2.0]), (3, [3.0, 1.0])]:
+        coll = orc.VisibilityCollector([conf], 1, cap)
+        coll.add(uvw, weights, vis, None, None, np.ones((1, 1), np.complex64), None)
+        np.testing.assert_array_equal(coll.slice_arrays(0, 0)['weights'][:, 0], lens)

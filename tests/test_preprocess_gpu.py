@@ -1,0 +1,311 @@
+"""GPU parity of the device preprocessor / visibility store against the
+restated collector (oracle.VisibilityCollector, pinned by test_preprocess.py's known answers)."""
+import types
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from helpers import context_queue
+from oracle import kimg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(configs, P):
+    ips, gps = [], []
+    for c in configs:
+        fixed_i = types.SimpleNamespace(polarizations=list(range(P)))
+        ips.append(types.SimpleNamespace(fixed=fixed_i, cell_size=c['cell_size']))
+        fixed_g = types.SimpleNamespace(max_w=c['max_w'], oversample=c['oversample'])
+        gps.append(types.SimpleNamespace(fixed=fixed_g, w_slices=c['w_slices'],
+                                         w_planes=c['w_planes']))
+    return ips, gps
+
+
+def _collect_device(configs, P, buffer_size, batches):
+    from katsdpimager_amd import preprocess
+    ctx, q = context_queue()
+    ips, gps = _params(configs, P)
+    coll = preprocess.VisibilityCollectorDevice(q, ips, gps, buffer_size)
+    for b in batches:
+        coll.add(*b)
+    coll.close()
+    return coll
+
+
+def _read(reader, channel, w_slice, block_size, dtype):
+    pieces = [p.copy() for p in reader.iter_slice(channel, w_slice, block_size)]
+    if pieces:
+        return np.rec.array(np.hstack(pieces))
+    return np.rec.recarray(0, dtype)
+
+
+def _known():
+    import test_oracle_known_answers as tk
+    return tk._known_preprocess_inputs()
+
+
+@pytest.mark.parametrize('use_feed_angles', [False, True])
+def test_known_answers(use_feed_angles):
+    """test_preprocess.py:76-136 (`_test_impl` + `check`) on the device collector."""
+    uvw, weights, vis, configs, expected = _known()
+    ident = np.identity(4, np.complex64)
+    fa = np.zeros(4, np.float32) if use_feed_angles else None
+    coll = _collect_device(configs, 4, 64,
+                           [(uvw, weights, vis, fa, fa, ident, ident if use_feed_angles else None)])
+    assert coll.num_input == 8 and coll.num_output == 5
+    reader = coll.reader()
+    assert reader.num_channels == 2
+    for ch, e in enumerate(expected):
+        assert reader.len(ch, 0) == len(e['uv'])
+        for block_size in [None, 1, 2, 100]:
+            actual = _read(reader, ch, 0, block_size, coll.store_dtype)
+            np.testing.assert_array_equal(actual.uv, e['uv'])
+            np.testing.assert_array_equal(actual.sub_uv, e['sub_uv'])
+            np.testing.assert_array_equal(actual.w_plane, e['w_plane'])
+            np.testing.assert_allclose(actual.weights, e['weights'], rtol=1e-6)
+            np.testing.assert_allclose(actual.vis, np.array(e['vis']), rtol=1e-5)
+
+
+def test_empty():
+    """test_preprocess.py:71-74."""
+    _, _, _, configs, _ = _known()
+    coll = _collect_device(configs, 4, 2, [])
+    reader = coll.reader()
+    for ch in range(2):
+        assert reader.len(ch, 0) == 0
+        assert list(reader.iter_slice(ch, 0)) == []
+        assert list(reader.iter_slice_device(ch, 0)) == []
+
+
+def _random_batch(rng, C, n, Q, clustered=8):
+    base = rng.uniform(-300, 300, (-(-n // clustered), 3)).astype(np.float32)
+    uvw = (np.repeat(base, clustered, axis=0)[:n] + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    weights = rng.uniform(0.5, 2, (C, n, Q)).astype(np.float32)
+    for q in range(Q):
+        weights[:, rng.random(n) < 0.05, q] = 0
+    weights[0, rng.random(n) < 0.01, 0] = -0.0
+    vis = (rng.normal(size=(C, n, Q)) + 1j * rng.normal(size=(C, n, Q))).astype(np.complex64)
+    vis[:, rng.random(n) < 0.02, Q - 1] = np.nan
+    vis[:, rng.random(n) < 0.02, 0] = np.inf
+    return uvw, weights, vis
+
+
+def _compare(coll, ref, configs, exact_float, P):
+    reader = coll.reader()
+    assert coll.num_input == ref.num_input
+    assert coll.num_output == ref.num_output
+    for ch, c in enumerate(configs):
+        assert reader.num_w_slices(ch) == c['w_slices']
+        for s in range(c['w_slices']):
+            e = ref.slice_arrays(ch, s)
+            assert reader.len(ch, s) == len(e['uv'])
+            got = _read(reader, ch, s, 4096, coll.store_dtype)
+            # index work: bit-exact
+            np.testing.assert_array_equal(got.uv, e['uv'])
+            np.testing.assert_array_equal(got.sub_uv, e['sub_uv'])
+            np.testing.assert_array_equal(got.w_plane, e['w_plane'])
+            if len(e['uv']) == 0:
+                continue
+            if exact_float:
+                np.testing.assert_array_equal(np.asarray(got.weights), e['weights'])
+                np.testing.assert_array_equal(np.ascontiguousarray(got.vis).view(np.float32),
+                                              e['vis'].view(np.float32))
+            else:
+                # float32 tolerance 1e-5 (north_star); sincosf differs from glibc by an ulp
+                np.testing.assert_allclose(got.weights, e['weights'], rtol=1e-5)
+                scale = np.abs(e['vis']).max()
+                assert np.abs(np.asarray(got.vis) - e['vis']).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize('P,Q,w_slices,buffer_size', [
+    (1, 1, 1, 5000), (1, 2, 5, 3001), (2, 2, 3, 70000), (4, 4, 1, 4096), (4, 4, 7, 9999),
+    (3, 4, 2, 20000), (2, 3, 33, 1 << 16)])
+def test_random_simple_mueller(P, Q, w_slices, buffer_size):
+    """Two add() calls, two channels, flags / -0 weights / NaN / inf visibilities, buffers that
+    do not divide the batch: identical records (floats bit for bit) to the restated collector."""
+    rng = np.random.default_rng(100 + P * 10 + Q)
+    configs = [dict(max_w=320.0, w_slices=w_slices, w_planes=16, oversample=8, cell_size=1.7),
+               dict(max_w=300.0, w_slices=w_slices, w_planes=8, oversample=4, cell_size=0.9)]
+    stokes = (rng.normal(size=(P, Q)) + 1j * rng.normal(size=(P, Q))).astype(np.complex64)
+    if Q > 1:
+        stokes[0, 0] = 0      # exercises the MulZ zero rule
+    batches = []
+    for n in (30011, 12345):
+        uvw, weights, vis = _random_batch(rng, 2, n, Q)
+        batches.append((uvw, weights, vis, None, None, stokes, None))
+    coll = _collect_device(configs, P, buffer_size, batches)
+    ref = orc.VisibilityCollector(configs, P, buffer_size)
+    for b in batches:
+        ref.add(*b)
+    assert 0 < ref.num_output < ref.num_input
+    _compare(coll, ref, configs, True, P)
+
+
+@pytest.mark.parametrize('P,Q', [(4, 4), (1, 2), (2, 4)])
+def test_random_parallactic(P, Q):
+    rng = np.random.default_rng(200 + P + Q)
+    configs = [dict(max_w=320.0, w_slices=4, w_planes=16, oversample=8, cell_size=1.7)]
+    n = 40000
+    uvw, weights, vis = _random_batch(rng, 1, n, Q)
+    stokes = (rng.normal(size=(P, 4)) + 1j * rng.normal(size=(P, 4))).astype(np.complex64)
+    circ = (rng.normal(size=(4, Q)) + 1j * rng.normal(size=(4, Q))).astype(np.complex64)
+    fa1 = rng.uniform(-3, 3, n).astype(np.float32)
+    fa2 = rng.uniform(-3, 3, n).astype(np.float32)
+    batch = (uvw, weights, vis, fa1, fa2, stokes, circ)
+    coll = _collect_device(configs, P, 16384, [batch])
+    ref = orc.VisibilityCollector(configs, P, 16384)
+    ref.add(*batch)
+    _compare(coll, ref, configs, False, P)
+
+
+def test_long_runs_and_all_flagged():
+    """One run spanning a whole buffer, a buffer with nothing valid, and a flagged head."""
+    n = 5000
+    uvw = np.tile(np.array([[10.0, -7.0, 3.0]], np.float32), (n, 1))
+    weights = np.ones((1, n, 1), np.float32)
+    weights[0, 0, 0] = 0                      # first record flagged
+    weights[0, 2000:3000, 0] = 0              # the whole second buffer flagged
+    vis = np.full((1, n, 1), 0.1 + 0.2j, np.complex64)
+    configs = [dict(max_w=100.0, w_slices=1, w_planes=4, oversample=8, cell_size=1.0)]
+    batch = (uvw, weights, vis, None, None, np.ones((1, 1), np.complex64), None)
+    coll = _collect_device(configs, 1, 1000, [batch])
+    ref = orc.VisibilityCollector(configs, 1, 1000)
+    ref.add(*batch)
+    assert ref.num_output == 4
+    _compare(coll, ref, configs, True, 1)
+
+
+def test_device_inputs_and_errors():
+    from katsdpimager_amd import accel, preprocess
+    ctx, q = context_queue()
+    uvw, weights, vis, configs, expected = _known()
+    ips, gps = _params(configs, 4)
+    coll = preprocess.VisibilityCollectorDevice(q, ips, gps, 64)
+    with pytest.raises(RuntimeError):
+        coll.reader()                                   # before close()
+    d = []
+    for a, dt in ((uvw, np.float32), (weights, np.float32), (vis, np.complex64)):
+        dev = accel.DeviceArray(ctx, a.shape, dt)
+        dev.set(q, a)
+        d.append(dev)
+    ident = np.identity(4, np.complex64)
+    coll.add(d[0], d[1], d[2], None, None, ident, None)
+    with pytest.raises(ValueError):
+        coll.add(uvw, weights[:, :3], vis, None, None, ident, None)
+    with pytest.raises(ValueError):
+        coll.add(uvw, weights, vis, np.zeros(4, np.float32), None, ident, None)
+    with pytest.raises(ValueError):
+        coll.add(uvw, weights, vis, None, None, np.identity(3, np.complex64), None)
+    coll.close()
+    with pytest.raises(RuntimeError):
+        coll.add(uvw, weights, vis, None, None, ident, None)
+    reader = coll.reader()
+    assert [reader.len(0, 0), reader.len(1, 0)] == [2, 3]
+    with pytest.raises(ValueError):
+        list(reader.iter_slice_device(0, 0, 65))
+    chunks = list(reader.iter_slice_device(1, 0, 2))
+    assert [c.num_vis for c in chunks] == [2, 1]
+    assert chunks[1].uv.shape == (2, 4) and chunks[1].vis.shape == (2, 4)
+    np.testing.assert_array_equal(chunks[0].uv.get(q)[:, :2], expected[1]['uv'][:2])
+
+
+def test_full_size_buffer():
+    """One reference-sized buffer (vis_block = 1 048 576) of a synthetic track, 4 -> 4
+    polarizations, against the C restatement; and the store grows across add() calls."""
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    t = np.arange(n, dtype=np.float64)
+    bl = rng.uniform(-2000, 2000, (n // 512 + 1, 3))
+    ph = (t % 512) * 2e-5
+    b = bl[(t // 512).astype(np.int64)]
+    uvw = np.stack([b[:, 0] * np.cos(ph) + b[:, 1] * np.sin(ph),
+                    -b[:, 0] * np.sin(ph) + b[:, 1] * np.cos(ph), b[:, 2]], axis=1).astype(np.float32)
+    weights = rng.uniform(0.5, 2, (1, n, 4)).astype(np.float32)
+    weights[0, rng.random(n) < 0.03, 1] = 0
+    vis = (rng.normal(size=(1, n, 4)) + 1j * rng.normal(size=(1, n, 4))).astype(np.complex64)
+    configs = [dict(max_w=2000.0, w_slices=3, w_planes=32, oversample=8, cell_size=2.5)]
+    stokes = np.array([[1, 0, 0, 1], [0, 1, 1, 0], [0, -1j, 1j, 0], [1, 0, 0, -1]], np.complex64)
+    batch = (uvw, weights, vis, None, None, stokes, None)
+    coll = _collect_device(configs, 4, n, [batch, batch])
+    ref = orc.VisibilityCollector(configs, 4, n)
+    ref.add(*batch)
+    ref.add(*batch)
+    assert ref.num_output < 0.7 * ref.num_input       # the tracks really merge
+    _compare(coll, ref, configs, True, 4)
+
+
+@pytest.mark.parametrize('name', list(gi.E2E_CONFIGS))
+def test_store_driven_channel_vs_golden(golden, name):
+    """Raw uvw / vis / weights -> device preprocessor -> HBM-resident store -> the major-cycle
+    driver (katsdpimager_amd.frontend.process_channel, zero-copy chunks) against the G9 golden
+    of the reference's ImagingHost, and against the same driver fed through the host setters."""
+    from helpers import make_params, kernel_taper, tapered_relerr, relerr
+    from katsdpimager_amd import frontend, imaging, parameters, preprocess, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS[name]
+    g = golden('g9_e2e_' + name)
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType(c['weight_type']), c['robustness'])
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    uvw, vis, weights = gi.e2e_raw(c)
+    n = len(uvw)
+    coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], max(n, c['vis_block']))
+    coll.add(uvw, weights[None], vis[None, :, None].astype(np.complex64), None, None,
+             np.ones((1, 1), np.complex64), None)
+    coll.close()
+    reader = coll.reader()
+    # the store holds exactly the records the goldens were generated from
+    data = gi.e2e_inputs(c)
+    for s, rec in enumerate(data['slices']):
+        got = _read(reader, 0, s, None, coll.store_dtype)
+        np.testing.assert_array_equal(got.uv, rec.uv)
+        np.testing.assert_array_equal(got.sub_uv, rec.sub_uv)
+        np.testing.assert_array_equal(got.w_plane, rec.w_plane)
+        np.testing.assert_array_equal(np.asarray(got.weights), rec.weights)
+        np.testing.assert_array_equal(np.ascontiguousarray(got.vis).view(np.float32),
+                                      np.ascontiguousarray(rec.vis).view(np.float32))
+
+    class HostReader:
+        """iter_slice only: forces the facade's host setters."""
+        num_channels = 1
+
+        def num_w_slices(self, channel):
+            return reader.num_w_slices(channel)
+
+        def len(self, channel, w_slice):
+            return reader.len(channel, w_slice)
+
+        def iter_slice(self, channel, w_slice, block_size=None):
+            return reader.iter_slice(channel, w_slice, block_size)
+
+    results = []
+    for rd, batched in ((reader, True), (HostReader(), False)):
+        template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
+        im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'])
+        im.ensure_all_bound()
+        stats = frontend.process_channel(rd, 0, im, ip, gp, cp, wp.weight_type, c['vis_block'],
+                                         c['major'], c['degrid'], batched_clean=batched)
+        results.append((stats, im.get_buffer('dirty'), im.get_buffer('model'),
+                        dict(im._model_components)))
+    (sa, da, ma, ca), (sb, db, mb, cb) = results
+    assert sa['psf_patch'] == sb['psf_patch'] == tuple(g['psf_patch'])
+    assert sa['minor'] == sb['minor'] and sa['major'] == sb['major'] == c['major']
+    assert sorted(ca) == sorted(cb)                       # same components, bit-exact positions
+    G = c['pixels']
+    taper = kernel_taper(c)
+    inner = np.s_[:, G // 8:-G // 8, G // 8:-G // 8]
+    # float atomics make two runs differ in the last bits; the taper division amplifies that at
+    # the image edge (see helpers.tapered_relerr)
+    assert tapered_relerr(da, db, taper) < 1e-5 and relerr(da[inner], db[inner]) < 1e-4
+    assert relerr(ma, mb) < 1e-5
+    # against the reference's host pipeline
+    np.testing.assert_array_equal(np.array(sorted(ca), np.int64).reshape(-1, 2), g['component_pos'])
+    assert tapered_relerr(da, g['dirty_final'], taper) < 2e-4
+    assert relerr(da[inner], g['dirty_final'][inner]) < 1e-3
+    assert relerr(ma, g['model_final']) < 2e-4
+    np.testing.assert_allclose(sa['peaks'][0], g['peak_values'][0], rtol=1e-4)
+    # the reference counts minor cycles like the goldens' n_minor (first cycle + loop)
+    assert sa['major'] == len(g['n_minor'])

@@ -90,6 +90,7 @@ def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
     u = u.to(torch.float32)
     v = v.to(torch.float32)
     w = w.to(torch.float32)
+    obs.uvw = torch.stack([u, v, w], dim=1).contiguous()      # raw metres, loader order
     flip = w < 0
     u = torch.where(flip, -u, u)
     v = torch.where(flip, -v, v)
