@@ -258,6 +258,21 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     q.finish()
     out['grid_to_image_ms'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
 
+    # restoring-beam convolution of one polarization plane (R2C + Gaussian + C2R, beam.py:351-398)
+    from katsdpimager_amd import beam
+    conv = beam.ConvolveBeamTemplate(ctx, (G, G), np.float32).instantiate(q)
+    conv.beam = beam.Beam(1.0, 2.5, 1.8, 0.4)
+    conv.ensure_all_bound()
+    conv.buffer('image').zero(q)
+    conv()
+    q.finish()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        conv()
+    q.finish()
+    out['convolve_beam_ms'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    del conv
+
     # CLEAN: dirty = 200 point sources (x) PSF + noise, patch from psf_patch
     dirty = g2i.buffer('image')
     img = dirty.get(q)

@@ -161,6 +161,20 @@ int kimg_fft_plan_create(void **plan, int size_y, int size_x);
 int kimg_fft_exec(void *plan, void *layer, int direction, void *stream);
 int kimg_fft_plan_destroy(void *plan);
 
+/* Restoring-beam convolution (beam.py:204-398: FourierBeam._run :283-311 + fourier_beam.mako,
+ * ConvolveBeam :351-398 = R2C FFT, multiply, C2R FFT), one polarization plane at a time.
+ *   kimg_rfft_*: out-of-place real <-> half-complex 2-D plans; image float32 [H][W] dense,
+ *       fourier complex64 [H][W/2+1] dense; direction -1 = R2C forward, +1 = C2R inverse
+ *       (unnormalised; the C2R transform overwrites `fourier`).
+ *   kimg_fourier_beam: data[y][x] *= amplitude * exp((a v + b u) v + c u u), u = x,
+ *       v = y < H/2 ? y : y - H  (the caller folds 1/(H W) and the axis scaling into
+ *       amplitude, a, b, c exactly as beam.py:287-299).  width = W/2+1 columns. */
+int kimg_rfft_plan_create(void **plan, int height, int width);
+int kimg_rfft_exec(void *plan, float *image, void *fourier, int direction, void *stream);
+int kimg_rfft_plan_destroy(void *plan);
+int kimg_fourier_beam(void *data, int64_t row_stride, int width, int height, float amplitude,
+                      float a, float b, float c, void *stream);
+
 /* ---- image-plane streams: image.py:351-367, :439-458, :539-558 (+ scale.mako,
  * add_image.mako, apply_primary_beam.mako).  scale_host: P floats on the HOST. */
 int kimg_scale(float *image, int64_t row_stride, int64_t pol_stride, int width, int height,

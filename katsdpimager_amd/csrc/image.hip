@@ -232,3 +232,38 @@ extern "C" int kimg_apply_primary_beam(float *image, int64_t row_stride, int64_t
         threshold, replacement);
     return kimg_launch_status();
 }
+
+// ---- restoring beam in the Fourier domain: beam.py:283-311 + fourier_beam.mako ----------
+namespace {
+__global__ __launch_bounds__(256) void fourier_beam_kernel(
+    float2 *__restrict__ data, int64_t stride, float amplitude, float a, float b, float c,
+    int width, int height)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= width)
+        return;
+    float u = (float) x;                 // only the non-negative half of this axis is stored
+    float v = (float) ((y * 2 >= height) ? y - height : y);
+    float power = (a * v + b * u) * v + c * u * u;
+    float ft = amplitude * expf(power);
+    int64_t addr = (int64_t) y * stride + x;
+    float2 value = data[addr];
+    value.x *= ft;
+    value.y *= ft;
+    data[addr] = value;
+}
+}  // namespace
+
+extern "C" int kimg_fourier_beam(void *data, int64_t row_stride, int width, int height,
+                                 float amplitude, float a, float b, float c, void *stream)
+{
+    KIMG_CHECK_ARG(width >= 0 && height >= 0 && row_stride >= width);
+    if (width == 0 || height == 0)
+        return 0;
+    KIMG_CHECK_ARG(data != nullptr && height <= 65535);
+    dim3 grid(kimg_divup(width, 256), height);
+    fourier_beam_kernel<<<grid, 256, 0, (hipStream_t) stream>>>(
+        static_cast<float2 *>(data), row_stride, amplitude, a, b, c, width, height);
+    return kimg_launch_status();
+}

@@ -680,3 +680,30 @@ class Clean:
         tx1 = min(-(-(x1 - bp) // ts), self._tile_max.shape[1])
         self._update_tiles(ty0, tx0, ty1, tx1)
         return peak_value, tuple(int(v) for v in peak_pos), model_pixel
+
+
+# --------------------------------------------------------------------------
+# beam.py:158-201   restoring-beam convolution
+# --------------------------------------------------------------------------
+def beam_covariance_sqrt(x_stddev, y_stddev, theta):
+    """beam.py:158-168: M = R diag(sx, sy) R^T."""
+    c, s = np.cos(theta), np.sin(theta)
+    Q = np.array([[c, -s], [s, c]])
+    return Q @ np.diag([x_stddev, y_stddev]) @ Q.T
+
+
+def convolve_beam(model, amplitude, x_stddev, y_stddev, theta):
+    """beam.py:172-201: multiply the FFT of every polarization plane by the analytic transform
+    2 pi A |det M| exp(-2 pi^2 |M k|^2) of the Gaussian beam and transform back (wraps)."""
+    model = np.asarray(model)
+    out = np.empty_like(model)
+    model_ft = np.fft.fftn(model, axes=[1, 2])
+    M = beam_covariance_sqrt(x_stddev, y_stddev, theta)
+    amp = 2 * np.pi * amplitude * np.abs(np.linalg.det(M))
+    u = np.fft.fftfreq(model.shape[1])
+    v = np.fft.fftfreq(model.shape[2])
+    coords = np.stack(np.meshgrid(u, v, indexing='ij'), axis=-1)
+    rotated = np.inner(coords, M)
+    beam_ft = amp * np.exp(-2.0 * np.pi ** 2 * np.sum(rotated ** 2, axis=-1))
+    out[:] = np.fft.ifftn(model_ft * beam_ft[np.newaxis, ...], axes=[1, 2]).real
+    return out

@@ -440,3 +440,26 @@ def run_major_cycle(im, c, data, host=False):
     out['dirty_final'] = np.array(im.get_buffer('dirty'))
     out['model_final'] = np.array(im.get_buffer('model'))
     return out
+
+
+# --------------------------------------------------------------------------
+# G10: restoring-beam convolution (beam.py:172-201)
+# --------------------------------------------------------------------------
+def beam_cases():
+    """(name, model float32 [P][H][W], beam dict) -- the first is test_beam.py:34-43."""
+    cases = []
+    model = np.zeros((4, 128, 128), np.float32)
+    model[0, 32, 80] = 1.0
+    model[0, 100, 40] = 2.0
+    model[1, 50, 60] = 3.0
+    model[2, 64, 64] = 4.0
+    model[2, 80, 64] = 3.0
+    cases.append(('testbeam', model, dict(amplitude=3.5, x_stddev=2.0, y_stddev=5.0, theta=1.0)))
+    rs = np.random.RandomState(21)
+    model = np.zeros((2, 96, 160), np.float32)
+    for _ in range(40):
+        model[rs.randint(2), rs.randint(96), rs.randint(160)] += rs.uniform(-1, 2)
+    cases.append(('rect', model, dict(amplitude=1.0, x_stddev=3.0, y_stddev=1.5, theta=-0.4)))
+    model = rs.standard_normal((1, 256, 256)).astype(np.float32)
+    cases.append(('dense', model, dict(amplitude=0.7, x_stddev=1.2, y_stddev=4.1, theta=2.5)))
+    return cases

@@ -678,3 +678,64 @@ def run_batched(im, c, data):
                 self._queue = list(vals) + [None]
             return self._queue.pop(0)
     return gi.run_major_cycle(Batched(im), c, data, host=False)
+
+
+# ---- restoring beam (beam.py:204-398) ---------------------------------------
+@pytest.mark.parametrize('case', range(3))
+def test_convolve_beam_vs_golden(golden, case):
+    """ConvolveBeam (R2C rocFFT -> fourier_beam kernel -> C2R) per polarization against the
+    reference's host convolve_beam (G10) and the restatement; tolerance as test_beam.py:62
+    (rtol 1e-5, atol 1e-5 of the peak)."""
+    from katsdpimager_amd import beam
+    ctx, q = context_queue()
+    name, model, b = gi.beam_cases()[case]
+    g = golden('g10_beam_' + name)
+    bm = beam.Beam(b['amplitude'], b['x_stddev'], b['y_stddev'], b['theta'])
+    np.testing.assert_allclose(beam.beam_covariance_sqrt(bm), g['cov_sqrt'], rtol=1e-13)
+    template = beam.ConvolveBeamTemplate(ctx, model.shape[1:], model.dtype)
+    fn = template.instantiate(q)
+    with pytest.raises(ValueError):
+        fn()                                    # beam not set (beam.py:284-285)
+    fn.beam = bm
+    fn.ensure_all_bound()
+    peak = np.abs(g['restored']).max()
+    ref = orc.convolve_beam(model, **b)
+    for pol in range(model.shape[0]):
+        fn.buffer('image').set(q, model[pol])
+        fn()
+        actual = fn.buffer('image').get(q)
+        np.testing.assert_allclose(actual, g['restored'][pol], rtol=1e-5, atol=1e-5 * peak)
+        np.testing.assert_allclose(actual, ref[pol], rtol=1e-5, atol=1e-5 * peak)
+
+
+def test_restore_step():
+    """frontend.py:623-641 on the facade buffers: model (x) beam + residuals."""
+    from katsdpimager_amd import beam, imaging, parameters, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS['degrid']
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType(c['weight_type']), c['robustness'])
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    im = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp).instantiate(
+        q, ip, gp, c['vis_block'], 0, c['major'])
+    im.ensure_all_bound()
+    G = c['pixels']
+    rs = np.random.RandomState(5)
+    model = np.zeros((1, G, G), np.float32)
+    for _ in range(30):
+        model[0, rs.randint(G), rs.randint(G)] += rs.uniform(0.1, 2)
+    resid = (0.01 * rs.standard_normal((1, G, G))).astype(np.float32)
+    im.set_buffer('model', model)
+    im.set_buffer('dirty', resid)
+    b = dict(amplitude=1.0, x_stddev=2.5, y_stddev=1.7, theta=0.3)
+    conv = beam.restore(im, beam.Beam(**b))
+    expected = orc.convolve_beam(model, **b) + resid
+    got = im.get_buffer('dirty')
+    np.testing.assert_allclose(got, expected, rtol=1e-5, atol=1e-5 * np.abs(expected).max())
+    # the operator is reusable
+    im.set_buffer('model', model)
+    im.set_buffer('dirty', resid)
+    assert beam.restore(im, beam.Beam(**b), conv) is conv
+    np.testing.assert_allclose(im.get_buffer('dirty'), expected, rtol=1e-5,
+                               atol=1e-5 * np.abs(expected).max())

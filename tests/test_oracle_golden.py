@@ -159,3 +159,15 @@ def test_g8_psf_patch_noise(golden):
         assert tuple(g['patch%d' % i]) == orc.psf_patch(psf, thr, lim)
     for i, (img, border) in enumerate(gi.noise_cases()):
         assert orc.noise_est(img, border) == g['noise%d' % i]
+
+
+@pytest.mark.parametrize('case', range(3))
+def test_g10_convolve_beam(golden, case):
+    """beam.convolve_beam (beam.py:172-201) vs the restatement."""
+    name, model, b = gi.beam_cases()[case]
+    g = golden('g10_beam_' + name)
+    np.testing.assert_allclose(orc.beam_covariance_sqrt(b['x_stddev'], b['y_stddev'], b['theta']),
+                               g['cov_sqrt'], rtol=1e-13)
+    out = orc.convolve_beam(model, **b)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, g['restored'], rtol=0, atol=1e-6 * np.abs(g['restored']).max())

@@ -335,3 +335,22 @@ def test_preprocess_buffer_boundary():
         coll = orc.VisibilityCollector([conf], 1, cap)
         coll.add(uvw, weights, vis, None, None, np.ones((1, 1), np.complex64), None)
         np.testing.assert_array_equal(coll.slice_arrays(0, 0)['weights'][:, 0], lens)
+
+
+def test_convolve_beam_sampled_reference():
+    """test_beam.py:13-46: the analytic-transform convolution equals a direct convolution with
+    the sampled Gaussian2D (rtol 1e-5, atol 1e-5) on the reference's own test case."""
+    import scipy.signal
+    name, model, b = gi.beam_cases()[0]
+    hh, hw = model.shape[1] // 2, model.shape[2] // 2
+    x, y = np.meshgrid(np.arange(-hh + 1, hh), np.arange(-hw + 1, hw), indexing='ij')
+    sx, sy, th = b['x_stddev'], b['y_stddev'], b['theta']
+    # astropy.modeling.models.Gaussian2D.evaluate
+    ca = np.cos(th) ** 2 / (2 * sx ** 2) + np.sin(th) ** 2 / (2 * sy ** 2)
+    cb = np.sin(2 * th) / (2 * sx ** 2) - np.sin(2 * th) / (2 * sy ** 2)
+    cc = np.sin(th) ** 2 / (2 * sx ** 2) + np.cos(th) ** 2 / (2 * sy ** 2)
+    beam_pixels = b['amplitude'] * np.exp(-(ca * x * x + cb * x * y + cc * y * y))
+    expected = np.stack([scipy.signal.fftconvolve(model[p], beam_pixels, 'same')
+                         for p in range(model.shape[0])])
+    actual = orc.convolve_beam(model, **b)
+    np.testing.assert_allclose(expected, actual, rtol=1e-5, atol=1e-5)
