@@ -219,26 +219,40 @@ __global__ __launch_bounds__(256) void pp_head_kernel(
     head[k] = h;
 }
 
-// The owner of each head sums its run in arrival order and writes the merged record.
-// With one w-slice the record goes straight to its final place.
+// hidx[o] = compacted index of the head of output run o.
+__global__ __launch_bounds__(256) void pp_headidx_kernel(
+    int64_t n, const int *__restrict__ head, const int *__restrict__ opos, int *__restrict__ hidx)
+{
+    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && head[k])
+        hidx[opos[k]] = (int) k;
+}
+
+// One thread per OUTPUT record: it sums its run of adjacent equal keys in arrival order
+// (:356-360, bit-identical to the host loop) and writes the merged record.  With one w-slice
+// the record goes straight to its final place.
 template <int P>
 __global__ __launch_bounds__(256) void pp_merge_kernel(
     int64_t n, const int *__restrict__ nv_valid, const int *__restrict__ nv_pos,
     const int *__restrict__ cidx, const int *__restrict__ head, const int *__restrict__ opos,
+    const int *__restrict__ hidx,
     const short *__restrict__ key, const float *__restrict__ w, const float2 *__restrict__ vis,
     int single_slice,
     short *__restrict__ m_uv, short *__restrict__ m_wplane, float *__restrict__ m_w,
     float2 *__restrict__ m_vis, unsigned short *__restrict__ skey,
     unsigned long long *__restrict__ counts)
 {
-    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
+    int64_t o = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n)
         return;
-    int nv = nv_pos[n - 1] + nv_valid[n - 1];
-    if (single_slice && k == 0)
-        counts[0] = (nv > 0) ? (unsigned long long) (opos[n - 1] + head[n - 1]) : 0ull;
-    if (k >= nv || !head[k])
+    const int nv = nv_pos[n - 1] + nv_valid[n - 1];
+    const int m = nv > 0 ? opos[n - 1] + head[n - 1] : 0;
+    if (single_slice && o == 0)
+        counts[0] = (unsigned long long) m;
+    if (o >= m)
         return;
+    const int64_t k = hidx[o];
+    const int64_t k_end = (o + 1 < m) ? hidx[o + 1] : nv;
     int64_t e = cidx[k];
     const int *kp = reinterpret_cast<const int *>(key + 6 * e);
     int k01 = kp[0], k23 = kp[1], k45 = kp[2];
@@ -249,7 +263,34 @@ __global__ __launch_bounds__(256) void pp_merge_kernel(
         aw[p] = w[e * P + p];
         av[p] = vis[e * P + p];
     }
-    for (int64_t j = k + 1; j < nv && !head[j]; j++) {       // :356-360
+    // Long runs (slowly moving short baselines) are latency chains: fetch UNROLL elements
+    // ahead, then add them in arrival order.
+    constexpr int UNROLL = 8;
+    int64_t j = k + 1;
+    for (; j + UNROLL <= k_end; j += UNROLL) {
+        int64_t f[UNROLL];
+        float2 tv[UNROLL][P];
+        float tw[UNROLL][P];
+#pragma unroll
+        for (int i = 0; i < UNROLL; i++)
+            f[i] = cidx[j + i];
+#pragma unroll
+        for (int i = 0; i < UNROLL; i++)
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                tv[i][p] = vis[f[i] * P + p];
+                tw[i][p] = w[f[i] * P + p];
+            }
+#pragma unroll
+        for (int i = 0; i < UNROLL; i++)
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                av[p].x += tv[i][p].x;
+                av[p].y += tv[i][p].y;
+                aw[p] += tw[i][p];
+            }
+    }
+    for (; j < k_end; j++) {
         int64_t f = cidx[j];
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -259,7 +300,6 @@ __global__ __launch_bounds__(256) void pp_merge_kernel(
             aw[p] += w[f * P + p];
         }
     }
-    int64_t o = opos[k];
     int *uv32 = reinterpret_cast<int *>(m_uv + 4 * o);
     uv32[0] = k01;
     uv32[1] = k23;
@@ -269,11 +309,32 @@ __global__ __launch_bounds__(256) void pp_merge_kernel(
         m_w[o * P + p] = aw[p];
         m_vis[o * P + p] = av[p];
     }
-    if (!single_slice) {
-        int slice = k45 >> 16;
-        skey[o] = (unsigned short) slice;
-        atomicAdd(&counts[slice], 1ull);
-    }
+    if (!single_slice)
+        skey[o] = (unsigned short) (k45 >> 16);
+}
+
+// Run length per w-slice from the sorted slice ids (a same-address atomic per record would
+// serialise in L2): counts[s] = lower_bound(s + 1) - lower_bound(s).  Unused tail entries
+// carry the sentinel w_slices and sort behind everything.
+__global__ void pp_slice_counts_kernel(
+    int64_t n, const unsigned short *__restrict__ sorted, int w_slices,
+    unsigned long long *__restrict__ counts)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= w_slices)
+        return;
+    auto lower_bound = [&](int value) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int) sorted[mid] < value)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    counts[s] = (unsigned long long) (lower_bound(s + 1) - lower_bound(s));
 }
 
 // Apply the stable slice order: output t takes merged record perm[t].
@@ -314,7 +375,7 @@ __global__ __launch_bounds__(256) void pp_real_to_complex_kernel(
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct pp_workspace {
-    int *valid, *pos, *cidx, *head, *opos, *sval_in, *sval_out;
+    int *valid, *pos, *cidx, *head, *opos, *hidx, *sval_in, *sval_out;
     unsigned short *skey_in, *skey_out;
     short *m_uv, *m_wplane;
     float *m_w;
@@ -355,6 +416,7 @@ hipError_t layout_workspace(int64_t n, int P, char *base, pp_workspace &ws)
     ws.cidx = (int *) take(ni);
     ws.head = (int *) take(ni);
     ws.opos = (int *) take(ni);
+    ws.hidx = (int *) take(ni);
     ws.sval_in = (int *) take(ni);
     ws.sval_out = (int *) take(ni);
     ws.skey_in = (unsigned short *) take((size_t) n * 2);
@@ -408,8 +470,9 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
     pp_head_kernel<<<blocks, 256, 0, stream>>>(n, ws.valid, ws.pos, ws.cidx, key, ws.head);
     cb = ws.cub_bytes;
     KIMG_HIP(hipcub::DeviceScan::ExclusiveSum(ws.cub, cb, ws.head, ws.opos, (int) n, stream));
+    pp_headidx_kernel<<<blocks, 256, 0, stream>>>(n, ws.head, ws.opos, ws.hidx);
     pp_merge_kernel<P><<<blocks, 256, 0, stream>>>(
-        n, ws.valid, ws.pos, ws.cidx, ws.head, ws.opos, key, w, vis, single,
+        n, ws.valid, ws.pos, ws.cidx, ws.head, ws.opos, ws.hidx, key, w, vis, single,
         single ? out_uv : ws.m_uv, single ? out_wplane : ws.m_wplane, single ? out_w : ws.m_w,
         single ? out_vis : ws.m_vis, ws.skey_in, counts);
     if (!single) {
@@ -417,6 +480,8 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
         KIMG_HIP(hipcub::DeviceRadixSort::SortPairs(ws.cub, cb, ws.skey_in, ws.skey_out, ws.sval_in,
                                                     ws.sval_out, (int) n, 0, slice_bits(w_slices),
                                                     stream));
+        pp_slice_counts_kernel<<<kimg_divup(w_slices, 64), 64, 0, stream>>>(n, ws.skey_out, w_slices,
+                                                                           counts);
         pp_gather_kernel<P><<<blocks, 256, 0, stream>>>(
             n, ws.head, ws.opos, ws.sval_out, ws.m_uv, ws.m_wplane, ws.m_w, ws.m_vis,
             out_uv, out_wplane, out_w, out_vis);

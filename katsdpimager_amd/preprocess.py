@@ -159,13 +159,20 @@ class VisibilityCollectorDevice:
         self._key = accel.DeviceArray(ctx, (B, 6), np.int16)
         self._cw = accel.DeviceArray(ctx, (B, P), np.float32)
         self._cvis = accel.DeviceArray(ctx, (B, P), np.complex64)
-        self._out = dict(
-            uv=accel.DeviceArray(ctx, (B, 4), np.int16),
-            w_plane=accel.DeviceArray(ctx, (B,), np.int16),
-            weights=accel.DeviceArray(ctx, (B, P), np.float32),
-            vis=accel.DeviceArray(ctx, (B, P), np.complex64))
+        # two sets of compress outputs + slice counts: the host reads the counts of buffer i
+        # (needed to place its records) while the device already works on buffer i + 1
         max_slices = max(gp.w_slices for gp in self.grid_parameters)
-        self._counts = accel.DeviceArray(ctx, (max_slices,), np.int64)
+        torch = accel._torch()
+        self._sets = []
+        for _ in range(2):
+            out = dict(
+                uv=accel.DeviceArray(ctx, (B, 4), np.int16),
+                w_plane=accel.DeviceArray(ctx, (B,), np.int16),
+                weights=accel.DeviceArray(ctx, (B, P), np.float32),
+                vis=accel.DeviceArray(ctx, (B, P), np.complex64))
+            counts = accel.DeviceArray(ctx, (max_slices,), np.int64)
+            host = torch.empty((max_slices,), dtype=torch.int64).pin_memory()
+            self._sets.append((out, counts, host, torch.cuda.Event()))
         self._ws_bytes = int(self._lib.kimg_preprocess_workspace_bytes(B, P))
         if self._ws_bytes == 0:
             raise ValueError('unsupported buffer_size / polarizations')
@@ -218,13 +225,31 @@ class VisibilityCollectorDevice:
         circular = self._matrix(mueller_circular, (4, Q))
         stream = self.queue.handle
         f32 = np.dtype(np.float32).itemsize
+        torch = accel._torch()
+        pending = None
+        step = 0
+
+        def retire(p):
+            """Place the records of a finished buffer (needs its slice counts on the host)."""
+            stores, w_slices, (out, _, host, event) = p
+            event.synchronize()
+            pos = 0
+            for s in range(w_slices):
+                c = int(host[s])
+                if c:
+                    stores[s].append(out, pos, c)
+                    pos += c
+            self.num_output += pos
+
         for ch in range(C):
             gp = self.grid_parameters[ch]
             cell = float(self.image_parameters[ch].cell_size)
-            stores = self._stores[ch]
             for i0 in range(0, N, self.buffer_size):
                 n = min(N, i0 + self.buffer_size) - i0
                 row = (ch * N + i0) * Q
+                cur = self._sets[step % 2]
+                step += 1
+                out, counts, host, event = cur
                 check(self._lib.kimg_preprocess_convert(
                     P, Q, n, d_uvw.ptr + i0 * 3 * f32, d_weights.ptr + row * f32,
                     d_vis.ptr + row * 2 * f32,
@@ -235,17 +260,16 @@ class VisibilityCollectorDevice:
                     self._key.ptr, self._cw.ptr, self._cvis.ptr, stream), 'kimg_preprocess_convert')
                 check(self._lib.kimg_preprocess_compress(
                     P, n, gp.w_slices, self._key.ptr, self._cw.ptr, self._cvis.ptr,
-                    self._out['uv'].ptr, self._out['w_plane'].ptr, self._out['weights'].ptr,
-                    self._out['vis'].ptr, self._counts.ptr, self._ws.ptr, self._ws_bytes, stream),
-                    'kimg_preprocess_compress')
-                counts = self._counts.get(self.queue)[:gp.w_slices]      # synchronises
-                pos = 0
-                for s, c in enumerate(counts):
-                    c = int(c)
-                    if c:
-                        stores[s].append(self._out, pos, c)
-                        pos += c
-                self.num_output += pos
+                    out['uv'].ptr, out['w_plane'].ptr, out['weights'].ptr, out['vis'].ptr,
+                    counts.ptr, self._ws.ptr, self._ws_bytes, stream), 'kimg_preprocess_compress')
+                with torch.cuda.stream(self.queue.stream):
+                    host.copy_(counts.tensor, non_blocking=True)
+                    event.record(self.queue.stream)
+                if pending is not None:
+                    retire(pending)
+                pending = (self._stores[ch], gp.w_slices, cur)
+        if pending is not None:
+            retire(pending)
         self.num_input += C * N
         # the staging arrays of this call may be freed once the stream has consumed them
         self.queue.finish()
