@@ -65,15 +65,22 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # KIMG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks share devices); the driver's runs use the default, RCCL with one GPU per rank.
+    backend = os.environ.get('KIMG_DIST_BACKEND', 'nccl')
+    device_index = local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch with torchrun'.format(
             args.gpus, world))
     _lib.lib()      # fail loudly if the HIP extension is missing
-    ctx = accel.Context(local_rank)
+    ctx = accel.Context(device_index)
     q = ctx.create_command_queue()
     dev = ctx.device
     P, K, W, G = args.polarizations, args.kernel_width, args.w_planes, args.pixels
@@ -143,7 +150,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == 'nccl':
+                dist.barrier(device_ids=[device_index])
+            else:
+                dist.barrier()
 
     for _ in range(args.warmup):
         step()

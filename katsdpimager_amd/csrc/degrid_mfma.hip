@@ -89,10 +89,31 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     int4 *recs = reinterpret_cast<int4 *>(rec_base) + wib * 64;
 
     // Stage the kernel table: rows zero-padded to 32 taps, stored twice, stride 65 taps.
-    for (int idx = threadIdx.x; idx < table_rows * TAPS; idx += NW * 64) {
-        const int row = idx / TAPS, t = idx & 31;
-        const float2 v = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
-        *reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + (idx % TAPS) * 8) = v;
+    // A thread issues all loads of a round before its first LDS write (one L2 round trip per
+    // round instead of one per element).
+    {
+        constexpr int STG = 8;
+        const int total = table_rows * 32;
+        for (int base = threadIdx.x; base < total; base += NW * 64 * STG) {
+            float2 v[STG];
+#pragma unroll
+            for (int i = 0; i < STG; i++) {
+                const int idx = base + i * NW * 64;
+                const int row = idx >> 5, t = idx & 31;
+                v[i] = (idx < total && t < K) ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int i = 0; i < STG; i++) {
+                const int idx = base + i * NW * 64;
+                const int row = idx >> 5, t = idx & 31;
+                if (idx < total) {
+                    float2 *dst = reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + t * 8);
+                    dst[0] = v[i];
+                    if (TAPS == 64)
+                        dst[32] = v[i];
+                }
+            }
+        }
     }
     __syncthreads();
 

@@ -237,13 +237,29 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     if ((K & 1) == 0) {
         const float4 *kern2 = reinterpret_cast<const float4 *>(kern);
         float4 *table2 = reinterpret_cast<float4 *>(smem);
-        for (int idx = threadIdx.x; idx < table_rows * 16; idx += NW * 64) {
-            const int row = idx >> 4, t2 = idx & 15;
-            const float4 v = 2 * t2 < K ? kern2[((int64_t) row * K >> 1) + t2]
-                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            table2[row * (ROW / 2) + t2] = v;
-            if (ROW == 64)
-                table2[row * (ROW / 2) + 16 + t2] = v;
+        // all of a thread's loads are issued before its first LDS write: one L2 round trip
+        // instead of one per iteration
+        constexpr int STG = 6;
+        const int total = table_rows * 16;
+        for (int base = threadIdx.x; base < total; base += NW * 64 * STG) {
+            float4 v[STG];
+#pragma unroll
+            for (int i = 0; i < STG; i++) {
+                const int idx = base + i * NW * 64;
+                const int row = idx >> 4, t2 = idx & 15;
+                v[i] = (idx < total && 2 * t2 < K) ? kern2[((int64_t) row * K >> 1) + t2]
+                                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int i = 0; i < STG; i++) {
+                const int idx = base + i * NW * 64;
+                const int row = idx >> 4, t2 = idx & 15;
+                if (idx < total) {
+                    table2[row * (ROW / 2) + t2] = v[i];
+                    if (ROW == 64)
+                        table2[row * (ROW / 2) + 16 + t2] = v[i];
+                }
+            }
         }
     } else {
         for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
