@@ -16,6 +16,9 @@ def main(out, tag):
     stats = glob.glob(os.path.join(out, 'stats', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         trim_stats.main(stats[0], os.path.join(out, tag + '_bench_kernel_stats.txt'))
+    stats = glob.glob(os.path.join(out, 'stats_full', '**', '*kernel_stats.csv'), recursive=True)
+    if stats:
+        trim_stats.main(stats[0], os.path.join(out, tag + '_bench_full_kernel_stats.txt'))
     agg = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(out, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
