@@ -353,15 +353,29 @@ __global__ __launch_bounds__(256) void abs_histogram_kernel(
     local[threadIdx.x] = 0;
     __syncthreads();
     const int shift = 8 * pass;
+    // Run-length accumulation: in the first pass (sign-less exponent byte) nearly every pixel
+    // of a noise-like image falls into the same two or three bins, and one LDS atomic per
+    // pixel would serialise the whole wave on them.
+    uint32_t run_bin = 0, run = 0;
     for (int p = 0; p < P; p++)
         for (int y = border + blockIdx.y; y < height - border; y += gridDim.y)
             for (int x = border + blockIdx.x * blockDim.x + threadIdx.x; x < width - border;
                  x += gridDim.x * blockDim.x) {
                 uint32_t key = __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
                                & 0x7fffffffu;
-                if (pass == 3 || (key >> (shift + 8)) == prefix)
-                    atomicAdd(&local[(key >> shift) & 255u], 1u);
+                if (pass == 3 || (key >> (shift + 8)) == prefix) {
+                    const uint32_t bin = (key >> shift) & 255u;
+                    if (bin != run_bin) {
+                        if (run)
+                            atomicAdd(&local[run_bin], run);
+                        run_bin = bin;
+                        run = 0;
+                    }
+                    run++;
+                }
             }
+    if (run)
+        atomicAdd(&local[run_bin], run);
     __syncthreads();
     if (local[threadIdx.x])
         atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
