@@ -144,3 +144,59 @@ def test_c4_full_stokes_checksum():
     g_generic = _grid_all(ctx, q, obs2, fn2)
     err = float((g - g_generic).abs().max() / g_generic.abs().max())
     assert err < 1e-5
+
+
+def _degrid_all(ctx, q, obs, template_args, model_grid, vis_block):
+    """vis = 0 - 1 * degrid(model_grid) over every chunk; returns the predicted visibilities."""
+    import torch
+    from katsdpimager_amd import accel, grid
+    ap, ip, gp = template_args
+    P = obs.vis.shape[1]
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, vis_block)
+    dg.bind(grid=model_grid)
+    ones = accel.DeviceArray(ctx, (vis_block, P), np.float32,
+                             tensor=torch.ones((vis_block, P), device=ctx.device))
+    dg.bind(weights=ones)
+    dg.ensure_all_bound()
+    n_full = obs.n_vis // vis_block * vis_block          # whole chunks only
+    out = torch.zeros((n_full, P), dtype=torch.complex64, device=ctx.device)
+    for start in range(0, n_full, vis_block):
+        sl = slice(start, start + vis_block)
+        dg.bind(uv=accel.DeviceArray(ctx, (vis_block, 4), np.int16, tensor=obs.uv[sl]),
+                w_plane=accel.DeviceArray(ctx, (vis_block,), np.int16, tensor=obs.w_plane[sl]),
+                vis=accel.DeviceArray(ctx, (vis_block, P), np.complex64, tensor=out[sl]))
+        dg.num_vis = vis_block
+        dg()
+    q.finish()
+    return -out, n_full
+
+
+@pytest.mark.parametrize('pixels,w_planes,P,n_vis,vis_block', [
+    (4096, 32, 1, 4 * 1048576, 1048576),          # BASELINE config 2 geometry
+    (8192, 64, 4, 2 * 524288, 524288)])           # BASELINE config 4 geometry
+def test_grid_degrid_adjoint(pixels, w_planes, P, n_vis, vis_block):
+    """Gridding (conjugated kernel, grid.py:1049-1050) and degridding (plain kernel,
+    grid.py:1150) are adjoint: <degrid(G), v> = <G, grid(v)> with <a, b> = sum conj(a) b, for any
+    model grid G and visibilities v.  Both sides at full size, inner products in float64."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel
+    ctx, q, obs, fn, wg = _setup(pixels, n_vis, w_planes, P, vis_block=vis_block)
+    wg.tensor.fill_(1.0)                                   # no density weights in the identity
+    ip, gp, ap = synth.make_parameters(obs, P, 28, degrid=True)
+    Gg = fn.slots['grid'].shape[1]
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(31)
+    G = torch.complex(torch.rand((P, Gg, Gg), generator=gen, device=ctx.device) - 0.5,
+                      torch.rand((P, Gg, Gg), generator=gen, device=ctx.device) - 0.5)
+    model_grid = accel.DeviceArray(ctx, (P, Gg, Gg), np.complex64, tensor=G)
+    pred, n_full = _degrid_all(ctx, q, obs, (ap, ip, gp), model_grid, vis_block)
+    assert n_full == n_vis
+    v = obs.vis[:n_full]
+    lhs = torch.sum(torch.conj(pred).to(torch.complex128) * v.to(torch.complex128), dim=0)
+    gridded = _grid_all(ctx, q, obs, fn)
+    rhs = torch.stack([torch.sum(torch.conj(G[p]).to(torch.complex128)
+                                 * gridded[p].to(torch.complex128)) for p in range(P)])
+    scale = float(torch.sum(pred.abs().to(torch.float64) * v.abs().to(torch.float64)))
+    err = float((lhs - rhs).abs().max()) / scale * P
+    assert float(pred.abs().max()) > 0 and err < 1e-6
