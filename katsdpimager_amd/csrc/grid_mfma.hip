@@ -160,19 +160,31 @@ __device__ inline int group8_max(int v)
     return v;
 }
 
-template <int P, int NW, int SUB, int ROW>
+// Kernel widths above 32 are gridded as 2 x 2 blocks of taps, one launch per block: the
+// launch handles row taps [tv0, tv0 + Kv) and column taps [tu0, tu0 + Ku) of the K-tap kernel
+// (each at most 32 wide), which is itself a gridding with a narrower kernel and a shifted
+// origin.  Off-diagonal blocks need different row and column taps, hence TWO tables in LDS.
+struct tap_split {
+    int K;              // full kernel width (row stride of the table in HBM, uv_bias)
+    int tv0, Kv;        // row (v) taps of this launch
+    int tu0, Ku;        // column (u) taps of this launch
+};
+
+template <int P, int NW, int SUB, int ROW, bool TWO>
 __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const float *__restrict__ weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float2 *__restrict__ vis, int64_t num_vis,
-    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block,
+    const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
     int p_total, int dbg)
 {
+    static_assert(!TWO || ROW == 32, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *table = reinterpret_cast<float2 *>(smem);                       // [W*OV][ROW]
     const int table_rows = W * OV;
-    unsigned char *rec_base = smem + (size_t) table_rows * ROW * sizeof(float2);
+    const int table_bytes = table_rows * ROW * (int) sizeof(float2);
+    const int u_table = TWO ? table_bytes : 0;           // byte offset of the column-tap table
+    unsigned char *rec_base = smem + (size_t) table_bytes * (TWO ? 2 : 1);
     // wave index: uniform by construction, but the compiler must be told (readfirstlane),
     // or every loop below is lowered to divergent (exec-masked) control flow
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -232,48 +244,55 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         load_raw(start + 64, r1);
     }
 
-    // Stage the kernel table: each row zero-padded from K to 32 taps (and stored twice when
-    // ROW == 64).  Two taps (16 bytes) per thread and iteration when K is even.
-    if ((K & 1) == 0) {
-        const float4 *kern2 = reinterpret_cast<const float4 *>(kern);
-        float4 *table2 = reinterpret_cast<float4 *>(smem);
-        // all of a thread's loads are issued before its first LDS write: one L2 round trip
-        // instead of one per iteration
-        constexpr int STG = 6;
-        const int total = table_rows * 16;
-        for (int base = threadIdx.x; base < total; base += NW * 64 * STG) {
-            float4 v[STG];
+    // Stage the kernel table(s): taps [tap0, tap0 + Kp) of every row, zero-padded to 32 taps
+    // (and stored twice when ROW == 64).  Two taps (16 bytes) per thread when alignment allows.
+    auto stage_table = [&](unsigned char *dst, int tap0, int Kp) __attribute__((always_inline)) {
+        if (((ts.K | tap0 | Kp) & 1) == 0) {
+            const float4 *kern2 = reinterpret_cast<const float4 *>(kern);
+            float4 *table2 = reinterpret_cast<float4 *>(dst);
+            // all of a thread's loads are issued before its first LDS write: one L2 round trip
+            // instead of one per iteration
+            constexpr int STG = 6;
+            const int total = table_rows * 16;
+            for (int base = threadIdx.x; base < total; base += NW * 64 * STG) {
+                float4 v[STG];
 #pragma unroll
-            for (int i = 0; i < STG; i++) {
-                const int idx = base + i * NW * 64;
-                const int row = idx >> 4, t2 = idx & 15;
-                v[i] = (idx < total && 2 * t2 < K) ? kern2[((int64_t) row * K >> 1) + t2]
-                                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
+                for (int i = 0; i < STG; i++) {
+                    const int idx = base + i * NW * 64;
+                    const int row = idx >> 4, t2 = idx & 15;
+                    v[i] = (idx < total && 2 * t2 < Kp)
+                               ? kern2[(((int64_t) row * ts.K + tap0) >> 1) + t2]
+                               : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
 #pragma unroll
-            for (int i = 0; i < STG; i++) {
-                const int idx = base + i * NW * 64;
-                const int row = idx >> 4, t2 = idx & 15;
-                if (idx < total) {
-                    table2[row * (ROW / 2) + t2] = v[i];
-                    if (ROW == 64)
-                        table2[row * (ROW / 2) + 16 + t2] = v[i];
+                for (int i = 0; i < STG; i++) {
+                    const int idx = base + i * NW * 64;
+                    const int row = idx >> 4, t2 = idx & 15;
+                    if (idx < total) {
+                        table2[row * (ROW / 2) + t2] = v[i];
+                        if (ROW == 64)
+                            table2[row * (ROW / 2) + 16 + t2] = v[i];
+                    }
                 }
             }
+        } else {
+            float2 *table = reinterpret_cast<float2 *>(dst);
+            for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
+                const int row = idx / ROW, t = idx & 31;
+                table[idx] = t < Kp ? kern[(int64_t) row * ts.K + tap0 + t] : make_float2(0.0f, 0.0f);
+            }
         }
-    } else {
-        for (int idx = threadIdx.x; idx < table_rows * ROW; idx += NW * 64) {
-            const int row = idx / ROW, t = idx & 31;
-            table[idx] = t < K ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
-        }
-    }
+    };
+    stage_table(smem, ts.tv0, ts.Kv);
+    if (TWO)
+        stage_table(smem + table_bytes, ts.tu0, ts.Ku);
     __syncthreads();
     if (!active)
         return;
     gather(start, r0);
 
-    const int uv_bias = (K - 1) / 2 - Gg / 2;           // grid.py:1038
-    const int S = WIN - K;                              // window slack
+    const int uv_bias = (ts.K - 1) / 2 - Gg / 2;        // grid.py:1038
+    const int Su = WIN - ts.Ku, Sv = WIN - ts.Kv;       // window slack along u and v
     const bool h = lane >= 32;                          // MFMA k index of this lane
     const int part = lane & 1;                          // 0: real part column, 1: imaginary
     // B operand: k=0 pairs with Re(a): (ku.re, -ku.im); k=1 with Im(a): (ku.im, ku.re).
@@ -297,18 +316,18 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     // Move the window so that [lo_u, hi_u] x [lo_v, hi_v] (first-tap coordinates) fits.
     auto fit_window = [&](int lo_u, int hi_u, int lo_v, int hi_v) __attribute__((always_inline)) {
         if (!have) {
-            Wu = lo_u - (S - (hi_u - lo_u)) / 2;
-            Wv = lo_v - (S - (hi_v - lo_v)) / 2;
+            Wu = lo_u - (Su - (hi_u - lo_u)) / 2;
+            Wv = lo_v - (Sv - (hi_v - lo_v)) / 2;
             have = true;
             return;
         }
-        const bool bad_u = lo_u < Wu || hi_u > Wu + S;
-        const bool bad_v = lo_v < Wv || hi_v > Wv + S;
+        const bool bad_u = lo_u < Wu || hi_u > Wu + Su;
+        const bool bad_v = lo_v < Wv || hi_v > Wv + Sv;
         if (!(bad_u || bad_v))
             return;
         // leave all the slack ahead in the direction of travel (tracks are smooth curves)
-        const int nWu = !bad_u ? Wu : (hi_u > Wu + S ? lo_u : hi_u - S);
-        const int nWv = !bad_v ? Wv : (hi_v > Wv + S ? lo_v : hi_v - S);
+        const int nWu = !bad_u ? Wu : (hi_u > Wu + Su ? lo_u : hi_u - Su);
+        const int nWv = !bad_v ? Wv : (hi_v > Wv + Sv ? lo_v : hi_v - Sv);
         const bool full = nWu - Wu >= WIN || Wu - nWu >= WIN || nWv - Wv >= WIN || Wv - nWv >= WIN;
         if (!(dbg & 2))
             flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane);
@@ -403,10 +422,10 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             const bool ok = coords_ok(b, r0);
             const int u = (short) (r0.uv.x & 0xffff), v = (short) (r0.uv.x >> 16);
             const int su = (short) (r0.uv.y & 0xffff), sv = (short) (r0.uv.y >> 16);
-            const int mu = u - uv_bias, mv = v - uv_bias;
+            const int mu = u - uv_bias + ts.tu0, mv = v - uv_bias + ts.tv0;
             // row byte offset (a multiple of ROW * 8) + tap byte offset (< 256)
             int2 r;
-            r.x = (ok ? (r0.wp * OV + su) * (ROW * 8) : 0) + ((-mu) & 31) * 8;
+            r.x = (ok ? (r0.wp * OV + su) * (ROW * 8) : 0) + ((-mu) & 31) * 8 + u_table;
             r.y = (ok ? (r0.wp * OV + sv) * (ROW * 8) : 0) + ((-mv) & 31) * 8;
             recs[lane] = r;
             origins[lane] = make_int2(mu, mv);
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 const int lo_v = __builtin_amdgcn_readlane(gmin_v, first);
                 const int hi_v = __builtin_amdgcn_readlane(gmax_v, first);
                 const bool any = lo_u <= hi_u;
-                const bool jump = hi_u - lo_u > S || hi_v - lo_v > S;
+                const bool jump = hi_u - lo_u > Su || hi_v - lo_v > Sv;
                 live = any && !jump;
                 if (live)
                     fit_window(lo_u, hi_u, lo_v, hi_v);     // whole group shares one window
@@ -486,8 +505,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                     const int hi_u = __builtin_amdgcn_readlane(gmax_u, next);
                     const int lo_v = __builtin_amdgcn_readlane(gmin_v, next);
                     const int hi_v = __builtin_amdgcn_readlane(gmax_v, next);
-                    const bool fits = have && lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + S
-                                      && lo_v >= Wv && hi_v <= Wv + S;
+                    const bool fits = have && lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + Su
+                                      && lo_v >= Wv && hi_v <= Wv + Sv;
                     if (!fits)
                         break;
                     live = true;
@@ -507,26 +526,26 @@ constexpr int waves_per_block()
     return 8;
 }
 
-size_t lds_bytes(int P, int NW, int W, int OV, int row)
+size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 {
-    return (size_t) W * OV * row * sizeof(float2)
+    return (size_t) tables * W * OV * row * sizeof(float2)
            + (size_t) NW * 64 * (sizeof(int2) + P * sizeof(float4) + sizeof(int2));
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int ROW, int NW>
+template <int P, int ROW, int NW, bool TWO>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
-           int W, int OV, int K, int p_total, hipStream_t stream)
+           int W, int OV, const tap_split &ts, int p_total, hipStream_t stream)
 {
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
-    const size_t lds = lds_bytes(P, NW, W, OV, ROW);
+    const size_t lds = lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
         KIMG_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW>),
+            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -537,7 +556,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
         const char *b = getenv("KIMG_GRID_BLOCKS");
         blocks_max_env = b ? atoi(b) : 0;
     }
-    // 8-wave blocks, as many resident per CU as the LDS (kernel table + staging) allows;
+    // as many blocks resident per CU as the LDS (kernel table + staging) allows;
     // every block streams a contiguous span (a multiple of 64).
     const int per_cu = lds <= LDS_LIMIT / 2 ? 2 : 1;
     const int blocks_max = blocks_max_env > 0 ? blocks_max_env : 256 * per_cu;
@@ -546,21 +565,23 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    grid_mfma_kernel<P, NW, SUB, ROW><<<blocks, NW * 64, lds, stream>>>(
+    grid_mfma_kernel<P, NW, SUB, ROW, TWO><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, K, vis_per_block, p_total, dbg);
+        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg);
     return kimg_launch_status();
 }
 
 } // namespace
 
 // The kernels are instantiated for 1 and 2 polarizations (32 accumulator registers each keep
-// two waves per SIMD without spills); 3 or 4 polarizations run as 2 + 1 / 2 + 2.
+// two waves per SIMD without spills); 3 or 4 polarizations run as 2 + 1 / 2 + 2.  Kernel widths
+// 33..64 run as 2 x 2 tap blocks with two single-row tables in LDS.
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
-    if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
+    if (P < 1 || P > 4 || kernel_width > 2 * WIN || kernel_width < 1)
         return false;
-    return lds_bytes(P > 1 ? 2 : 1, 8, w_planes, oversample, 32) <= LDS_LIMIT;
+    const int tables = kernel_width > WIN ? 2 : 1;
+    return lds_bytes(P > 1 ? 2 : 1, 8, w_planes, oversample, 32, tables) <= LDS_LIMIT;
 }
 
 size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P)
@@ -583,33 +604,51 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
         const char *e = getenv("KIMG_GRID_WAVES");      // timing experiments only
         nw_env = e ? atoi(e) : 0;
     }
+    const int K = kernel_width;
+    const bool wide = K > WIN;
+    const int Kh = wide ? (K + 1) / 2 : K;              // taps per block along one axis
+    const int nblk = wide ? 2 : 1;
     for (int p0 = 0; p0 < P; p0 += 2) {
         const int pn = P - p0 >= 2 ? 2 : 1;
         float *g = (float *) grid + 2 * p0 * grid_pol_stride;
         const float *wg = weights_grid + p0 * wg_pol_stride;
         const float2 *v = (const float2 *) vis + p0;
         const float2 *kern = (const float2 *) convolve_kernel;
-        int rc;
-#define LAUNCH(PP, ROWV, NWV) rc = launch<PP, ROWV, NWV>(g, grid_row_stride, grid_pol_stride, \
-        grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
-        oversample, kernel_width, P, stream)
-        if (pn == 1) {
-            // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
-            if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
-                LAUNCH(1, 64, 12);
-            else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                LAUNCH(1, 64, 8);
-            else
-                LAUNCH(1, 32, 8);
-        } else {
-            if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                LAUNCH(2, 64, 8);
-            else
-                LAUNCH(2, 32, 8);
-        }
+        for (int jb = 0; jb < nblk; jb++)
+            for (int kb = 0; kb < nblk; kb++) {
+                tap_split ts;
+                ts.K = K;
+                ts.tv0 = jb * Kh;
+                ts.Kv = jb ? K - Kh : Kh;
+                ts.tu0 = kb * Kh;
+                ts.Ku = kb ? K - Kh : Kh;
+                int rc;
+#define LAUNCH(PP, ROWV, NWV, TWOV) rc = launch<PP, ROWV, NWV, TWOV>(g, grid_row_stride, \
+        grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, \
+        w_planes, oversample, ts, P, stream)
+                if (wide) {
+                    if (pn == 1)
+                        LAUNCH(1, 32, 8, true);
+                    else
+                        LAUNCH(2, 32, 8, true);
+                } else if (pn == 1) {
+                    // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
+                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
+                        LAUNCH(1, 64, 12, false);
+                    else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                        LAUNCH(1, 64, 8, false);
+                    else
+                        LAUNCH(1, 32, 8, false);
+                } else {
+                    if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                        LAUNCH(2, 64, 8, false);
+                    else
+                        LAUNCH(2, 32, 8, false);
+                }
 #undef LAUNCH
-        if (rc)
-            return rc;
+                if (rc)
+                    return rc;
+            }
     }
     return 0;
 }

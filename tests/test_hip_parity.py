@@ -85,6 +85,34 @@ def test_gridder_bruteforce(variant, P):
     assert relerr(actual, G_or) < GRID_TOL
 
 
+@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('K,P', [(33, 1), (45, 2), (60, 1), (60, 4), (64, 3)])
+def test_gridder_wide_kernels(variant, K, P):
+    """Kernel widths 33..64 (60 is the reference's CLI default, frontend.py:325): the MFMA
+    gridder runs them as 2 x 2 tap blocks; odd widths split unevenly.  Against the oracle."""
+    c = gi.make_config(512, 0.0001, 0.01, P, K, 16, grid_cover=300, n_vis=1500)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, variant, max_vis=2048)
+    actual = _run_gridder(fn, q, t)
+    expected = np.zeros(actual.shape, np.complex64)
+    wg = np.zeros(actual.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(fn.convolve_kernel.data, expected, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(actual, expected) < GRID_TOL
+    # no locality at all
+    rs = np.random.RandomState(K)
+    n = 700
+    half = (t['weights_grid'].shape[-1] // 2) - 1
+    adv = dict(uv=rs.randint(-half, half, (n, 2)).astype(np.int16),
+               sub_uv=rs.randint(0, 8, (n, 2)).astype(np.int16),
+               w_plane=rs.randint(0, 16, n).astype(np.int16), weights_grid=t['weights_grid'],
+               vis=(rs.standard_normal((n, P)) + 1j * rs.standard_normal((n, P))).astype(np.complex64))
+    actual = _run_gridder(fn, q, adv)
+    expected[:] = 0
+    orc.grid(fn.convolve_kernel.data, expected, wg, adv['uv'], adv['sub_uv'], adv['w_plane'], adv['vis'])
+    assert relerr(actual, expected) < GRID_TOL
+
+
 def test_gridder_64_planes():
     """64 W-planes: the doubled LDS table does not fit, single-row variant (config 4)."""
     c = gi.make_config(256, 0.0001, 0.01, 2, 28, 64, grid_cover=180, n_vis=1000)
