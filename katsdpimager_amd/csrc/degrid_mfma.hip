@@ -1,6 +1,7 @@
 // MFMA window degridder for gfx950 (CDNA4).
 //
-// Replaces Degridder.static_run / degrid.mako:77-199 of the reference for kernel widths <= 32.
+// Replaces Degridder.static_run / degrid.mako:77-199 of the reference for kernel widths <= 64
+// (widths above 32 as 2 x 2 tap blocks).
 // Same result as DegridderHost/_degrid (grid.py:1138-1154):
 //     vis[r][p] -= weights[r][p] * sum_{j,k} kern[w][sv][j] * kern[w][su][k] * grid[p][v0+j][u0+k].
 //
@@ -70,18 +71,31 @@ struct window_regs {
     float g[P][WIN];        // g[p][y]: (lane < 32 ? Re : Im) of G[p][row y][column lane & 31]
 };
 
-template <int P, int NW, int TAPS>
+// Kernel widths above 32 are degridded as 2 x 2 blocks of taps, one launch per block, each
+// subtracting its partial sum (see grid_mfma.hip): row taps [tv0, tv0 + Kv) and column taps
+// [tu0, tu0 + Ku) of the K-tap kernel; off-diagonal blocks need TWO tables in LDS.
+struct tap_split {
+    int K;
+    int tv0, Kv;
+    int tu0, Ku;
+};
+
+template <int P, int NW, int TAPS, bool TWO>
 __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
-    const float2 *__restrict__ kern, int W, int OV, int K, int64_t vis_per_block, int p_total)
+    const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
+    int p_total)
 {
+    static_assert(!TWO || TAPS == 32, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = smem;
     const int table_rows = W * OV;
-    unsigned char *rec_base = smem + (size_t) table_rows * ROW_BYTES;
+    const int table_bytes = table_rows * ROW_BYTES;
+    const int u_table = TWO ? table_bytes : 0;
+    unsigned char *rec_base = smem + (size_t) table_bytes * (TWO ? 2 : 1);
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // per-wave staging of 64 visibilities: (table offset for kv, for ku, mu, mv); mu = INT_MIN
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     // Stage the kernel table: rows zero-padded to 32 taps, stored twice, stride 65 taps.
     // A thread issues all loads of a round before its first LDS write (one L2 round trip per
     // round instead of one per element).
-    {
+    auto stage_table = [&](unsigned char *dst_base, int tap0, int Kp) __attribute__((always_inline)) {
         constexpr int STG = 8;
         const int total = table_rows * 32;
         for (int base = threadIdx.x; base < total; base += NW * 64 * STG) {
@@ -100,21 +114,25 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             for (int i = 0; i < STG; i++) {
                 const int idx = base + i * NW * 64;
                 const int row = idx >> 5, t = idx & 31;
-                v[i] = (idx < total && t < K) ? kern[(int64_t) row * K + t] : make_float2(0.0f, 0.0f);
+                v[i] = (idx < total && t < Kp) ? kern[(int64_t) row * ts.K + tap0 + t]
+                                               : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
             for (int i = 0; i < STG; i++) {
                 const int idx = base + i * NW * 64;
                 const int row = idx >> 5, t = idx & 31;
                 if (idx < total) {
-                    float2 *dst = reinterpret_cast<float2 *>(smem + (size_t) row * ROW_BYTES + t * 8);
+                    float2 *dst = reinterpret_cast<float2 *>(dst_base + (size_t) row * ROW_BYTES + t * 8);
                     dst[0] = v[i];
                     if (TAPS == 64)
                         dst[32] = v[i];
                 }
             }
         }
-    }
+    };
+    stage_table(smem, ts.tv0, ts.Kv);
+    if (TWO)
+        stage_table(smem + table_bytes, ts.tu0, ts.Ku);
     __syncthreads();
 
     const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
@@ -127,9 +145,9 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     if (start >= end)
         return;
 
-    const int uv_bias = (K - 1) / 2 - Gg / 2;           // grid.py:1141
+    const int uv_bias = (ts.K - 1) / 2 - Gg / 2;        // grid.py:1141
     const int half = Gg / 2;
-    const int S = WIN - K;
+    const int Su = WIN - ts.Ku, Sv = WIN - ts.Kv;
     const bool h = lane >= 32;
     const int x_lane = lane & 31;                       // window column held by this lane
     const int part = lane & 1;                          // output column parity: 0 re, 1 im
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             const bool ok = i < end && (unsigned) (u + half) < (unsigned) Gg
                             && (unsigned) (v + half) < (unsigned) Gg && (unsigned) su < (unsigned) OV
                             && (unsigned) sv < (unsigned) OV && (unsigned) wp < (unsigned) W;
-            const int mu = u - uv_bias, mv = v - uv_bias;
+            const int mu = u - uv_bias + ts.tu0, mv = v - uv_bias + ts.tv0;
             int4 r;
             // TAPS == 64: byte address of tap ((-m) & 31) of the row; TAPS == 32: row number in
             // the high half and the tap offset in the low byte (wrapped at read time)
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             const int mu = rec.z, mv = rec.w;
             const bool mine = mu != INT_MIN;
             unsigned long long pending = __ballot(mine);
-            const bool whole = hi_u - lo_u <= S && hi_v - lo_v <= S;
+            const bool whole = hi_u - lo_u <= Su && hi_v - lo_v <= Sv;
             while (pending) {
                 // ---- choose / move the window ------------------------------------------------
                 // the whole group when it fits one window position, else the first pending
@@ -236,19 +254,19 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                     lu = hu = __builtin_amdgcn_readlane(mu, src);
                     lv = hv = __builtin_amdgcn_readlane(mv, src);
                 }
-                auto place = [&](int lo, int hi, int cur) __attribute__((always_inline)) {
+                auto place = [&](int lo, int hi, int cur, int S) __attribute__((always_inline)) {
                     if (!have)
                         return lo - (S - (hi - lo)) / 2;
                     if (lo >= cur && hi <= cur + S)
                         return cur;
                     return hi > cur + S ? lo : hi - S;
                 };
-                const int nWu = place(lu, hu, Wu);
-                const int nWv = place(lv, hv, Wv);
+                const int nWu = place(lu, hu, Wu, Su);
+                const int nWv = place(lv, hv, Wv, Sv);
                 if (!have || nWu != Wu || nWv != Wv)
                     load_window(nWu, nWv);
-                const bool fit = mine && (unsigned) (mu - Wu) <= (unsigned) S
-                                 && (unsigned) (mv - Wv) <= (unsigned) S;
+                const bool fit = mine && (unsigned) (mu - Wu) <= (unsigned) Su
+                                 && (unsigned) (mv - Wv) <= (unsigned) Sv;
                 const unsigned long long done = __ballot(fit) & pending;
                 pending &= ~done;
                 const bool active = (done >> lane) & 1ull;
@@ -272,8 +290,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
                 }
                 // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
-                const unsigned char *pu = tbytes + (TAPS == 64 ? rec.y + h32
-                                                               : (rec.y >> 16) * ROW_BYTES);
+                const unsigned char *pu = tbytes + u_table
+                                          + (TAPS == 64 ? rec.y + h32 : (rec.y >> 16) * ROW_BYTES);
                 const int off_u = (rec.y & 0xff) + h32;
                 float sum[P];
 #pragma unroll
@@ -312,22 +330,22 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     }
 }
 
-size_t lds_bytes(int NW, int W, int OV, int taps)
+size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 {
-    return (size_t) W * OV * (taps + 1) * 8 + (size_t) NW * 64 * sizeof(int4);
+    return (size_t) tables * W * OV * (taps + 1) * 8 + (size_t) NW * 64 * sizeof(int4);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int NW, int TAPS>
+template <int P, int NW, int TAPS, bool TWO>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
-           const float2 *kern, int W, int OV, int K, int p_total, hipStream_t stream)
+           const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream)
 {
-    const size_t lds = lds_bytes(NW, W, OV, TAPS);
+    const size_t lds = lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS>),
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -337,8 +355,8 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    degrid_mfma_kernel<P, NW, TAPS><<<blocks, NW * 64, lds, stream>>>(
-        grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, K,
+    degrid_mfma_kernel<P, NW, TAPS, TWO><<<blocks, NW * 64, lds, stream>>>(
+        grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, ts,
         vis_per_block, p_total);
     return kimg_launch_status();
 }
@@ -347,9 +365,9 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
 
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
-    if (P < 1 || P > 4 || kernel_width > WIN || kernel_width < 1)
+    if (P < 1 || P > 4 || kernel_width > 2 * WIN || kernel_width < 1)
         return false;
-    return lds_bytes(12, w_planes, oversample, 32) <= LDS_LIMIT;
+    return lds_bytes(12, w_planes, oversample, 32, kernel_width > WIN ? 2 : 1) <= LDS_LIMIT;
 }
 
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
@@ -357,23 +375,38 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
                      int w_planes, int oversample, int kernel_width, hipStream_t stream)
 {
+    const int K = kernel_width;
+    const bool wide = K > WIN;
+    const int Kh = wide ? (K + 1) / 2 : K;
+    const int nblk = wide ? 2 : 1;
     // instantiated for 1 and 2 polarizations; 3 or 4 run as 2 + 1 / 2 + 2 (register budget)
     for (int p0 = 0; p0 < P; p0 += 2) {
         const int pn = P - p0 >= 2 ? 2 : 1;
         const float *g = (const float *) grid + 2 * p0 * grid_pol_stride;
-        int rc;
-#define LAUNCH(PP, NWV, TAPSV) rc = launch<PP, NWV, TAPSV>(g, grid_row_stride, grid_pol_stride, \
-        grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, kernel_width, P, stream)
-        const bool doubled = lds_bytes(12, w_planes, oversample, 64) <= LDS_LIMIT;
-        if (pn == 1) {
-            if (doubled) LAUNCH(1, 12, 64); else LAUNCH(1, 12, 32);
-        } else {
-            if (doubled) LAUNCH(2, 8, 64); else LAUNCH(2, 8, 32);
-        }
+        for (int jb = 0; jb < nblk; jb++)
+            for (int kb = 0; kb < nblk; kb++) {
+                tap_split ts;
+                ts.K = K;
+                ts.tv0 = jb * Kh;
+                ts.Kv = jb ? K - Kh : Kh;
+                ts.tu0 = kb * Kh;
+                ts.Ku = kb ? K - Kh : Kh;
+                int rc;
+#define LAUNCH(PP, NWV, TAPSV, TWOV) rc = launch<PP, NWV, TAPSV, TWOV>(g, grid_row_stride, \
+        grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream)
+                const bool doubled = lds_bytes(12, w_planes, oversample, 64) <= LDS_LIMIT;
+                if (wide) {
+                    if (pn == 1) LAUNCH(1, 12, 32, true); else LAUNCH(2, 8, 32, true);
+                } else if (pn == 1) {
+                    if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
+                } else {
+                    if (doubled) LAUNCH(2, 8, 64, false); else LAUNCH(2, 8, 32, false);
+                }
 #undef LAUNCH
-        if (rc)
-            return rc;
+                if (rc)
+                    return rc;
+            }
     }
     return 0;
 }

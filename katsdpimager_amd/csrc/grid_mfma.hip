@@ -1,6 +1,7 @@
 // MFMA window gridder for gfx950 (CDNA4) -- the hot kernel of the path.
 //
-// Replaces Gridder.static_run / grid.mako:63-197 of the reference for kernel widths <= 32.
+// Replaces Gridder.static_run / grid.mako:63-197 of the reference for kernel widths <= 64
+// (widths above 32 as 2 x 2 tap blocks, see tap_split).
 // Same result as GridderHost/_grid (grid.py:1032-1052):
 //     grid[p][v0+j][u0+k] += vis[p]*wgt[p] * conj(kern[w][sv][j]) * conj(kern[w][su][k]).
 //

@@ -243,6 +243,45 @@ def test_degridder_adversarial(P, W):
         np.testing.assert_allclose(actual, expected, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('K,P', [(33, 1), (45, 2), (60, 1), (60, 4), (64, 3)])
+def test_degridder_wide_kernels(K, P):
+    """Kernel widths 33..64 through the MFMA degridder (2 x 2 tap blocks, each subtracting its
+    partial sum) against the oracle: a smooth track and positions without any locality."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(512, 0.0001, 0.01, P, K, 16, grid_cover=300, n_vis=1500)
+    t = gi.grid_track(c)
+    ip, gp, ap = make_params(c)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn.ensure_all_bound()
+    G = fn.buffer('grid').shape[-1]
+    rs = gi.RandomState(K)
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    fn.buffer('grid').set(q, gdata)
+    kernel = fn.convolve_kernel.data
+    half = t['weights_grid'].shape[-1] // 2 - 1
+    n2 = 900
+    cases = [(np.concatenate((t['uv'], t['sub_uv']), axis=1), t['w_plane']),
+             (np.concatenate([rs.randint(-half, half, (n2, 2)), rs.randint(0, 8, (n2, 2))],
+                             axis=1).astype(np.int16), rs.randint(0, 16, n2).astype(np.int16))]
+    for uv, wp in cases:
+        n = len(uv)
+        vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+        w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
+        fn.num_vis = n
+        fn.buffer('uv').set_region(q, uv, np.s_[:n], np.s_[:])
+        fn.buffer('w_plane').set_region(q, wp, np.s_[:n], np.s_[:])
+        fn.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+        fn.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+        fn()
+        expected = vis.copy()
+        orc.degrid(kernel, gdata, np.ascontiguousarray(uv[:, :2]), np.ascontiguousarray(uv[:, 2:]),
+                   wp, w, expected)
+        actual = fn.buffer('vis').get(q)[:n]
+        scale = np.abs(expected).max()
+        assert np.abs(actual - expected).max() <= 1e-5 * scale
+
+
 def test_predict_vs_golden(golden):
     """G4: reference _predict_host (norm-wise: see tests/test_oracle_golden.py::test_g4)."""
     from katsdpimager_amd import predict
