@@ -347,6 +347,35 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     q.finish()
     total = sum(c[3] for c in chunks)
     out['degrid_Mvis_per_s'] = round(2 * total / (time.perf_counter() - t0) / 1e6, 2)
+
+    # direct (DFT) prediction of a 1000-component model over every chunk: the reference's default
+    # predictor when --degrid is not given (frontend.py:113-138, predict.py:419-438)
+    from katsdpimager_amd import predict
+    S = 1000
+    pr = predict.PredictTemplate(ctx, np.float32, P).instantiate(q, ip, gp, args.vis_block, S)
+    pr.bind(weights=wts)
+    pr.ensure_all_bound()
+    rs = np.random.RandomState(3)
+    lm = rs.uniform(-0.4, 0.4, (S, 2)) * float(ip.image_size)
+    lmn = np.concatenate([lm, np.sqrt(1 - np.sum(lm * lm, axis=1, keepdims=True)) - 1], axis=1)
+    pr.set_sky_arrays(lmn.astype(np.float32), rs.uniform(0.1, 1, (S, P)).astype(np.float32))
+    pr.set_w(0.0)
+
+    def predict_some(nchunks):
+        for uv_c, wp_c, vis_c, n in chunks[:nchunks]:
+            pr.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+            pr.num_vis = n
+            pr._run()
+    nch = min(8, len(chunks))
+    predict_some(1)
+    q.finish()
+    t0 = time.perf_counter()
+    predict_some(nch)
+    q.finish()
+    dt = time.perf_counter() - t0
+    pairs = sum(c[3] for c in chunks[:nch]) * S
+    out['predict_Gpairs_per_s'] = round(pairs / dt / 1e9, 1)
+    out['predict_sources'] = S
     return out
 
 

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(256) void degrid_generic_kernel(
     }
 }
 
-// One thread per visibility; sources staged through LDS in chunks (predict.mako:38-74).
+// One thread per visibility; sources staged through LDS in chunks (predict.mako:38-74) as
+// (l, m, n-1, flux[0]) records so that a source costs one broadcast 16-byte LDS read.
+// Transcendental-bound: per (visibility, source) 3 FMA-class ops for the phase, v_fract (the
+// range reduction: v_sin / v_cos take turns), v_sin + v_cos (quarter rate) and 2 FMA per
+// polarization; 4 sources are in flight per thread to cover the transcendental latency.
 template <int P>
 __global__ __launch_bounds__(256) void predict_kernel(
     float2 *__restrict__ vis, const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
@@ -166,7 +170,8 @@ __global__ __launch_bounds__(256) void predict_kernel(
     float uv_scale, float w_scale, float w_bias)
 {
     constexpr int CHUNK = 256;
-    __shared__ float sl[CHUNK], sm[CHUNK], sn[CHUNK], sb[P][CHUNK];
+    __shared__ float4 src[CHUNK];                       // l, m, n-1, flux[0]
+    __shared__ float sb[P > 1 ? P - 1 : 1][CHUNK];      // flux[1..P-1]
     const int64_t gid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = gid < num_vis;
     float u = 0, v = 0, w = 0;
@@ -183,29 +188,43 @@ __global__ __launch_bounds__(256) void predict_kernel(
     for (int start = 0; start < num_sources; start += CHUNK) {
         const int batch = min(CHUNK, num_sources - start);
         __syncthreads();
-        if ((int) threadIdx.x < batch) {
+        {
+            // pad the chunk to a multiple of 4 with zero-flux sources
             const int s = start + threadIdx.x;
-            sl[threadIdx.x] = lmn[3 * s];
-            sm[threadIdx.x] = lmn[3 * s + 1];
-            sn[threadIdx.x] = lmn[3 * s + 2];
+            const bool real = (int) threadIdx.x < batch;
+            src[threadIdx.x] = real ? make_float4(lmn[3 * s], lmn[3 * s + 1], lmn[3 * s + 2],
+                                                  flux[s * P])
+                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (int p = 0; p < P; p++)
-                sb[p][threadIdx.x] = flux[s * P + p];
+            for (int p = 1; p < P; p++)
+                sb[p - 1][threadIdx.x] = real ? flux[s * P + p] : 0.0f;
         }
         __syncthreads();
-        if (live)
-            for (int s = 0; s < batch; s++) {
-                float phase = sl[s] * u + sm[s] * v + sn[s] * w;          // turns
-                phase -= rintf(phase);
-                // e^{-2 pi i phase}; v_sin/v_cos take their argument in turns
-                const float cs = __builtin_amdgcn_cosf(phase);
-                const float sn_ = -__builtin_amdgcn_sinf(phase);
+        const int padded = (batch + 3) & ~3;
+        for (int s0 = 0; s0 < padded; s0 += 4) {
+            float cs[4], sn[4];
+            float4 rec[4];
 #pragma unroll
-                for (int p = 0; p < P; p++) {
-                    acc[p].x = fmaf(cs, sb[p][s], acc[p].x);
-                    acc[p].y = fmaf(sn_, sb[p][s], acc[p].y);
+            for (int i = 0; i < 4; i++) {
+                rec[i] = src[s0 + i];
+                float phase = rec[i].x * u + rec[i].y * v + rec[i].z * w;     // turns
+                phase = __builtin_amdgcn_fractf(phase);
+                // e^{-2 pi i phase}; v_sin / v_cos take their argument in turns
+                cs[i] = __builtin_amdgcn_cosf(phase);
+                sn[i] = __builtin_amdgcn_sinf(phase);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc[0].x = fmaf(cs[i], rec[i].w, acc[0].x);
+                acc[0].y = fmaf(-sn[i], rec[i].w, acc[0].y);
+#pragma unroll
+                for (int p = 1; p < P; p++) {
+                    const float f = sb[p - 1][s0 + i];
+                    acc[p].x = fmaf(cs[i], f, acc[p].x);
+                    acc[p].y = fmaf(-sn[i], f, acc[p].y);
                 }
             }
+        }
     }
     if (!live)
         return;
