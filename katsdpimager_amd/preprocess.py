@@ -19,8 +19,6 @@ Layout in HBM, per (channel, w_slice): ``uv`` int16 [N][4] = (u, v, sub_u, sub_v
 visibility at P=1, 58 B at P=4) — exactly the arrays the gridder, degridder, predictor and
 weight kernels consume, so a major cycle touches no host memory.
 """
-import ctypes
-
 import numpy as np
 
 from . import accel
@@ -104,12 +102,14 @@ class _SliceStore:
         return out
 
 
-def _to_device(context, queue, ary, dtype, shape_tail=None):
+def _to_device(context, queue, ary, dtype):
     if ary is None:
         return None
     if isinstance(ary, accel.DeviceArray):
         if ary.dtype != np.dtype(dtype):
             raise TypeError('device input must have dtype {}'.format(np.dtype(dtype)))
+        if not ary.tensor.is_contiguous():
+            raise ValueError('device input must be contiguous')
         return ary
     host = np.require(np.asarray(ary), dtype, 'C')
     dev = accel.DeviceArray(context, host.shape, dtype)

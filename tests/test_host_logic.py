@@ -141,3 +141,151 @@ def test_preprocess_argument_validation():
                                       None, 0, None) == -10001
     assert L.kimg_real_to_complex(None, None, -1, None) == -10001
     assert L.kimg_real_to_complex(None, None, 0, None) == 0
+
+
+class _Recorder:
+    """Stands in for Imaging: records the calls of the driver (no device needed)."""
+
+    def __init__(self, num_pols=1, peaks=(1.0,), cycles_before_threshold=3):
+        self.calls = []
+        self.command_queue = None
+        self._peaks = list(peaks)
+        self._cycles = cycles_before_threshold
+        self._dirty = _FakeDirty(num_pols)
+        self.num_vis = 0
+
+    def buffer(self, name):
+        assert name == 'dirty'
+        return self._dirty
+
+    def finalize_weights(self):
+        self.calls.append(('finalize_weights',))
+        return 0.5, 2.0
+
+    def psf_patch(self):
+        self.calls.append(('psf_patch',))
+        return (1, 9, 11)
+
+    def noise_est(self):
+        self.calls.append(('noise_est',))
+        return 0.01
+
+    def clean_cycle(self, psf_patch, threshold=0.0):
+        self.calls.append(('clean_cycle', threshold))
+        if threshold == 0.0:
+            return self._peaks.pop(0)
+        self._cycles -= 1
+        return 0.5 if self._cycles >= 0 else None
+
+    def clean_cycles(self, psf_patch, threshold, max_cycles):
+        self.calls.append(('clean_cycles', max_cycles))
+        return [0.5] * min(self._cycles, max_cycles)
+
+    def __getattr__(self, name):
+        def record(*args, **kwargs):
+            self.calls.append((name,) + tuple(a for a in args if isinstance(a, (str, int, float))))
+        return record
+
+
+class _FakeDirty:
+    def __init__(self, P):
+        self.shape = (P, 8, 8)
+        self.dtype = np.dtype(np.float32)
+
+    def get_region(self, queue, out, region, out_region):
+        out[...] = 2.0
+
+
+class _HostReader:
+    def __init__(self, lengths, P=1):
+        self.lengths = lengths
+        self.dtype = np.dtype([('uv', 'i2', (2,)), ('sub_uv', 'i2', (2,)), ('w_plane', 'i2'),
+                               ('weights', 'f4', (P,)), ('vis', 'c8', (P,))])
+
+    def num_w_slices(self, channel):
+        return len(self.lengths)
+
+    def len(self, channel, w_slice):
+        return self.lengths[w_slice]
+
+    def iter_slice(self, channel, w_slice, block_size=None):
+        n = self.lengths[w_slice]
+        for start in range(0, n, block_size):
+            yield np.rec.recarray((min(block_size, n - start),), self.dtype)
+
+
+class _DeviceReader(_HostReader):
+    def iter_slice_device(self, channel, w_slice, block_size=None):
+        from katsdpimager_amd import preprocess
+        n = self.lengths[w_slice]
+        for start in range(0, n, block_size):
+            yield preprocess.DeviceChunk(min(block_size, n - start), None, None, None, None)
+
+
+def _driver_params(major_gain=0.85, threshold=5.0, minor=10):
+    import types
+    from katsdpimager_amd import clean
+    image_p = types.SimpleNamespace(fixed=types.SimpleNamespace(polarizations=[0]), wavelength=0.2)
+    grid_p = types.SimpleNamespace(fixed=types.SimpleNamespace(max_w=100.0), w_slices=3)
+    clean_p = types.SimpleNamespace(mode=clean.CLEAN_I, threshold=threshold, major_gain=major_gain,
+                                    minor=minor)
+    return image_p, grid_p, clean_p
+
+
+def test_frontend_driver_call_sequence():
+    """The driver issues the calls of frontend.make_weights / make_dirty / process_channel
+    (frontend.py:86-142, 497-585) in the reference's order, on either kind of reader."""
+    from katsdpimager_amd import frontend, weight
+    image_p, grid_p, clean_p = _driver_params()
+    mid_w = frontend.slice_mid_w(image_p, grid_p)
+    np.testing.assert_allclose(mid_w, np.arange(3) * (100.0 / 0.2 / 2.5))
+
+    # host reader, degridding, uniform weights, 2 major cycles; slice 1 is empty
+    im = _Recorder(peaks=[1.0, 1.0], cycles_before_threshold=3)
+    out = frontend.process_channel(_HostReader([5, 0, 3]), 0, im, image_p, grid_p, clean_p,
+                                   weight.WeightType.UNIFORM, 4, 2, True, batched_clean=False)
+    names = [c[0] for c in im.calls]
+    assert names[:2] == ['clear_model', 'clear_weights']
+    assert names.count('grid_weights') == 3                  # chunks of 4: 4+1, (empty), 3
+    first_dirty = names.index('clear_dirty')
+    assert names[first_dirty - 1] == 'finalize_weights'
+    # PSF pass: per non-empty slice clear_grid, chunks (set_coordinates, set_vis, grid), FFT
+    psf = names[first_dirty:names.index('scale_dirty')]
+    assert psf == ['clear_dirty',
+                   'clear_grid', 'set_coordinates', 'set_vis', 'grid',
+                   'set_coordinates', 'set_vis', 'grid', 'grid_to_image',
+                   'clear_grid', 'set_coordinates', 'set_vis', 'grid', 'grid_to_image']
+    assert 'set_weights' not in psf and 'predict' not in psf
+    assert names[names.index('scale_dirty'):][:3] == ['scale_dirty', 'dirty_to_psf', 'psf_patch']
+    # second major cycle predicts through the model grid before gridding each chunk
+    second = names[len(names) - names[::-1].index('clear_dirty') - 1:]
+    assert second[:3] == ['clear_dirty', 'model_to_grid', 'clear_grid']
+    assert second.count('predict') == 3 and second.count('set_weights') == 3
+    assert second.index('predict') < second.index('grid')
+    assert 'model_to_predict' not in names
+    # minor cycles: 3 successful + the one that hit the threshold, in each of the 2 major cycles?
+    # the recorder only allows 3 in total: first cycle 3 + 1 (None), second 0 + 1 (None)
+    assert out['major'] == 2 and out['minor'] == 5
+    assert out['psf_patch'] == (1, 9, 11) and out['weights_noise'] == 0.5
+    np.testing.assert_array_equal(out['scale'], [0.5])
+    assert names[-1] == 'noise_est'                          # frontend.py:583-585
+
+    # device reader, DFT predictor, natural weights: zero-copy calls, no grid_weights at all
+    im = _Recorder(peaks=[1.0, 1.0], cycles_before_threshold=20)
+    out = frontend.process_channel(_DeviceReader([5, 0, 3]), 0, im, image_p, grid_p, clean_p,
+                                   weight.WeightType.NATURAL, 4, 2, False, batched_clean=True)
+    names = [c[0] for c in im.calls]
+    assert 'grid_weights' not in names and 'grid_weights_device' not in names
+    assert names.count('set_chunk_device') == 9 and 'set_coordinates' not in names
+    assert [c for c in im.calls if c[0] == 'set_chunk_device'][:3] == [('set_chunk_device', 'weights')] * 3
+    assert names.count('model_to_predict') == 1 and 'model_to_grid' not in names
+    assert [c for c in im.calls if c[0] == 'clean_cycles'] == [('clean_cycles', 9)] * 2
+    assert out['minor'] == 18                                # 9 + 9, none hit the threshold
+
+    # stops when the first peak is already below the threshold; nothing to do without data
+    im = _Recorder(peaks=[0.01])
+    out = frontend.process_channel(_HostReader([5]), 0, im, image_p, grid_p, clean_p,
+                                   weight.WeightType.UNIFORM, 4, 3, True)
+    assert out['major'] == 1 and out['minor'] == 0
+    assert frontend.process_channel(_HostReader([0, 0]), 0, _Recorder(), image_p, grid_p, clean_p,
+                                    weight.WeightType.UNIFORM, 4, 3, True) is None
