@@ -224,6 +224,28 @@ def main():
             big._run()
         q.finish()
         sec['grid_single_launch_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+        # PCIe-inclusive: the reference-style host path, every chunk copied from host memory
+        # (uv, w_plane, vis: 18 B per visibility at P=1) before it is gridded
+        host_fn = template.instantiate(q, ap, ip, gp, vb)
+        host_fn.bind(grid=grid_buf, weights_grid=wg)
+        host_fn.ensure_all_bound()
+        h_uv = uv_all[:vb].cpu().numpy()
+        h_wp = wp_all[:vb].cpu().numpy()
+        h_vis = vis_all[:vb].cpu().numpy()
+        host_fn.num_vis = vb
+
+        def host_chunk():
+            host_fn.buffer('uv').set(q, h_uv)
+            host_fn.buffer('w_plane').set(q, h_wp)
+            host_fn.buffer('vis').set(q, h_vis)
+            host_fn._run()
+        host_chunk()
+        q.finish()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            host_chunk()
+        q.finish()
+        sec['grid_host_chunks_Mvis_per_s'] = round(8 * vb / (time.perf_counter() - t0) / 1e6, 1)
         if args.major_loop:
             # PSF pass grids the weights as visibilities (frontend.py:511)
             wt_all = padded(obs.weights)
