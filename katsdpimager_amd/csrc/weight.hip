@@ -5,23 +5,53 @@
 
 namespace {
 
+// One lane per visibility.  Consecutive visibilities of a track fall into the same cell many
+// times over (a same-address float atomic per visibility serialises in L2), so each wave first
+// sums its runs of equal (u, v) with a segmented scan and only the last lane of a run issues
+// the atomics.
 template <int P>
 __global__ __launch_bounds__(256) void grid_weights_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int half_u, int half_v,
     const int16_t *__restrict__ uv, const float *__restrict__ weights, int64_t num_vis)
 {
-    int64_t gid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= num_vis)
-        return;
+    const int64_t gid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = gid < num_vis;
     // first two of the four int16 are (u, v): one 4-byte load
-    int packed = reinterpret_cast<const int *>(uv)[2 * gid];
-    int u = (short) (packed & 0xffff);
-    int v = (short) (packed >> 16);
+    const int packed = live ? reinterpret_cast<const int *>(uv)[2 * gid] : 0;
     float w[P];
 #pragma unroll
     for (int p = 0; p < P; p++)
-        w[p] = weights[gid * P + p];
-    int64_t addr = (int64_t) (v + half_v) * row_stride + (u + half_u);
+        w[p] = live ? weights[gid * P + p] : 0.0f;
+    const int prev = __shfl_up(packed, 1, WAVE);
+    // a dead lane continues its predecessor's run with zero weight
+    int head = lane == 0 || (live && packed != prev);
+    const int next_head = __shfl_down(head, 1, WAVE);
+    const bool tail = lane == 63 || next_head;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int f_up = __shfl_up(head, d, WAVE);
+        float w_up[P];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            w_up[p] = __shfl_up(w[p], d, WAVE);
+        if (lane >= d && !head) {
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                w[p] += w_up[p];
+            head = f_up;
+        }
+    }
+    // the run's key: dead lanes inherit it from the run they extend
+    const unsigned long long heads = __ballot(lane == 0 || (live && packed != prev));
+    const int run_head = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+    const int key = __shfl(packed, run_head, WAVE);
+    const bool any_live = __shfl((int) live, run_head, WAVE);
+    if (!tail || !any_live)
+        return;
+    const int u = (short) (key & 0xffff);
+    const int v = (short) (key >> 16);
+    const int64_t addr = (int64_t) (v + half_v) * row_stride + (u + half_u);
 #pragma unroll
     for (int p = 0; p < P; p++)
         atomicAdd(&grid[addr + p * pol_stride], w[p]);
