@@ -11,6 +11,7 @@
 #include "kimg_common.h"
 #include <limits.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -538,7 +539,7 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s)
 // launch-bound, and replaying a captured graph costs far less host time than 2 launches
 // per cycle.  The device-side `limit` makes surplus cycles of the last replay no-ops.
 constexpr int GRAPH_CYCLES = 64;
-constexpr int GRAPH_CACHE = 4;
+constexpr int GRAPH_CACHE = 16;     // argument sets (channels in flight x patch sizes)
 
 struct graph_entry {
     bool valid;
@@ -547,9 +548,11 @@ struct graph_entry {
 };
 graph_entry graph_cache[GRAPH_CACHE];
 int graph_next = 0;
+std::mutex graph_mutex;         // channels imaged concurrently share the cache
 
 hipGraphExec_t cycles_graph(const cycle_args &a, hipStream_t s)
 {
+    std::lock_guard<std::mutex> lock(graph_mutex);
     for (int i = 0; i < GRAPH_CACHE; i++)
         if (graph_cache[i].valid && memcmp(&graph_cache[i].args, &a, sizeof(a)) == 0)
             return graph_cache[i].exec;

@@ -141,3 +141,25 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
         if i == major - 1:
             out['noise'] = imager.noise_est()
     return out
+
+
+def process_channels(jobs, workers=2):
+    """Image several channels of one GPU concurrently, one host thread and one HIP stream
+    (command queue) per channel in flight.
+
+    The reference loops over channels serially (frontend.py:749-767).  Within a channel the
+    stages are dependent, and the CLEAN minor cycles are a latency-bound chain of small launches
+    that leaves most of the device idle; running a second channel's gridding / FFTs next to it on
+    another stream fills those gaps.  ``jobs`` is a list of dicts of :func:`process_channel`
+    keyword arguments (each with its own ``imager``, hence its own command queue; they may share
+    a reader).  Returns the list of results in job order.
+    """
+    import concurrent.futures
+    if workers <= 1 or len(jobs) <= 1:
+        return [process_channel(**job) for job in jobs]
+    queues = {id(job['imager'].command_queue) for job in jobs}
+    if len(queues) != len(jobs):
+        raise ValueError('concurrent channels need one command queue each')
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+        futures = [pool.submit(process_channel, **job) for job in jobs]
+        return [f.result() for f in futures]

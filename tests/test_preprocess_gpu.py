@@ -309,3 +309,49 @@ def test_store_driven_channel_vs_golden(golden, name):
     np.testing.assert_allclose(sa['peaks'][0], g['peak_values'][0], rtol=1e-4)
     # the reference counts minor cycles like the goldens' n_minor (first cycle + loop)
     assert sa['major'] == len(g['n_minor'])
+
+
+def test_concurrent_channels_match_serial():
+    """frontend.process_channels: two channels in flight on two streams (two host threads, one
+    command queue each) give the same images as one after the other."""
+    from helpers import make_params, relerr
+    from katsdpimager_amd import frontend, imaging, parameters, preprocess, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS['degrid']
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType(c['weight_type']), c['robustness'])
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    uvw, vis, weights = gi.e2e_raw(c)
+    coll = preprocess.VisibilityCollectorDevice(q, [ip, ip], [gp, gp], len(uvw))
+    both = np.stack([vis, 0.5 * vis])[:, :, None].astype(np.complex64)      # two "channels"
+    coll.add(uvw, np.stack([weights, weights]), both, None, None, np.ones((1, 1), np.complex64), None)
+    coll.close()
+    reader = coll.reader()
+    template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
+
+    def jobs():
+        out = []
+        for ch in range(2):
+            qi = ctx.create_command_queue()
+            im = template.instantiate(qi, ip, gp, c['vis_block'], 0, c['major'])
+            im.ensure_all_bound()
+            out.append(dict(reader=reader, rel_channel=ch, imager=im, image_p=ip, grid_p=gp,
+                            clean_p=cp, weight_type=wp.weight_type, vis_block=c['vis_block'],
+                            major=c['major'], degrid=True))
+        return out
+    serial, conc = jobs(), jobs()
+    rs = frontend.process_channels(serial, workers=1)
+    rc = frontend.process_channels(conc, workers=2)
+    for a, b, ja, jb in zip(rs, rc, serial, conc):
+        assert a['minor'] == b['minor'] and a['psf_patch'] == b['psf_patch']
+        assert sorted(ja['imager']._model_components) == sorted(jb['imager']._model_components)
+        assert relerr(ja['imager'].get_buffer('model'), jb['imager'].get_buffer('model')) < 1e-5
+    # the two channels differ by the factor put into the visibilities
+    m0 = serial[0]['imager'].get_buffer('model')
+    m1 = serial[1]['imager'].get_buffer('model')
+    assert relerr(0.5 * m0, m1) < 1e-3
+    with pytest.raises(ValueError):
+        shared = jobs()
+        shared[1]['imager'] = shared[0]['imager']
+        frontend.process_channels(shared, workers=2)
