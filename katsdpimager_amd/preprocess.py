@@ -74,11 +74,17 @@ class _SliceStore:
             a.zero(self.queue)       # the slack rows are read (and masked) by full-block views
         return arrays
 
-    def reserve(self, extra):
+    def ensure_slack(self, slack):
+        """Make full-size block views of up to ``slack`` rows possible (reallocates once)."""
+        if slack > self.slack:
+            self.slack = slack
+            self.reserve(0, exact=True)
+
+    def reserve(self, extra, exact=False):
         need = self.length + extra + self.slack
         if need <= self.capacity:
             return
-        rows = max(need, 2 * self.capacity)
+        rows = need if exact else max(need, 2 * self.capacity)
         arrays = self._allocate(rows)
         if self.arrays is not None and self.length:
             for name, old in self.arrays.items():
@@ -308,12 +314,17 @@ class VisibilityReaderDevice:
 
     def iter_slice_device(self, channel, w_slice, block_size=None):
         """Yield :class:`DeviceChunk` views of ``block_size`` rows (the last one partly
-        valid).  ``block_size`` defaults to, and may not exceed, the collector's buffer size."""
+        valid).  ``block_size`` defaults to the collector's buffer size; a larger one — up to a
+        whole slice per block, i.e. one gridder launch per slice — makes the store reallocate
+        once so that every block view has its full ``block_size`` rows."""
         store = self._stores[channel][w_slice]
         if block_size is None:
             block_size = self.collector.buffer_size
-        if block_size <= 0 or block_size > store.slack:
-            raise ValueError('block_size must be in 1..{}'.format(store.slack))
+        if block_size <= 0:
+            raise ValueError('block_size must be positive')
+        if store.length == 0:
+            return
+        store.ensure_slack(block_size)
         for start in range(0, store.length, block_size):
             v = store.view(start, block_size)
             yield DeviceChunk(min(block_size, store.length - start), v['uv'], v['w_plane'],

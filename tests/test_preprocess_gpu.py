@@ -204,7 +204,11 @@ def test_device_inputs_and_errors():
     reader = coll.reader()
     assert [reader.len(0, 0), reader.len(1, 0)] == [2, 3]
     with pytest.raises(ValueError):
-        list(reader.iter_slice_device(0, 0, 65))
+        list(reader.iter_slice_device(0, 0, 0))
+    big = list(reader.iter_slice_device(1, 0, 1000))       # larger than the buffer: store regrows
+    assert len(big) == 1 and big[0].num_vis == 3 and big[0].uv.shape == (1000, 4)
+    np.testing.assert_array_equal(big[0].uv.get(q)[:3, :2], expected[1]['uv'])
+    assert not np.any(big[0].vis.get(q)[3:])
     chunks = list(reader.iter_slice_device(1, 0, 2))
     assert [c.num_vis for c in chunks] == [2, 1]
     assert chunks[1].uv.shape == (2, 4) and chunks[1].vis.shape == (2, 4)
