@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument('--vis-block', type=int, default=1048576)
     p.add_argument('--variant', default='auto', choices=['auto', 'generic', 'mfma'])
     p.add_argument('--clean-cycles', type=int, default=1000)
-    p.add_argument('--cpu-sample', type=int, default=4_000_000,
+    p.add_argument('--cpu-sample', type=int, default=16_000_000,
                    help='visibilities gridded by the CPU baseline (0 disables it)')
     p.add_argument('--major-loop', action='store_true',
                    help='also time the full major-cycle loop (BASELINE config 5)')
