@@ -359,3 +359,24 @@ def test_concurrent_channels_match_serial():
         shared = jobs()
         shared[1]['imager'] = shared[0]['imager']
         frontend.process_channels(shared, workers=2)
+
+
+def test_example_runs_and_recovers_sources():
+    """examples/image_channel.py at a small size: the three synthetic sources come back at their
+    positions with their fluxes (robust weighting, 3 major cycles, restored with a 1.5-pixel beam)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'examples', 'image_channel.py')
+    spec = importlib.util.spec_from_file_location('image_channel_example', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    restored, stats = mod.main(['--pixels', '1024', '--vis', '600000', '--major', '3',
+                                '--minor', '300', '--vis-block', '131072'])
+    assert stats['major'] >= 2 and stats['minor'] > 10
+    G = 1024
+    # a Gaussian restoring beam of amplitude 1 and sigma 1.5 px keeps the peak = flux
+    for (lp, mp), flux in [((40, -25), 1.0), ((-120, 60), 0.5), ((15, 200), 0.25)]:
+        y, x = G // 2 + mp, G // 2 + lp
+        peak = float(restored[y - 2:y + 3, x - 2:x + 3].max())
+        assert abs(peak - flux) < 0.1 * flux, (lp, mp, flux, peak)
