@@ -11,7 +11,6 @@ host in float64 exactly as the reference does for both its CPU and GPU paths
 (grid.py:235-334: the device classes also build the table with numpy and
 upload it).
 """
-import ctypes
 import math
 
 import numpy as np

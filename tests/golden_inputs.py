@@ -328,7 +328,6 @@ def run_major_cycle(im, c, data, host=False):
     frontend.process_channel (frontend.py:465-585; make_weights :86-106,
     make_dirty :110-142).  Works on the reference's ImagingHost and on
     katsdpimager_amd.imaging.Imaging alike; returns arrays for comparison."""
-    import math
     G = c['pixels']
     slices = data['slices']
     vb = c['vis_block']
