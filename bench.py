@@ -355,6 +355,7 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
                             tensor=torch.ones((args.vis_block, P), device=ctx.device))
     dg.bind(weights=wts)
     dg.ensure_all_bound()
+    torch.cuda.synchronize()        # torch filled `wts` on its own stream
 
     def degrid_all():
         for uv_c, wp_c, vis_c, n in chunks:

@@ -11,6 +11,7 @@ host in float64 exactly as the reference does for both its CPU and GPU paths
 (grid.py:235-334: the device classes also build the table with numpy and
 upload it).
 """
+import collections
 import math
 
 import numpy as np
@@ -128,6 +129,29 @@ class ConvolutionKernelDevice(ConvolutionKernel):
         return self.data.shape[-1]
 
 
+_kernel_cache = collections.OrderedDict()
+_KERNEL_CACHE_SIZE = 8
+
+
+def shared_kernel_device(context, image_parameters, grid_parameters, pad=0):
+    """The (read-only) device kernel table for these parameters.  A channel's gridder and
+    degridder use the same table, and generating it on the host costs several milliseconds —
+    comparable with imaging a whole channel — so the most recent few are shared."""
+    fixed = grid_parameters.fixed
+    key = (id(context), float(image_parameters.cell_size), float(image_parameters.wavelength),
+           float(fixed.max_w), grid_parameters.w_slices, grid_parameters.w_planes, fixed.oversample,
+           float(fixed.image_oversample), fixed.kernel_width, float(fixed.antialias_width), pad)
+    kernel = _kernel_cache.get(key)
+    if kernel is None:
+        kernel = ConvolutionKernelDevice(context, image_parameters, grid_parameters, pad)
+        _kernel_cache[key] = kernel
+        while len(_kernel_cache) > _KERNEL_CACHE_SIZE:
+            _kernel_cache.popitem(last=False)
+    else:
+        _kernel_cache.move_to_end(key)
+    return kernel
+
+
 # --------------------------------------------------------------------------
 # Operators
 # --------------------------------------------------------------------------
@@ -188,7 +212,7 @@ class GridDegrid(VisOperation):
         assert grid_parameters.fixed == template.fixed_grid_parameters
         num_polarizations = len(image_parameters.fixed.polarizations)
         super().__init__(command_queue, num_polarizations, max_vis, allocator)
-        self.convolve_kernel = ConvolutionKernelDevice(
+        self.convolve_kernel = shared_kernel_device(
             template.context, image_parameters, grid_parameters, template.kernel_pad)
         # Longest baseline must leave the whole footprint inside the grid (grid.py:753-761)
         max_uv_src = float(array_parameters.longest_baseline / image_parameters.cell_size)

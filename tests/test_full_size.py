@@ -32,15 +32,18 @@ def _setup(pixels, n_vis, w_planes, P, K=28, variant='auto', vis_block=1048576):
                            tensor=torch.rand((P, Gg, Gg), generator=gen, device=ctx.device))
     fn.bind(weights_grid=wg)
     fn.ensure_all_bound()
+    torch.cuda.synchronize()        # torch generated the inputs on its own stream
     return ctx, q, obs, fn, wg
 
 
 def _grid_all(ctx, q, obs, fn, vis=None, zero=True):
     """Grid every chunk of the observation (optionally with substitute visibilities)."""
+    import torch
     from katsdpimager_amd import accel
     vb = fn.max_vis
     P = obs.vis.shape[1]
     vis = obs.vis if vis is None else vis
+    torch.cuda.synchronize()        # inputs may have been produced on torch's stream
     if zero:
         fn.buffer('grid').zero(q)
     for start in range(0, obs.n_vis, vb):
@@ -160,6 +163,8 @@ def _degrid_all(ctx, q, obs, template_args, model_grid, vis_block):
     dg.ensure_all_bound()
     n_full = obs.n_vis // vis_block * vis_block          # whole chunks only
     out = torch.zeros((n_full, P), dtype=torch.complex64, device=ctx.device)
+    # torch fills on its own stream; the operators run on the queue's stream
+    torch.cuda.synchronize()
     for start in range(0, n_full, vis_block):
         sl = slice(start, start + vis_block)
         dg.bind(uv=accel.DeviceArray(ctx, (vis_block, 4), np.int16, tensor=obs.uv[sl]),
@@ -190,6 +195,7 @@ def test_grid_degrid_adjoint(pixels, w_planes, P, n_vis, vis_block):
     G = torch.complex(torch.rand((P, Gg, Gg), generator=gen, device=ctx.device) - 0.5,
                       torch.rand((P, Gg, Gg), generator=gen, device=ctx.device) - 0.5)
     model_grid = accel.DeviceArray(ctx, (P, Gg, Gg), np.complex64, tensor=G)
+    torch.cuda.synchronize()
     pred, n_full = _degrid_all(ctx, q, obs, (ap, ip, gp), model_grid, vis_block)
     assert n_full == n_vis
     v = obs.vis[:n_full]
