@@ -50,6 +50,7 @@ def main(argv=None):
     vis = vis.to(torch.complex64)[None, :, None].contiguous()
     weights = torch.ones((1, obs.n_vis, 1), dtype=torch.float32, device=ctx.device)
 
+    torch.cuda.synchronize()        # the inputs above were produced on torch's own stream
     t0 = time.perf_counter()
     collector = preprocess.VisibilityCollectorDevice(queue, [image_p], [grid_p], args.vis_block)
     collector.add(accel.DeviceArray(ctx, (obs.n_vis, 3), np.float32, tensor=obs.uvw),

@@ -202,6 +202,9 @@ class VisibilityCollectorDevice:
         uvw: N x 3 float32 metres; weights: C x N x Q float32; vis: C x N x Q complex64;
         feed_angle1/2: N float32 radians or None; mueller_stokes: P x Q (no feed angles) or
         P x 4; mueller_circular: 4 x Q or None.
+
+        Device inputs are read on this collector's command queue: whatever produced them on
+        another stream must have completed (or been synchronised with) before the call.
         """
         if self._closed:
             raise RuntimeError('collector is closed')
