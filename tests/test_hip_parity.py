@@ -113,6 +113,54 @@ def test_gridder_wide_kernels(variant, K, P):
     assert relerr(actual, expected) < GRID_TOL
 
 
+@pytest.mark.parametrize('K,OV,W,P', [(1, 8, 3, 1), (2, 4, 8, 2), (7, 16, 4, 1), (15, 2, 8, 3),
+                                      (31, 8, 5, 1), (32, 8, 8, 2), (32, 4, 1, 4), (27, 2, 7, 1)])
+def test_grid_degrid_odd_shapes(K, OV, W, P):
+    """Unusual kernel widths (1, odd, exactly the window width: no slack), oversampling factors and
+    plane counts through the MFMA gridder and degridder, smooth and scattered positions."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(256, 0.0001, 0.01, P, K, W, oversample=OV, grid_cover=180, n_vis=1200)
+    t = gi.grid_track(c)
+    rs = gi.RandomState(K * 100 + OV)
+    n2 = 800
+    scattered = dict(
+        uv=rs.randint(-80, 80, (n2, 2)).astype(np.int16),
+        sub_uv=rs.randint(0, OV, (n2, 2)).astype(np.int16),
+        w_plane=rs.randint(0, W, n2).astype(np.int16), weights_grid=t['weights_grid'],
+        vis=rs.complex_uniform(-1, 1, size=(n2, P)).astype(np.complex64))
+    fn, q = _gridder(c, 'mfma', max_vis=2048)
+    kernel = fn.convolve_kernel.data
+    assert kernel.shape == (W, OV, K)
+    ip, gp, ap = make_params(c)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    dg.ensure_all_bound()
+    G = dg.buffer('grid').shape[-1]
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    dg.buffer('grid').set(q, gdata)
+    for data in (t, scattered):
+        actual = _run_gridder(fn, q, data)
+        expected = np.zeros(actual.shape, np.complex64)
+        wg = np.zeros(actual.shape, np.float32)
+        gi.middle(wg, data['weights_grid'].shape)[:] = data['weights_grid']
+        orc.grid(kernel, expected, wg, data['uv'], data['sub_uv'], data['w_plane'], data['vis'])
+        assert relerr(actual, expected) < GRID_TOL
+        n = len(data['uv'])
+        vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+        w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
+        dg.num_vis = n
+        dg.buffer('uv').set_region(q, np.concatenate((data['uv'], data['sub_uv']), axis=1),
+                                   np.s_[:n], np.s_[:])
+        dg.buffer('w_plane').set_region(q, data['w_plane'], np.s_[:n], np.s_[:])
+        dg.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+        dg.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+        dg()
+        want = vis.copy()
+        orc.degrid(kernel, gdata, data['uv'], data['sub_uv'], data['w_plane'], w, want)
+        got = dg.buffer('vis').get(q)[:n]
+        assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
+
+
 def test_gridder_64_planes():
     """64 W-planes: the doubled LDS table does not fit, single-row variant (config 4)."""
     c = gi.make_config(256, 0.0001, 0.01, 2, 28, 64, grid_cover=180, n_vis=1000)
