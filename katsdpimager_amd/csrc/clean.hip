@@ -358,13 +358,26 @@ __global__ __launch_bounds__(256) void abs_histogram_kernel(
     // of a noise-like image falls into the same two or three bins, and one LDS atomic per
     // pixel would serialise the whole wave on them.
     uint32_t run_bin = 0, run = 0;
+    // four rows per round, their loads issued together (the loop is otherwise one dependent
+    // memory round trip per pixel row)
+    constexpr int ROWS = 4;
+    const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool x_ok = x < width - border;
     for (int p = 0; p < P; p++)
-        for (int y = border + blockIdx.y; y < height - border; y += gridDim.y)
-            for (int x = border + blockIdx.x * blockDim.x + threadIdx.x; x < width - border;
-                 x += gridDim.x * blockDim.x) {
-                uint32_t key = __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
-                               & 0x7fffffffu;
-                if (pass == 3 || (key >> (shift + 8)) == prefix) {
+        for (int y0 = border + blockIdx.y; y0 < height - border; y0 += gridDim.y * ROWS) {
+            uint32_t keys[ROWS];
+            bool ok[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + r * gridDim.y;
+                ok[r] = x_ok && y < height - border;
+                keys[r] = ok[r] ? __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
+                                      & 0x7fffffffu : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const uint32_t key = keys[r];
+                if (ok[r] && (pass == 3 || (key >> (shift + 8)) == prefix)) {
                     const uint32_t bin = (key >> shift) & 255u;
                     if (bin != run_bin) {
                         if (run)
@@ -375,6 +388,7 @@ __global__ __launch_bounds__(256) void abs_histogram_kernel(
                     run++;
                 }
             }
+        }
     if (run)
         atomicAdd(&local[run_bin], run);
     __syncthreads();
@@ -387,34 +401,59 @@ __global__ __launch_bounds__(256) void abs_count_le_kernel(
     int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out)
 {
     uint32_t count = 0, next = 0xffffffffu;
+    constexpr int ROWS = 4;
+    const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool x_ok = x < width - border;
     for (int p = 0; p < P; p++)
-        for (int y = border + blockIdx.y; y < height - border; y += gridDim.y)
-            for (int x = border + blockIdx.x * blockDim.x + threadIdx.x; x < width - border;
-                 x += gridDim.x * blockDim.x) {
-                uint32_t key = __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
-                               & 0x7fffffffu;
-                if (key <= value_bits)
-                    count++;
-                else
-                    next = min(next, key);
+        for (int y0 = border + blockIdx.y; y0 < height - border; y0 += gridDim.y * ROWS) {
+            uint32_t keys[ROWS];
+            bool ok[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + r * gridDim.y;
+                ok[r] = x_ok && y < height - border;
+                keys[r] = ok[r] ? __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
+                                      & 0x7fffffffu : 0u;
             }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++)
+                if (ok[r]) {
+                    if (keys[r] <= value_bits)
+                        count++;
+                    else
+                        next = min(next, keys[r]);
+                }
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         count += __shfl_xor(count, off, WAVE);
         next = min(next, (uint32_t) __shfl_xor((int) next, off, WAVE));
     }
+    // one pair of atomics per workgroup (same-address atomics from thousands of waves serialise)
+    __shared__ uint32_t s_count[4], s_next[4];
+    const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
+        s_count[wv] = count;
+        s_next[wv] = next;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int) (blockDim.x >> 6); w++) {
+            count += s_count[w];
+            next = min(next, s_next[w]);
+        }
         if (count)
             atomicAdd(&out[0], count);
-        atomicMin(&out[1], next);
+        if (next != 0xffffffffu)
+            atomicMin(&out[1], next);
     }
 }
 
-dim3 region_grid(int width, int height)
+dim3 region_grid(int width, int height, int max_blocks = 2048)
 {
     int bx = kimg_divup(width, 256);
     if (bx < 1) bx = 1;
-    int by = height < 2048 / bx ? height : 2048 / bx;
+    int by = height < max_blocks / bx ? height : max_blocks / bx;
     return dim3(bx, by > 0 ? by : 1);
 }
 
@@ -644,7 +683,7 @@ extern "C" int kimg_abs_histogram(const float *image, int64_t row_stride, int64_
     KIMG_CHECK_ARG(width > 2 * border && height > 2 * border && num_polarizations >= 1);
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
-    abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border), 256, 0, s>>>(
+    abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border, 512), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist);
     return kimg_launch_status();
 }
@@ -661,7 +700,7 @@ extern "C" int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t
     union { float f; uint32_t u; } conv;
     conv.f = value;
     const uint32_t bits = conv.u;
-    abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border), 256, 0, s>>>(
+    abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 1024), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border,
         bits & 0x7fffffffu, out);
     return kimg_launch_status();
