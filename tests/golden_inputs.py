@@ -253,6 +253,8 @@ _E2E = dict(pixels=256, pixel_size=4.0e-4, wavelength=0.2, P=1, kernel_width=16,
 E2E_CONFIGS = {
     'degrid': make_config(**dict(_E2E, degrid=True)),
     'predict': make_config(**dict(_E2E, degrid=False)),
+    # full Stokes, CLEAN_SUMSQ peak metric (clean.py:28-31), uniform weights
+    'stokes': make_config(**dict(_E2E, degrid=True, P=4, mode=1, weight_type=1, n_vis=1200)),
 }
 
 
@@ -305,6 +307,16 @@ def e2e_raw(c, seed=11):
                                               + uvw_wl[:, 2] * (nn - 1)))
     vis += 0.02 * (rs.standard_normal(len(uvw)) + 1j * rs.standard_normal(len(uvw)))
     weights = rs.uniform(0.5, 1.5, (len(uvw), 1)).astype(np.float32)
+    P = c['P']
+    if P > 1:
+        # further polarizations: scaled copies of the first with their own noise and weights
+        # (drawn after everything above, so that the single-polarization inputs are unchanged)
+        pol_scale = np.array([1.0, 0.25, -0.15, 0.05])[:P]
+        extra = 0.02 * (rs.standard_normal((len(uvw), P)) + 1j * rs.standard_normal((len(uvw), P)))
+        extra[:, 0] = 0
+        vis = vis[:, None] * pol_scale[None, :] + extra
+        weights = np.concatenate(
+            [weights, rs.uniform(0.5, 1.5, (len(uvw), P - 1)).astype(np.float32)], axis=1)
     return uvw, vis, weights
 
 
@@ -312,7 +324,8 @@ def e2e_inputs(c, seed=11):
     """:func:`e2e_raw` quantised and compressed with the restated preprocessor rules."""
     from oracle import kimg_oracle as orc
     uvw, vis, weights = e2e_raw(c, seed)
-    rec = orc.quantise_uvw(uvw, vis[:, None].astype(np.complex64), weights, c['cell_size'],
+    vis = vis[:, None] if vis.ndim == 1 else vis
+    rec = orc.quantise_uvw(uvw, vis.astype(np.complex64), weights, c['cell_size'],
                            c['max_w'], c['w_slices'], c['w_planes'], c['oversample'])
     rec = orc.compress(rec)
     slices = []
@@ -323,11 +336,13 @@ def e2e_inputs(c, seed=11):
     return dict(slices=slices)
 
 
-def run_major_cycle(im, c, data, host=False):
+def run_major_cycle(im, c, data, host=False, conv=None):
     """Drive an Imaging-shaped object through the per-channel loop of
     frontend.process_channel (frontend.py:465-585; make_weights :86-106,
     make_dirty :110-142).  Works on the reference's ImagingHost and on
     katsdpimager_amd.imaging.Imaging alike; returns arrays for comparison."""
+    if conv is None:
+        from oracle import kimg_oracle as conv      # same formulas as katsdpimager.clean
     G = c['pixels']
     slices = data['slices']
     vb = c['vis_block']
@@ -418,11 +433,13 @@ def run_major_cycle(im, c, data, host=False):
         im.clean_reset()
         peak_value = im.clean_cycle(psf_patch)
         vals = [peak_value]
-        peak_power = peak_value          # CLEAN_I (clean.py:166-174)
-        noise_threshold = noise * c['threshold']
+        # frontend.py:566-576 with the conversions of clean.py:166-203
+        peak_power = conv.metric_to_power(c['mode'], peak_value)
+        noise_threshold = noise * conv.noise_threshold_scale(c['mode'], c['threshold'], c['P'])
         mgain_threshold = (1.0 - c['major_gain']) * peak_power
         threshold = max(noise_threshold, mgain_threshold)
         if peak_power > threshold:
+            threshold = conv.power_to_metric(c['mode'], threshold)
             for j in range(c['minor'] - 1):
                 value = im.clean_cycle(psf_patch, threshold)
                 if value is None:

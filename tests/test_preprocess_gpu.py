@@ -257,8 +257,9 @@ def test_store_driven_channel_vs_golden(golden, name):
     uvw, vis, weights = gi.e2e_raw(c)
     n = len(uvw)
     coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], max(n, c['vis_block']))
-    coll.add(uvw, weights[None], vis[None, :, None].astype(np.complex64), None, None,
-             np.ones((1, 1), np.complex64), None)
+    vis = vis[:, None] if vis.ndim == 1 else vis
+    coll.add(uvw, weights[None], vis[None].astype(np.complex64), None, None,
+             np.identity(c['P'], dtype=np.complex64), None)
     coll.close()
     reader = coll.reader()
     # the store holds exactly the records the goldens were generated from
