@@ -73,6 +73,8 @@ GRID_CONFIGS = {
     'p1_f64': make_config(128, 0.0002, 0.01, 1, 28, 32, real_dtype='float64',
                           grid_cover=90, n_vis=600),
     'p1_k8': make_config(96, 0.0002, 0.01, 1, 8, 8, grid_cover=80, n_vis=1500),
+    # the CLI's default kernel width (frontend.py:325), two polarizations
+    'p2_k60': make_config(192, 0.0002, 0.01, 2, 60, 8, grid_cover=110, n_vis=400),
 }
 
 

@@ -42,7 +42,7 @@ def _run_gridder(fn, q, t):
 
 
 @pytest.mark.parametrize('variant', ['generic', 'mfma'])
-@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8'])
+@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8', 'p2_k60'])
 def test_gridder_vs_golden(golden, name, variant):
     """G2: reference GridderHost output on the test_grid.py track recipe."""
     c = gi.GRID_CONFIGS[name]
@@ -224,7 +224,7 @@ def test_gridder_too_small_image():
         template.instantiate(q, ap, ip, gp, 100)
 
 
-@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8'])
+@pytest.mark.parametrize('name', ['p4_f32', 'p1_k8', 'p2_k60'])
 def test_degridder_vs_golden(golden, name):
     """G3: reference DegridderHost residuals (rtol 1e-5 as test_grid.py:135, plus an absolute
     floor for values that cancel)."""
