@@ -53,7 +53,12 @@ const char *kimg_error_string(int code);
  *   vis             complex64 [N][P]
  *   convolve_kernel complex64 [w_planes][oversample][kernel_width], unpadded
  *   workspace       scratch, at least kimg_grid_workspace_bytes(max N, P) bytes
- *   variant         0 = automatic; 1 = generic scatter kernel; 2 = MFMA window kernel
+ *   variant         0 = automatic; 1 = generic scatter kernel (any kernel width); 2 = MFMA window
+ *                   kernel (kernel_width <= 64 and the kernel table(s) fit LDS:
+ *                   w_planes*oversample <= 512 rows for widths <= 32, <= 256 for 33..64),
+ *                   KIMG_EUNSUPPORTED otherwise.  Automatic = MFMA when supported.
+ *   Out-of-range coordinates (footprint outside the grid, sub_uv >= oversample, w_plane >=
+ *   w_planes) contribute nothing instead of faulting.
  */
 size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations);
 int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
