@@ -381,3 +381,68 @@ def test_example_runs_and_recovers_sources():
         y, x = G // 2 + mp, G // 2 + lp
         peak = float(restored[y - 2:y + 3, x - 2:x + 3].max())
         assert abs(peak - flux) < 0.1 * flux, (lp, mp, flux, peak)
+
+
+def test_continuum_subtraction_removes_the_sources():
+    """frontend.make_dirty(..., subtract_model=True) (frontend.py:135-136): the façade's
+    continuum predictor, fed the true source list with `set_sky_arrays`, removes the three
+    synthetic sources from the dirty image; and it equals gridding the residuals that the
+    oracle's predictor computes from the same records."""
+    from helpers import make_params, kernel_taper, tapered_relerr
+    from katsdpimager_amd import frontend, imaging, parameters, preprocess, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS['predict']
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType.NATURAL, 0.0)
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    uvw, vis, weights = gi.e2e_raw(c)
+    coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], len(uvw))
+    coll.add(uvw, weights[None], vis[None, :, None].astype(np.complex64), None, None,
+             np.ones((1, 1), np.complex64), None)
+    coll.close()
+    reader = coll.reader()
+    # the sources of golden_inputs.e2e_raw: (l, m) in pixels and flux; vis carries flux / n
+    src_lm = np.array([[20, -33], [-41, 12], [5, 60]]) * c['pixel_size']
+    n = np.sqrt(1 - np.sum(src_lm ** 2, axis=1))
+    lmn = np.concatenate([src_lm, (n - 1)[:, None]], axis=1).astype(np.float32)
+    flux = (np.array([1.0, 0.6, 0.35]) / n)[:, None].astype(np.float32)
+    im = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp).instantiate(
+        q, ip, gp, c['vis_block'], 3, c['major'])
+    im.ensure_all_bound()
+    im.set_sky_arrays(lmn, flux)
+    mid_w = frontend.slice_mid_w(ip, gp)
+    frontend.make_weights(reader, 0, im, wp.weight_type, c['vis_block'])
+    frontend.make_dirty(reader, 0, 'vis', im, mid_w, c['vis_block'], False)
+    with_sources = im.get_buffer('dirty')
+    frontend.make_dirty(reader, 0, 'vis', im, mid_w, c['vis_block'], False, subtract_model=True)
+    subtracted = im.get_buffer('dirty')
+    assert np.abs(subtracted).max() < 0.1 * np.abs(with_sources).max()
+
+    # expectation: oracle predict on the stored records, gridded by the same device path
+    uv_scale, w_scale, w_bias = orc.uvw_scale_bias(c['cell_size'], c['wavelength'], c['max_w'],
+                                                   c['w_slices'], c['w_planes'], c['oversample'])
+
+    class Residuals:
+        """Host reader whose visibilities already have the model subtracted."""
+        def num_w_slices(self, ch):
+            return reader.num_w_slices(ch)
+
+        def len(self, ch, s):
+            return reader.len(ch, s)
+
+        def iter_slice(self, ch, s, block):
+            for rec in reader.iter_slice(ch, s, block):
+                rec = rec.copy()
+                v = np.ascontiguousarray(rec.vis)
+                orc.predict(v, rec.uv, rec.sub_uv, rec.w_plane, np.ascontiguousarray(rec.weights),
+                            lmn, flux, c['oversample'], uv_scale, w_scale,
+                            w_bias + mid_w[s])
+                rec.vis = v
+                yield rec
+    frontend.make_dirty(Residuals(), 0, 'vis', im, mid_w, c['vis_block'], False)
+    expected = im.get_buffer('dirty')
+    taper = kernel_taper(c)
+    scale = np.abs(with_sources).max() / np.abs(expected).max()
+    # the difference is the float32 phase error of the predicted part (2e-3 of the sources)
+    assert tapered_relerr(subtracted, expected, taper) < 2e-3 * scale
