@@ -161,6 +161,44 @@ def test_grid_degrid_odd_shapes(K, OV, W, P):
         assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
 
 
+def test_kernel_wider_than_mfma_window():
+    """K = 70 exceeds the 2 x 2 tap-block range: the automatic variant falls back to the
+    per-tap kernels, the explicit MFMA variant is refused (KIMG_EUNSUPPORTED)."""
+    from katsdpimager_amd import grid, _lib
+    ctx, q = context_queue()
+    c = gi.make_config(512, 0.0001, 0.01, 1, 70, 4, grid_cover=300, n_vis=300)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'auto', max_vis=512)
+    actual = _run_gridder(fn, q, t)
+    expected = np.zeros(actual.shape, np.complex64)
+    wg = np.zeros(actual.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(fn.convolve_kernel.data, expected, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(actual, expected) < GRID_TOL
+    fn2, q = _gridder(c, 'mfma', max_vis=512)
+    with pytest.raises(_lib.KimgError):
+        _run_gridder(fn2, q, t)
+    ip, gp, ap = make_params(c)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 512)
+    dg.ensure_all_bound()
+    G = dg.buffer('grid').shape[-1]
+    rs = gi.RandomState(70)
+    gdata = rs.complex_uniform(-1, 1, size=(1, G, G)).astype(np.complex64)
+    dg.buffer('grid').set(q, gdata)
+    n = len(t['uv'])
+    vis = rs.complex_uniform(-1, 1, size=(n, 1)).astype(np.complex64)
+    w = rs.uniform(0.5, 1.5, size=(n, 1)).astype(np.float32)
+    dg.num_vis = n
+    dg.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+    dg.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+    dg.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+    dg.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+    dg()
+    want = vis.copy()
+    orc.degrid(fn.convolve_kernel.data, gdata, t['uv'], t['sub_uv'], t['w_plane'], w, want)
+    assert np.abs(dg.buffer('vis').get(q)[:n] - want).max() <= 1e-5 * np.abs(want).max()
+
+
 def test_gridder_64_planes():
     """64 W-planes: the doubled LDS table does not fit, single-row variant (config 4)."""
     c = gi.make_config(256, 0.0001, 0.01, 2, 28, 64, grid_cover=180, n_vis=1000)
