@@ -52,15 +52,18 @@ const char *kimg_error_string(int code);
  *   w_plane         int16 [N]
  *   vis             complex64 [N][P]
  *   convolve_kernel complex64 [w_planes][oversample][kernel_width], unpadded
- *   workspace       scratch, at least kimg_grid_workspace_bytes(max N, P) bytes
+ *   workspace       device scratch, at least kimg_grid_workspace_bytes(max N, P, w_planes,
+ *                   oversample, kernel_width) bytes (0 unless the kernel table is too large for
+ *                   LDS -- more than 512 rows w_planes*oversample for widths <= 32, 256 for 33..64
+ *                   -- in which case a zero-padded copy of it is built there on every call)
  *   variant         0 = automatic; 1 = generic scatter kernel (any kernel width); 2 = MFMA window
- *                   kernel (kernel_width <= 64 and the kernel table(s) fit LDS:
- *                   w_planes*oversample <= 512 rows for widths <= 32, <= 256 for 33..64),
- *                   KIMG_EUNSUPPORTED otherwise.  Automatic = MFMA when supported.
+ *                   kernel (kernel_width <= 64), KIMG_EUNSUPPORTED otherwise.
+ *                   Automatic = MFMA when supported.
  *   Out-of-range coordinates (footprint outside the grid, sub_uv >= oversample, w_plane >=
  *   w_planes) contribute nothing instead of faulting.
  */
-size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations);
+size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations, int w_planes,
+                                 int oversample, int kernel_width);
 int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
               int num_polarizations,
               const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
@@ -77,7 +80,11 @@ int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stri
                 const int16_t *uv, const int16_t *w_plane, const float *weights, void *vis,
                 int64_t num_vis,
                 const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
-                void *stream);
+                void *workspace, size_t workspace_bytes, void *stream);
+/* Device scratch kimg_degrid needs (0 unless the kernel table is too large for LDS; then a padded
+ * copy of it is built there on every call, as for kimg_grid). */
+size_t kimg_degrid_workspace_bytes(int num_polarizations, int w_planes, int oversample,
+                                   int kernel_width);
 
 /* ---- direct prediction: predict.py:386-416 Predict._run + predict.mako:10-87
  * vis[r][p] -= weights[r][p] * sum_s flux[s][p] * exp(-2 pi i (l u + m v + (n-1) w)),

@@ -21,9 +21,10 @@ F = c_float
 PROTOTYPES = {
     'kimg_version': (c_int, []),
     'kimg_error_string': (c_char_p, [I]),
-    'kimg_grid_workspace_bytes': (c_size_t, [L, I]),
+    'kimg_grid_workspace_bytes': (c_size_t, [L, I, I, I, I]),
     'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, P]),
-    'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P]),
+    'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, P]),
+    'kimg_degrid_workspace_bytes': (c_size_t, [I, I, I, I]),
     'kimg_predict': (c_int, [P, P, P, P, P, P, L, I, I, I, F, F, F, P]),
     'kimg_grid_weights': (c_int, [P, L, L, I, I, I, P, P, L, P]),
     'kimg_mean_weight': (c_int, [P, P, L, I, I, P]),

@@ -80,22 +80,24 @@ struct tap_split {
     int tu0, Ku;
 };
 
-template <int P, int NW, int TAPS, bool TWO>
+// TG: table(s) too large for LDS are read from a padded copy in HBM (same row layout), see
+// grid_mfma.hip.
+template <int P, int NW, int TAPS, bool TWO, bool TG = false>
 __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
-    int p_total)
+    int p_total, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || TAPS == 32, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
-    const unsigned char *tbytes = smem;
+    const unsigned char *tbytes = TG ? padded : smem;
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW_BYTES;
     const int u_table = TWO ? table_bytes : 0;
-    unsigned char *rec_base = smem + (size_t) table_bytes * (TWO ? 2 : 1);
+    unsigned char *rec_base = smem + (TG ? 0 : (size_t) table_bytes * (TWO ? 2 : 1));
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // per-wave staging of 64 visibilities: (table offset for kv, for ku, mu, mv); mu = INT_MIN
@@ -130,9 +132,11 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             }
         }
     };
-    stage_table(smem, ts.tv0, ts.Kv);
-    if (TWO)
-        stage_table(smem + table_bytes, ts.tu0, ts.Ku);
+    if (!TG) {
+        stage_table(smem, ts.tv0, ts.Kv);
+        if (TWO)
+            stage_table(smem + table_bytes, ts.tu0, ts.Ku);
+    }
     __syncthreads();
 
     const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
@@ -330,6 +334,19 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     }
 }
 
+// HBM copy of the table in the LDS row layout: (TAPS + 1) taps per row, the 32 zero-padded taps
+// of [tap0, tap0 + Kp) once (TAPS = 32) or twice (TAPS = 64).
+template <int TAPS>
+__global__ __launch_bounds__(256) void pad_table_kernel(
+    const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * (TAPS + 1))
+        return;
+    const int row = idx / (TAPS + 1), c = idx % (TAPS + 1), t = c & 31;
+    out[idx] = (c < TAPS && t < Kp) ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
+}
+
 size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 {
     return (size_t) tables * W * OV * (taps + 1) * 8 + (size_t) NW * 64 * sizeof(int4);
@@ -337,15 +354,25 @@ size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int NW, int TAPS, bool TWO>
+template <int P, int NW, int TAPS, bool TWO, bool TG = false>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
-           const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream)
+           const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
+           unsigned char *padded = nullptr)
 {
-    const size_t lds = lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
+    const size_t lds = TG ? lds_bytes(NW, 0, 0, TAPS) : lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
+    if (TG) {
+        const int rows = W * OV;
+        float2 *out = reinterpret_cast<float2 *>(padded);
+        pad_table_kernel<TAPS><<<kimg_divup(rows * (TAPS + 1), 256), 256, 0, stream>>>(
+            kern, rows, ts.K, ts.tv0, ts.Kv, out);
+        if (TWO)
+            pad_table_kernel<TAPS><<<kimg_divup(rows * (TAPS + 1), 256), 256, 0, stream>>>(
+                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * (TAPS + 1));
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO>),
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO, TG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -355,26 +382,46 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    degrid_mfma_kernel<P, NW, TAPS, TWO><<<blocks, NW * 64, lds, stream>>>(
+    degrid_mfma_kernel<P, NW, TAPS, TWO, TG><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, ts,
-        vis_per_block, p_total);
+        vis_per_block, p_total, padded);
     return kimg_launch_status();
 }
 
 } // namespace
 
+static bool tables_fit_lds(int w_planes, int oversample, int kernel_width)
+{
+    return lds_bytes(12, w_planes, oversample, 32, kernel_width > WIN ? 2 : 1) <= LDS_LIMIT;
+}
+
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
-    if (P < 1 || P > 4 || kernel_width > 2 * WIN || kernel_width < 1)
-        return false;
-    return lds_bytes(12, w_planes, oversample, 32, kernel_width > WIN ? 2 : 1) <= LDS_LIMIT;
+    return P >= 1 && P <= 4 && kernel_width >= 1 && kernel_width <= 2 * WIN
+           && (int64_t) w_planes * oversample * 65 * 8 * 2 < ((int64_t) 1 << 31);
+}
+
+// Scratch for the padded HBM copy of the table (none when the tables fit LDS).
+size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
+{
+    if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width)
+        || tables_fit_lds(w_planes, oversample, kernel_width))
+        return 0;
+    return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
 }
 
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                      int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
-                     int w_planes, int oversample, int kernel_width, hipStream_t stream)
+                     int w_planes, int oversample, int kernel_width, void *workspace,
+                     size_t workspace_bytes, hipStream_t stream)
 {
+    const bool in_lds = tables_fit_lds(w_planes, oversample, kernel_width);
+    if (!in_lds && (workspace == nullptr
+                    || workspace_bytes < kimg_degrid_mfma_workspace_bytes(P, w_planes, oversample,
+                                                                         kernel_width)))
+        return KIMG_EWORKSPACE;
+    unsigned char *padded = static_cast<unsigned char *>(workspace);
     const int K = kernel_width;
     const bool wide = K > WIN;
     const int Kh = wide ? (K + 1) / 2 : K;
@@ -396,7 +443,16 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
         grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream)
                 const bool doubled = lds_bytes(12, w_planes, oversample, 64) <= LDS_LIMIT;
-                if (wide) {
+#define LAUNCH_TG(PP, NWV, TAPSV, TWOV) rc = launch<PP, NWV, TAPSV, TWOV, true>(g, grid_row_stride, \
+        grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
+        (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded)
+                if (!in_lds) {
+                    if (wide) {
+                        if (pn == 1) LAUNCH_TG(1, 12, 32, true); else LAUNCH_TG(2, 8, 32, true);
+                    } else {
+                        if (pn == 1) LAUNCH_TG(1, 12, 64, false); else LAUNCH_TG(2, 8, 64, false);
+                    }
+                } else if (wide) {
                     if (pn == 1) LAUNCH(1, 12, 32, true); else LAUNCH(2, 8, 32, true);
                 } else if (pn == 1) {
                     if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
@@ -404,6 +460,7 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                     if (doubled) LAUNCH(2, 8, 64, false); else LAUNCH(2, 8, 32, false);
                 }
 #undef LAUNCH
+#undef LAUNCH_TG
                 if (rc)
                     return rc;
             }

@@ -14,11 +14,13 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
                    void *workspace, size_t workspace_bytes, hipStream_t stream);
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
-size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P);
+size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                      int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
-                     int w_planes, int oversample, int kernel_width, hipStream_t stream);
+                     int w_planes, int oversample, int kernel_width, void *workspace,
+                     size_t workspace_bytes, hipStream_t stream);
+size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 
 namespace {
@@ -250,9 +252,11 @@ int check_grid_args(int grid_size, int P, int64_t num_vis, int w_planes, int ove
 
 } // namespace
 
-extern "C" size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations)
+extern "C" size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations, int w_planes,
+                                           int oversample, int kernel_width)
 {
-    return kimg_grid_mfma_workspace_bytes(max_vis, num_polarizations);
+    (void) max_vis;
+    return kimg_grid_mfma_workspace_bytes(num_polarizations, w_planes, oversample, kernel_width);
 }
 
 extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
@@ -299,11 +303,18 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     return kimg_launch_status();
 }
 
+extern "C" size_t kimg_degrid_workspace_bytes(int num_polarizations, int w_planes, int oversample,
+                                             int kernel_width)
+{
+    return kimg_degrid_mfma_workspace_bytes(num_polarizations, w_planes, oversample, kernel_width);
+}
+
 extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                            int grid_size, int num_polarizations, const int16_t *uv,
                            const int16_t *w_plane, const float *weights, void *vis,
                            int64_t num_vis, const void *convolve_kernel, int w_planes,
-                           int oversample, int kernel_width, void *stream)
+                           int oversample, int kernel_width, void *workspace,
+                           size_t workspace_bytes, void *stream)
 {
     KIMG_CHECK_ARG(grid && uv && w_plane && weights && vis && convolve_kernel);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
@@ -322,7 +333,8 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
         && kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample, kernel_width))
         return kimg_degrid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
                                 num_polarizations, uv, w_plane, weights, vis, num_vis,
-                                convolve_kernel, w_planes, oversample, kernel_width, s);
+                                convolve_kernel, w_planes, oversample, kernel_width, workspace,
+                                workspace_bytes, s);
     int blocks = kimg_divup(num_vis, 4);
     if (blocks > 16384)
         blocks = 16384;

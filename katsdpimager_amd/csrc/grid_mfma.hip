@@ -34,6 +34,7 @@
 #include "kimg_common.h"
 #include <limits.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -171,21 +172,25 @@ struct tap_split {
     int tu0, Ku;        // column (u) taps of this launch
 };
 
-template <int P, int NW, int SUB, int ROW, bool TWO>
+// TG: the padded table(s) do not fit LDS (many W planes: the reference's default w-step gives
+// hundreds per slice) and are read from a zero-padded copy in HBM instead ([rows][32] taps,
+// built per call by pad_table_kernel; served by L1/L2 -- rows recur along a track).  Everything
+// else is unchanged; only the operand reads are global loads.
+template <int P, int NW, int SUB, int ROW, bool TWO, bool TG = false>
 __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const float *__restrict__ weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float2 *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
-    int p_total, int dbg)
+    int p_total, int dbg, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || ROW == 32, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW * (int) sizeof(float2);
     const int u_table = TWO ? table_bytes : 0;           // byte offset of the column-tap table
-    unsigned char *rec_base = smem + (size_t) table_bytes * (TWO ? 2 : 1);
+    unsigned char *rec_base = smem + (TG ? 0 : (size_t) table_bytes * (TWO ? 2 : 1));
     // wave index: uniform by construction, but the compiler must be told (readfirstlane),
     // or every loop below is lowered to divergent (exec-masked) control flow
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                       + wib * 64 * P;
     int2 *origins = reinterpret_cast<int2 *>(rec_base + (size_t) NW * 64 * (sizeof(int2) + P * sizeof(float4)))
                     + wib * 64;
-    const unsigned char *tbytes = smem;
+    const unsigned char *tbytes = TG ? padded : smem;
 
     // This wave's contiguous range.
     const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
@@ -284,9 +289,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             }
         }
     };
-    stage_table(smem, ts.tv0, ts.Kv);
-    if (TWO)
-        stage_table(smem + table_bytes, ts.tu0, ts.Ku);
+    if (!TG) {
+        stage_table(smem, ts.tv0, ts.Kv);
+        if (TWO)
+            stage_table(smem + table_bytes, ts.tu0, ts.Ku);
+    }
     __syncthreads();
     if (!active)
         return;
@@ -527,6 +534,19 @@ constexpr int waves_per_block()
     return 8;
 }
 
+// Zero-padded copy of taps [tap0, tap0 + Kp) of every table row: [rows][ROW] float2 (ROW = 64:
+// the 32 taps twice).
+template <int ROW>
+__global__ __launch_bounds__(256) void pad_table_kernel(
+    const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * ROW)
+        return;
+    const int row = idx / ROW, t = idx & 31;
+    out[idx] = t < Kp ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
+}
+
 size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 {
     return (size_t) tables * W * OV * row * sizeof(float2)
@@ -535,18 +555,29 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int ROW, int NW, bool TWO>
+template <int P, int ROW, int NW, bool TWO, bool TG = false>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
-           int W, int OV, const tap_split &ts, int p_total, hipStream_t stream)
+           int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
+           unsigned char *padded = nullptr)
 {
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
-    const size_t lds = lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
+    const size_t lds = TG ? lds_bytes(P, NW, 0, 0, ROW) : lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
+    if (TG) {
+        // the padded table(s) of this launch: row taps first, column taps behind them
+        const int rows = W * OV;
+        float2 *out = reinterpret_cast<float2 *>(padded);
+        pad_table_kernel<ROW><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
+            kern, rows, ts.K, ts.tv0, ts.Kv, out);
+        if (TWO)
+            pad_table_kernel<ROW><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
+                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * ROW);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         KIMG_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO>),
+            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -559,16 +590,16 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     }
     // as many blocks resident per CU as the LDS (kernel table + staging) allows;
     // every block streams a contiguous span (a multiple of 64).
-    const int per_cu = lds <= LDS_LIMIT / 2 ? 2 : 1;
+    const int per_cu = (!TG && lds <= LDS_LIMIT / 2) ? 2 : 1;
     const int blocks_max = blocks_max_env > 0 ? blocks_max_env : 256 * per_cu;
     int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
     vis_per_block = (vis_per_block + 63) / 64 * 64;
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    grid_mfma_kernel<P, NW, SUB, ROW, TWO><<<blocks, NW * 64, lds, stream>>>(
+    grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg);
+        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded);
     return kimg_launch_status();
 }
 
@@ -577,19 +608,27 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
 // The kernels are instantiated for 1 and 2 polarizations (32 accumulator registers each keep
 // two waves per SIMD without spills); 3 or 4 polarizations run as 2 + 1 / 2 + 2.  Kernel widths
 // 33..64 run as 2 x 2 tap blocks with two single-row tables in LDS.
-bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
+static bool tables_fit_lds(int P, int w_planes, int oversample, int kernel_width)
 {
-    if (P < 1 || P > 4 || kernel_width > 2 * WIN || kernel_width < 1)
-        return false;
     const int tables = kernel_width > WIN ? 2 : 1;
     return lds_bytes(P > 1 ? 2 : 1, 8, w_planes, oversample, 32, tables) <= LDS_LIMIT;
 }
 
-size_t kimg_grid_mfma_workspace_bytes(int64_t max_vis, int P)
+bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
-    (void) max_vis;
-    (void) P;
-    return 0;       // records are staged through LDS; no HBM scratch needed
+    // any number of W planes: tables that do not fit LDS are read from a padded copy in HBM
+    return P >= 1 && P <= 4 && kernel_width >= 1 && kernel_width <= 2 * WIN
+           && (int64_t) w_planes * oversample * 256 * 2 < ((int64_t) 1 << 31);
+}
+
+// Scratch for the padded table copy (none when the tables fit LDS).
+size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
+{
+    if (!kimg_grid_mfma_supported(P, w_planes, oversample, kernel_width))
+        return 0;
+    if (tables_fit_lds(P, w_planes, oversample, kernel_width) && !getenv("KIMG_GRID_TABLE"))
+        return 0;
+    return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
 }
 
 int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
@@ -598,8 +637,17 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
                    void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    (void) workspace;
-    (void) workspace_bytes;
+    static int table_env = -1;
+    if (table_env < 0) {
+        const char *e = getenv("KIMG_GRID_TABLE");      // "hbm32" / "hbm64": timing experiments
+        table_env = !e ? 0 : (strcmp(e, "hbm32") == 0 ? 32 : (strcmp(e, "hbm64") == 0 ? 64 : 0));
+    }
+    const bool in_lds = tables_fit_lds(P, w_planes, oversample, kernel_width) && table_env == 0;
+    if (!in_lds && (workspace == nullptr
+                    || workspace_bytes < kimg_grid_mfma_workspace_bytes(P, w_planes, oversample,
+                                                                       kernel_width)))
+        return KIMG_EWORKSPACE;
+    unsigned char *padded = static_cast<unsigned char *>(workspace);
     static int nw_env = -1;
     if (nw_env < 0) {
         const char *e = getenv("KIMG_GRID_WAVES");      // timing experiments only
@@ -627,7 +675,32 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 #define LAUNCH(PP, ROWV, NWV, TWOV) rc = launch<PP, ROWV, NWV, TWOV>(g, grid_row_stride, \
         grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, \
         w_planes, oversample, ts, P, stream)
-                if (wide) {
+                if (!in_lds) {
+                    // table(s) in HBM; 12-wave blocks (P = 1) as for the LDS form
+                    if (wide) {
+                        if (pn == 1)
+                            rc = launch<1, 32, 12, true, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
+                                kern, w_planes, oversample, ts, P, stream, padded);
+                        else
+                            rc = launch<2, 32, 8, true, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
+                                kern, w_planes, oversample, ts, P, stream, padded);
+                    } else if (pn == 1 && table_env != 32) {
+                        // doubled rows (no wrap arithmetic): 5 % faster than single rows
+                        rc = launch<1, 64, 12, false, true>(g, grid_row_stride, grid_pol_stride,
+                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
+                            kern, w_planes, oversample, ts, P, stream, padded);
+                    } else if (pn == 1) {
+                        rc = launch<1, 32, 12, false, true>(g, grid_row_stride, grid_pol_stride,
+                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
+                            kern, w_planes, oversample, ts, P, stream, padded);
+                    } else {
+                        rc = launch<2, 64, 8, false, true>(g, grid_row_stride, grid_pol_stride,
+                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
+                            kern, w_planes, oversample, ts, P, stream, padded);
+                    }
+                } else if (wide) {
                     if (pn == 1)
                         LAUNCH(1, 32, 8, true);
                     else

@@ -247,7 +247,9 @@ class Gridder(GridDegrid):
         super().__init__(*args, **kwargs)
         self.slots['weights_grid'] = accel.IOSlot(self.slots['grid'].shape, np.float32)
         num_pols = self.slots['grid'].shape[0]
-        nbytes = lib().kimg_grid_workspace_bytes(self.max_vis, num_pols)
+        table = self.convolve_kernel.padded_data
+        nbytes = lib().kimg_grid_workspace_bytes(self.max_vis, num_pols, table.shape[0],
+                                                 table.shape[1], table.shape[2])
         self._workspace = None
         self._workspace_bytes = nbytes
         if nbytes:
@@ -295,6 +297,13 @@ class Degridder(GridDegrid):
         num_pols = self.slots['grid'].shape[0]
         self.slots['weights'] = accel.IOSlot(
             (self.max_vis, accel.Dimension(num_pols, exact=True)), np.float32)
+        table = self.convolve_kernel.padded_data
+        nbytes = lib().kimg_degrid_workspace_bytes(num_pols, table.shape[0], table.shape[1],
+                                                   table.shape[2])
+        self._workspace = None
+        self._workspace_bytes = nbytes
+        if nbytes:
+            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8)
 
     def _run(self):
         grid = self.buffer('grid')
@@ -303,5 +312,7 @@ class Degridder(GridDegrid):
         rc = lib().kimg_degrid(
             grid.ptr, G, G * G, G, P,
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('weights').ptr,
-            self.buffer('vis').ptr, self.num_vis, table, W, OV, K, self.command_queue.handle)
+            self.buffer('vis').ptr, self.num_vis, table, W, OV, K,
+            self._workspace.ptr if self._workspace is not None else None, self._workspace_bytes,
+            self.command_queue.handle)
         check(rc, 'kimg_degrid')

@@ -161,6 +161,74 @@ def test_grid_degrid_odd_shapes(K, OV, W, P):
         assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
 
 
+@pytest.mark.parametrize('K,W,P', [(28, 128, 1), (28, 300, 2), (16, 96, 4), (60, 48, 1), (45, 64, 3)])
+def test_gridder_many_w_planes(K, W, P):
+    """More W planes than an LDS-resident table allows (the reference's default w-step gives
+    hundreds per slice): the MFMA gridder reads a padded copy of the table from HBM instead.
+    Smooth track and scattered positions over all planes, against the oracle; the result must
+    also agree with the per-tap kernel."""
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1500)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'mfma', max_vis=2048)
+    assert fn._workspace_bytes > 0
+    kernel = fn.convolve_kernel.data
+    rs = gi.RandomState(K + W)
+    n2 = 900
+    half = t['weights_grid'].shape[-1] // 2 - 1
+    scattered = dict(
+        uv=rs.randint(-half, half, (n2, 2)).astype(np.int16),
+        sub_uv=rs.randint(0, 8, (n2, 2)).astype(np.int16),
+        w_plane=rs.randint(0, W, n2).astype(np.int16), weights_grid=t['weights_grid'],
+        vis=rs.complex_uniform(-1, 1, size=(n2, P)).astype(np.complex64))
+    fg, _ = _gridder(c, 'generic', max_vis=2048)
+    for data in (t, scattered):
+        actual = _run_gridder(fn, q, data)
+        expected = np.zeros(actual.shape, np.complex64)
+        wg = np.zeros(actual.shape, np.float32)
+        gi.middle(wg, data['weights_grid'].shape)[:] = data['weights_grid']
+        orc.grid(kernel, expected, wg, data['uv'], data['sub_uv'], data['w_plane'], data['vis'])
+        assert relerr(actual, expected) < GRID_TOL
+        assert relerr(_run_gridder(fg, q, data), actual) < GRID_TOL
+
+
+@pytest.mark.parametrize('K,W,P', [(28, 128, 1), (28, 300, 2), (16, 96, 4), (60, 48, 1), (45, 64, 3)])
+def test_degridder_many_w_planes(K, W, P):
+    """The degridder with its table in HBM (more W planes than LDS holds), against the oracle."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1500)
+    t = gi.grid_track(c)
+    ip, gp, ap = make_params(c)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn.ensure_all_bound()
+    assert fn._workspace_bytes > 0
+    G = fn.buffer('grid').shape[-1]
+    rs = gi.RandomState(K + W + 1)
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    fn.buffer('grid').set(q, gdata)
+    kernel = fn.convolve_kernel.data
+    half = t['weights_grid'].shape[-1] // 2 - 1
+    n2 = 900
+    cases = [(np.concatenate((t['uv'], t['sub_uv']), axis=1), t['w_plane']),
+             (np.concatenate([rs.randint(-half, half, (n2, 2)), rs.randint(0, 8, (n2, 2))],
+                             axis=1).astype(np.int16), rs.randint(0, W, n2).astype(np.int16))]
+    for uv, wp in cases:
+        n = len(uv)
+        vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+        w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
+        fn.num_vis = n
+        fn.buffer('uv').set_region(q, uv, np.s_[:n], np.s_[:])
+        fn.buffer('w_plane').set_region(q, wp, np.s_[:n], np.s_[:])
+        fn.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+        fn.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+        fn()
+        expected = vis.copy()
+        orc.degrid(kernel, gdata, np.ascontiguousarray(uv[:, :2]), np.ascontiguousarray(uv[:, 2:]),
+                   wp, w, expected)
+        actual = fn.buffer('vis').get(q)[:n]
+        assert np.abs(actual - expected).max() <= 1e-5 * np.abs(expected).max()
+
+
 def test_kernel_wider_than_mfma_window():
     """K = 70 exceeds the 2 x 2 tap-block range: the automatic variant falls back to the
     per-tap kernels, the explicit MFMA variant is refused (KIMG_EUNSUPPORTED)."""
