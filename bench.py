@@ -246,6 +246,34 @@ def main():
             host_chunk()
         q.finish()
         sec['grid_host_chunks_Mvis_per_s'] = round(8 * vb / (time.perf_counter() - t0) / 1e6, 1)
+        # many W planes (the reference's default w-step gives hundreds per slice): the kernel
+        # table no longer fits LDS and is read from a padded copy in HBM
+        del host_fn, big
+        n2 = min(n_vis, 16 * vb)
+        obs2 = synth.make_observation(G, n2, 256, P, device=dev, seed=5)
+        ip2, gp2, ap2 = synth.make_parameters(obs2, P, K)
+        fn2 = template.instantiate(q, ap2, ip2, gp2, vb)
+        grid2 = accel.DeviceArray(ctx, fn2.slots['grid'].shape, np.complex64)
+        wg2 = accel.DeviceArray(ctx, fn2.slots['grid'].shape, np.float32,
+                                tensor=torch.ones(fn2.slots['grid'].shape, device=dev))
+        fn2.bind(grid=grid2, weights_grid=wg2)
+        fn2.ensure_all_bound()
+        torch.cuda.synchronize()
+
+        def grid_obs2():
+            for start in range(0, n2 - vb + 1, vb):
+                sl = slice(start, start + vb)
+                fn2.bind(uv=accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=obs2.uv[sl]),
+                         w_plane=accel.DeviceArray(ctx, (vb,), np.int16, tensor=obs2.w_plane[sl]),
+                         vis=accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=obs2.vis[sl]))
+                fn2.num_vis = vb
+                fn2._run()
+        grid_obs2()
+        q.finish()
+        t0 = time.perf_counter()
+        grid_obs2()
+        q.finish()
+        sec['grid_256_planes_Mvis_per_s'] = round((n2 // vb) * vb / (time.perf_counter() - t0) / 1e6, 1)
         if args.major_loop:
             # PSF pass grids the weights as visibilities (frontend.py:511)
             wt_all = padded(obs.weights)
