@@ -28,6 +28,9 @@ def main(argv=None):
     ap.add_argument('--major', type=int, default=3)
     ap.add_argument('--minor', type=int, default=500)
     ap.add_argument('--vis-block', type=int, default=1 << 20)
+    ap.add_argument('--w-planes', type=int, default=32,
+                    help='W planes per slice (more than 64: the kernel table is read from HBM)')
+    ap.add_argument('--kernel-width', type=int, default=28)
     args = ap.parse_args(argv)
     import torch
     import synth
@@ -36,8 +39,8 @@ def main(argv=None):
     ctx = accel.create_some_context()
     queue = ctx.create_command_queue()
     # array geometry, uvw tracks (metres) and the matching imaging parameters
-    obs = synth.make_observation(args.pixels, args.vis, 32, 1, device=ctx.device)
-    image_p, grid_p, array_p = synth.make_parameters(obs, 1, 28, degrid=True)
+    obs = synth.make_observation(args.pixels, args.vis, args.w_planes, 1, device=ctx.device)
+    image_p, grid_p, array_p = synth.make_parameters(obs, 1, args.kernel_width, degrid=True)
     # three point sources -> raw visibilities (the loader's job in the reference)
     sources = [((40, -25), 1.0), ((-120, 60), 0.5), ((15, 200), 0.25)]      # (l, m) in pixels, Jy
     uvw_wl = obs.uvw.to(torch.float64) / obs.wavelength
