@@ -206,18 +206,26 @@ __global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
     const int32_t *__restrict__ tile_pos, int num_tiles, float loop_gain, float threshold,
     clean_state *__restrict__ state, float *__restrict__ log)
 {
-    if (state->done)
-        return;
+    // The kernel is a chain of dependent memory round trips; keep it short: the state words are
+    // fetched together with the tile maxima (not before them), and the pixel and model values of
+    // all polarizations are fetched together before anything is stored.
+    const int done = state->done, count = state->count, limit = state->limit;
     float value;
     int t = peak_tile(tile_max, num_tiles, value);
-    if (threadIdx.x != 0)
+    if (threadIdx.x != 0 || done)
         return;
-    if (t < 0 || value < threshold || state->count >= state->limit) {   // clean.py:1065-1066
+    if (t < 0 || value < threshold || count >= limit) {   // clean.py:1065-1066
         state->done = 1;
         return;
     }
     const int y = tile_pos[2 * t], x = tile_pos[2 * t + 1];
-    float *entry = log + (int64_t) state->count * (3 + P);
+    float pix[4], mod[4];
+    for (int p = 0; p < P; p++) {
+        const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
+        pix[p] = dirty[a];
+        mod[p] = model[a];
+    }
+    float *entry = log + (int64_t) count * (3 + P);
     entry[0] = value;
     entry[1] = __int_as_float(y);
     entry[2] = __int_as_float(x);
@@ -225,12 +233,12 @@ __global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
     state->pos_x = x;
     for (int p = 0; p < P; p++) {
         const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
-        const float s = loop_gain * dirty[a];   // clean.py:1044
+        const float s = loop_gain * pix[p];     // clean.py:1044
         state->scale[p] = s;
         entry[3 + p] = s;
-        model[a] += s;                          // clean.py:1047
+        model[a] = mod[p] + s;                  // clean.py:1047
     }
-    state->count += 1;
+    state->count = count + 1;
 }
 
 // One workgroup per 32x32 block of the tile lattice that the PSF patch can touch: subtract
@@ -244,9 +252,14 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     float *__restrict__ tile_max, int32_t *__restrict__ tile_pos, int tiles_x, int tiles_y,
     const clean_state *__restrict__ state)
 {
-    if (state->done)
-        return;
+    // one round trip for all the state words (they share a cache line)
+    const int done = state->done;
     const int px = state->pos_x, py = state->pos_y;
+    float scale[4];
+    for (int p = 0; p < 4; p++)
+        scale[p] = state->scale[p];
+    if (done)
+        return;
     const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
     // floor division: the lattice extends into the border with negative indices
     const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
@@ -255,9 +268,6 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     const int ox = tx * TILE + border, oy = ty * TILE + border;
     const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;  // psf index = image index + d
     const bool is_tile = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;
-    float scale[4];
-    for (int p = 0; p < P; p++)
-        scale[p] = state->scale[p];
 
     best_t b = {0.0f, INT_MAX};
 #pragma unroll
