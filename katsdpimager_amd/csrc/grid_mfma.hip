@@ -344,11 +344,13 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     };
 
     // LDS byte addresses of this lane's row tap / column tap for a staged record
+    // (unsigned: with the table in HBM the 32-bit offset then rides on the scalar base pointer
+    // -- global_load v, v_off, s[base] -- instead of costing a sign extension and a 64-bit add)
     auto addr_v = [&](int ry) __attribute__((always_inline)) {
-        return ROW == 64 ? ry + lane_v : (ry & ~0xff) | ((ry + lane_v) & 0xf8);
+        return (unsigned) (ROW == 64 ? ry + lane_v : (ry & ~0xff) | ((ry + lane_v) & 0xf8));
     };
     auto addr_u = [&](int rx) __attribute__((always_inline)) {
-        return ROW == 64 ? rx + lane_u : (rx & ~0xff) | ((rx + lane_u) & 0xfc);
+        return (unsigned) (ROW == 64 ? rx + lane_u : (rx & ~0xff) | ((rx + lane_u) & 0xfc));
     };
 
     // ---- software-pipeline stages over sub-blocks of SUB staged visibilities ---------------
@@ -361,10 +363,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     auto stage_b = [&](sub_ops<P, SUB> &o, int first) __attribute__((always_inline)) {     // sample + kernel-table reads
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
-            const int au = addr_u(rec[t].x);
+            const unsigned au = addr_u(rec[t].x);
             o.kv[t] = *reinterpret_cast<const float2 *>(tbytes + addr_v(rec[t].y));
             o.b0[t] = *reinterpret_cast<const float *>(tbytes + au);
-            o.b1[t] = *reinterpret_cast<const float *>(tbytes + (ROW == 64 ? au + 128 : au ^ 128));  // column + 16
+            o.b1[t] = *reinterpret_cast<const float *>(                                  // column + 16
+                ROW == 64 ? tbytes + au + 128 : tbytes + (au ^ 128u));
 #pragma unroll
             for (int p = 0; p < P; p++)
                 o.c[p][t] = *reinterpret_cast<const float2 *>(
@@ -410,10 +413,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             fit_window(__builtin_amdgcn_readfirstlane(org.x), __builtin_amdgcn_readfirstlane(org.x),
                        __builtin_amdgcn_readfirstlane(org.y), __builtin_amdgcn_readfirstlane(org.y));
             const int2 r = recs[idx];
-            const int au = addr_u(r.x);
+            const unsigned au = addr_u(r.x);
             const float2 kv = *reinterpret_cast<const float2 *>(tbytes + addr_v(r.y));
             const float b0 = *reinterpret_cast<const float *>(tbytes + au) * b_sign;
-            const float b1 = *reinterpret_cast<const float *>(tbytes + (ROW == 64 ? au + 128 : au ^ 128)) * b_sign;
+            const float b1 = *reinterpret_cast<const float *>(
+                ROW == 64 ? tbytes + au + 128 : tbytes + (au ^ 128u)) * b_sign;
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const float a = fmaf(c[p].x, kv.x, c[p].y * kv.y);
