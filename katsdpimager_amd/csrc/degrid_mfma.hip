@@ -23,6 +23,7 @@
 // Algorithmic work per visibility: 8*K*K*P flop; executed 2 MFMA x 4096 flop per polarization.
 #include "kimg_common.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
     int p_total, const unsigned char *__restrict__ padded)
 {
-    static_assert(!TWO || TAPS == 32, "two tables only fit LDS with single rows");
+    static_assert(!TWO || TAPS == 32 || TG, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = TG ? padded : smem;
@@ -405,8 +406,8 @@ bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_
 size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
 {
     if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width)
-        || tables_fit_lds(w_planes, oversample, kernel_width))
-        return 0;
+        || (tables_fit_lds(w_planes, oversample, kernel_width) && !getenv("KIMG_DEGRID_TABLE")))
+        return 0;       // (with the experiment variable set, scratch is reserved either way)
     return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
 }
 
@@ -416,7 +417,8 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                      int w_planes, int oversample, int kernel_width, void *workspace,
                      size_t workspace_bytes, hipStream_t stream)
 {
-    const bool in_lds = tables_fit_lds(w_planes, oversample, kernel_width);
+    const char *tenv = getenv("KIMG_DEGRID_TABLE");        // "hbm": timing experiments only
+    const bool in_lds = tables_fit_lds(w_planes, oversample, kernel_width) && !(tenv && tenv[0]);
     if (!in_lds && (workspace == nullptr
                     || workspace_bytes < kimg_degrid_mfma_workspace_bytes(P, w_planes, oversample,
                                                                          kernel_width)))
@@ -448,7 +450,7 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded)
                 if (!in_lds) {
                     if (wide) {
-                        if (pn == 1) LAUNCH_TG(1, 12, 32, true); else LAUNCH_TG(2, 8, 32, true);
+                        if (pn == 1) LAUNCH_TG(1, 12, 64, true); else LAUNCH_TG(2, 8, 64, true);
                     } else {
                         if (pn == 1) LAUNCH_TG(1, 12, 64, false); else LAUNCH_TG(2, 8, 64, false);
                     }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
     int p_total, int dbg, const unsigned char *__restrict__ padded)
 {
-    static_assert(!TWO || ROW == 32, "two tables only fit LDS with single rows");
+    static_assert(!TWO || ROW == 32 || TG, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW * (int) sizeof(float2);
@@ -625,12 +625,27 @@ bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_wi
            && (int64_t) w_planes * oversample * 256 * 2 < ((int64_t) 1 << 31);
 }
 
-// Scratch for the padded table copy (none when the tables fit LDS).
+// Where the kernel reads its table from: LDS when it fits -- except for wide kernels, whose two
+// single-row tables in LDS leave room for 8 waves only and lose to doubled rows in HBM with 12
+// (1.46 vs 1.63 Gvis/s at K = 60).  KIMG_GRID_TABLE = lds / hbm32 / hbm64 overrides (experiments).
+static bool table_in_lds(int P, int w_planes, int oversample, int kernel_width)
+{
+    const char *e = getenv("KIMG_GRID_TABLE");
+    const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
+    if (e && strcmp(e, "lds") == 0)
+        return fits;
+    if (e && strncmp(e, "hbm", 3) == 0)
+        return false;
+    return fits && kernel_width <= WIN;
+}
+
+// Scratch for the padded table copy (none when the kernel reads its table from LDS).
 size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
 {
     if (!kimg_grid_mfma_supported(P, w_planes, oversample, kernel_width))
         return 0;
-    if (tables_fit_lds(P, w_planes, oversample, kernel_width) && !getenv("KIMG_GRID_TABLE"))
+    const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
+    if (fits && kernel_width <= WIN && !getenv("KIMG_GRID_TABLE"))
         return 0;
     return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
 }
@@ -646,7 +661,7 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
         const char *e = getenv("KIMG_GRID_TABLE");      // "hbm32" / "hbm64": timing experiments
         table_env = !e ? 0 : (strcmp(e, "hbm32") == 0 ? 32 : (strcmp(e, "hbm64") == 0 ? 64 : 0));
     }
-    const bool in_lds = tables_fit_lds(P, w_planes, oversample, kernel_width) && table_env == 0;
+    const bool in_lds = table_in_lds(P, w_planes, oversample, kernel_width);
     if (!in_lds && (workspace == nullptr
                     || workspace_bytes < kimg_grid_mfma_workspace_bytes(P, w_planes, oversample,
                                                                        kernel_width)))
@@ -683,11 +698,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                     // table(s) in HBM; 12-wave blocks (P = 1) as for the LDS form
                     if (wide) {
                         if (pn == 1)
-                            rc = launch<1, 32, 12, true, true>(g, grid_row_stride, grid_pol_stride,
+                            rc = launch<1, 64, 12, true, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
                                 kern, w_planes, oversample, ts, P, stream, padded);
                         else
-                            rc = launch<2, 32, 8, true, true>(g, grid_row_stride, grid_pol_stride,
+                            rc = launch<2, 64, 8, true, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
                                 kern, w_planes, oversample, ts, P, stream, padded);
                     } else if (pn == 1 && table_env != 32) {
