@@ -81,8 +81,10 @@ struct tap_split {
     int tu0, Ku;
 };
 
-// TG: table(s) too large for LDS are read from a padded copy in HBM (same row layout), see
-// grid_mfma.hip.
+// TG: table(s) too large for LDS (hundreds of W planes) stay in HBM as [rows][32] zero-padded
+// taps (pad_rows_kernel, rebuilt per call in the caller's workspace).  Each wave copies the 2 x 16
+// rows its current 16 visibilities need into a private LDS cache (coalesced 16-byte loads: a row
+// is 256 bytes) and then works exactly like the single-row LDS form (TAPS must be 32).
 template <int P, int NW, int TAPS, bool TWO, bool TG = false>
 __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
@@ -98,12 +100,17 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW_BYTES;
     const int u_table = TWO ? table_bytes : 0;
+    static_assert(!TG || TAPS == 32, "the row cache uses single rows");
     unsigned char *rec_base = smem + (TG ? 0 : (size_t) table_bytes * (TWO ? 2 : 1));
+    constexpr int CACHE_ROW = 272;                      // bytes per cached row (34 taps: 16-byte aligned)
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // per-wave staging of 64 visibilities: (table offset for kv, for ku, mu, mv); mu = INT_MIN
     // marks a visibility to skip
     int4 *recs = reinterpret_cast<int4 *>(rec_base) + wib * 64;
+    // TG: per-wave cache of the rows of the current 16 visibilities (row taps, then column taps)
+    unsigned char *cache_v = rec_base + (size_t) NW * 64 * sizeof(int4) + (size_t) wib * 2 * BATCH * CACHE_ROW;
+    unsigned char *cache_u = cache_v + BATCH * CACHE_ROW;
 
     // Stage the kernel table: rows zero-padded to 32 taps, stored twice, stride 65 taps.
     // A thread issues all loads of a round before its first LDS write (one L2 round trip per
@@ -245,6 +252,29 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             if (lo_u > hi_u)
                 continue;                               // nothing to do in this group
             const int4 rec = recs[first + b_lane];      // this lane's visibility of the group
+            if (TG) {
+                // lane l copies quarter l & 3 (64 bytes) of the rows of visibility l >> 2
+                const int4 rr = recs[first + (lane >> 2)];
+                const unsigned row_v = (unsigned) rr.x >> 16, row_u = (unsigned) rr.y >> 16;
+                const float4 *src_v = reinterpret_cast<const float4 *>(
+                    padded + (size_t) row_v * 256) + (lane & 3) * 4;
+                const float4 *src_u = reinterpret_cast<const float4 *>(
+                    padded + (TWO ? (size_t) table_rows * 256 : 0) + (size_t) row_u * 256) + (lane & 3) * 4;
+                float4 tv[4], tu[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    tv[i] = src_v[i];
+                    tu[i] = src_u[i];
+                }
+                float4 *dst_v = reinterpret_cast<float4 *>(cache_v + (lane >> 2) * CACHE_ROW) + (lane & 3) * 4;
+                float4 *dst_u = reinterpret_cast<float4 *>(cache_u + (lane >> 2) * CACHE_ROW) + (lane & 3) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    dst_v[i] = tv[i];
+                    dst_u[i] = tu[i];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             const int mu = rec.z, mv = rec.w;
             const bool mine = mu != INT_MIN;
             unsigned long long pending = __ballot(mine);
@@ -283,8 +313,9 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
 #pragma unroll
                     for (int k = 0; k < 16; k++)
                         acc[p][k] = 0.0f;
-                const unsigned char *pv = tbytes + (TAPS == 64 ? rec.x : (rec.x >> 16) * ROW_BYTES)
-                                          + b_comp;
+                const unsigned char *pv = TG ? cache_v + b_lane * CACHE_ROW + b_comp
+                                             : tbytes + (TAPS == 64 ? rec.x : (rec.x >> 16) * ROW_BYTES)
+                                                   + b_comp;
                 const int off_v = rec.x & 0xff;
 #pragma unroll
                 for (int y = 0; y < WIN; y++) {
@@ -295,8 +326,9 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
                 }
                 // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
-                const unsigned char *pu = tbytes + u_table
-                                          + (TAPS == 64 ? rec.y + h32 : (rec.y >> 16) * ROW_BYTES);
+                const unsigned char *pu = TG ? cache_u + b_lane * CACHE_ROW
+                                             : tbytes + u_table
+                                                   + (TAPS == 64 ? rec.y + h32 : (rec.y >> 16) * ROW_BYTES);
                 const int off_u = (rec.y & 0xff) + h32;
                 float sum[P];
 #pragma unroll
@@ -348,6 +380,17 @@ __global__ __launch_bounds__(256) void pad_table_kernel(
     out[idx] = (c < TAPS && t < Kp) ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
 }
 
+// TG: [rows][32] zero-padded taps (256-byte rows).
+__global__ __launch_bounds__(256) void pad_rows_kernel(
+    const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * 32)
+        return;
+    const int row = idx >> 5, t = idx & 31;
+    out[idx] = t < Kp ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
+}
+
 size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 {
     return (size_t) tables * W * OV * (taps + 1) * 8 + (size_t) NW * 64 * sizeof(int4);
@@ -361,15 +404,16 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
            const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
            unsigned char *padded = nullptr)
 {
-    const size_t lds = TG ? lds_bytes(NW, 0, 0, TAPS) : lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
+    const size_t lds = TG ? lds_bytes(NW, 0, 0, TAPS) + (size_t) NW * 2 * BATCH * 272
+                          : lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
     if (TG) {
         const int rows = W * OV;
         float2 *out = reinterpret_cast<float2 *>(padded);
-        pad_table_kernel<TAPS><<<kimg_divup(rows * (TAPS + 1), 256), 256, 0, stream>>>(
-            kern, rows, ts.K, ts.tv0, ts.Kv, out);
+        pad_rows_kernel<<<kimg_divup(rows * 32, 256), 256, 0, stream>>>(kern, rows, ts.K, ts.tv0,
+                                                                       ts.Kv, out);
         if (TWO)
-            pad_table_kernel<TAPS><<<kimg_divup(rows * (TAPS + 1), 256), 256, 0, stream>>>(
-                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * (TAPS + 1));
+            pad_rows_kernel<<<kimg_divup(rows * 32, 256), 256, 0, stream>>>(
+                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * 32);
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -399,7 +443,7 @@ static bool tables_fit_lds(int w_planes, int oversample, int kernel_width)
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width)
 {
     return P >= 1 && P <= 4 && kernel_width >= 1 && kernel_width <= 2 * WIN
-           && (int64_t) w_planes * oversample * 65 * 8 * 2 < ((int64_t) 1 << 31);
+           && (int64_t) w_planes * oversample < 65536;        // row index packed in 16 bits
 }
 
 // Scratch for the padded HBM copy of the table (none when the tables fit LDS).
@@ -450,9 +494,9 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded)
                 if (!in_lds) {
                     if (wide) {
-                        if (pn == 1) LAUNCH_TG(1, 12, 64, true); else LAUNCH_TG(2, 8, 64, true);
+                        if (pn == 1) LAUNCH_TG(1, 12, 32, true); else LAUNCH_TG(2, 8, 32, true);
                     } else {
-                        if (pn == 1) LAUNCH_TG(1, 12, 64, false); else LAUNCH_TG(2, 8, 64, false);
+                        if (pn == 1) LAUNCH_TG(1, 12, 32, false); else LAUNCH_TG(2, 8, 32, false);
                     }
                 } else if (wide) {
                     if (pn == 1) LAUNCH(1, 12, 32, true); else LAUNCH(2, 8, 32, true);
