@@ -18,12 +18,15 @@
 //    ku.re]].  Two tiles cover the 32x32 window: 2 MFMAs per visibility and polarization.
 //    All per-tap arithmetic therefore runs on the matrix pipe; the VALU only prepares one A
 //    and two B elements per lane per visibility.
-//  * The separable kernel table (W x OV rows, padded to 32 taps) lives in LDS.  Visibilities
-//    are loaded 64 at a time (lane i <-> visibility i, coalesced, next batch prefetched),
-//    staged per wave in LDS and read back as broadcasts.  The scalar unit is a scarce
-//    resource (one issue slot shared by a SIMD's waves), so the window test runs once per
-//    group of 8 visibilities on bounds reduced with cross-lane shuffles; the common path
-//    is 8 x (5 LDS reads, ~17 VALU, 2 MFMA) of straight-line code.
+//  * The separable kernel table (W x OV rows, padded to 32 taps) lives in LDS when it fits
+//    (up to 512 rows); otherwise -- hundreds of W planes, or the two tables of a wide kernel --
+//    the operands come from a zero-padded copy in HBM (template flag TG, served by L1/L2).
+//    Visibilities are loaded 64 at a time (lane i <-> visibility i, coalesced, two batches
+//    prefetched), staged per wave in LDS and read back as broadcasts.  The scalar unit is a
+//    scarce resource (one issue slot shared by a SIMD's waves), so the window test runs once
+//    per group of 8 visibilities on bounds reduced with DPP; the hot loop is a hand-pipelined
+//    sequence of 4-visibility stages (operand reads one stage ahead of 8 back-to-back MFMAs)
+//    with no flush code inside.
 //  * Accumulator columns are (re, im)-interleaved, so a flush writes 128 contiguous bytes
 //    per half-wave -- the shape global float atomics run at full rate for.
 //  * Window slack 32-K lets consecutive visibilities whose footprints differ by a few
