@@ -960,3 +960,58 @@ def test_restore_step():
     assert beam.restore(im, beam.Beam(**b), conv) is conv
     np.testing.assert_allclose(im.get_buffer('dirty'), expected, rtol=1e-5,
                                atol=1e-5 * np.abs(expected).max())
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_grid_degrid_fuzz(seed):
+    """Seeded random configurations (kernel width 1..64, oversampling, plane count incl. tables that
+    do not fit LDS, polarizations, chunk sizes, track speed from static to teleporting) through the
+    automatic gridder and degridder variants, against the oracle."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    rs = gi.RandomState(1000 + seed)
+    OV = int(rs.choice([2, 4, 8, 16]))
+    K = int(rs.randint(1, 65))
+    if (K * OV) % 2:
+        K += 1
+    K = min(K, 64)
+    W = int(rs.choice([1, 2, 5, 16, 33, 64, 90, 200]))
+    P = int(rs.randint(1, 5))
+    n = int(rs.choice([1, 37, 64, 200, 1000, 2500]))
+    pixels = int(rs.choice([192, 256, 384]))
+    cover = int(pixels * 0.6) & ~1
+    c = gi.make_config(pixels, 0.0001, 0.01, P, K, W, oversample=OV, grid_cover=cover, n_vis=n)
+    t = gi.grid_track(c)
+    # vary the locality: scale the step between consecutive visibilities
+    speed = float(rs.choice([0.0, 0.3, 1.0, 4.0, 40.0]))
+    half = t['weights_grid'].shape[-1] // 2 - 1
+    uv = t['uv'].astype(np.int64)
+    uv = uv[0] + np.round((uv - uv[0]) * speed).astype(np.int64)
+    uv = ((uv + half) % (2 * half)) - half
+    t['uv'] = uv.astype(np.int16)
+    fn, q = _gridder(c, 'auto', max_vis=4096)
+    kernel = fn.convolve_kernel.data
+    actual = _run_gridder(fn, q, t)
+    expected = np.zeros(actual.shape, np.complex64)
+    wg = np.zeros(actual.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(kernel, expected, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(actual, expected) < GRID_TOL, (K, OV, W, P, n, speed)
+    ip, gp, ap = make_params(c)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 4096)
+    dg.ensure_all_bound()
+    G = dg.buffer('grid').shape[-1]
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    dg.buffer('grid').set(q, gdata)
+    vis = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+    w = rs.uniform(0.5, 1.5, size=(n, P)).astype(np.float32)
+    dg.num_vis = n
+    dg.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+    dg.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+    dg.buffer('vis').set_region(q, vis, np.s_[:n], np.s_[:])
+    dg.buffer('weights').set_region(q, w, np.s_[:n], np.s_[:])
+    dg()
+    want = vis.copy()
+    orc.degrid(kernel, gdata, t['uv'], t['sub_uv'], t['w_plane'], w, want)
+    got = dg.buffer('vis').get(q)[:n]
+    assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), (K, OV, W, P, n, speed)
