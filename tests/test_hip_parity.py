@@ -1075,3 +1075,72 @@ def test_clean_fuzz(seed):
         np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_array_equal(fn.buffer('dirty').get(q), ref_img)
     np.testing.assert_array_equal(fn.buffer('model').get(q), ref_model)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_grid_image_weights_fuzz(seed):
+    """Seeded random sizes through grid -> image, image -> grid and the weights pipeline against
+    the oracle: image sizes that are not powers of two, grids smaller than the image, w != 0,
+    off-centre lm bias, accumulation into a non-zero image; runs of equal cells and scattered
+    cells in the weight scatter, all three weight types."""
+    from katsdpimager_amd import image, weight
+    ctx, q = context_queue()
+    rs = gi.RandomState(7000 + seed)
+    G = int(rs.choice([64, 96, 120, 160, 250, 256]))
+    Gg = int(rs.choice([g for g in (16, 40, 64, 90, 120, 200, 256) if g <= G]))
+    P = int(rs.randint(1, 5))
+    w = float(rs.choice([0.0, 3.7, -12.5, 250.0]))
+    lm_scale = float(rs.uniform(2e-4, 2e-3))
+    lm_bias = -0.5 * G * lm_scale * float(rs.choice([1.0, 0.9, 1.1]))
+    k1d = rs.uniform(0.5, 2.0, G).astype(np.float32)
+    small = rs.complex_uniform(-1, 1, (P, Gg, Gg)).astype(np.complex64)
+    start = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
+    template = image.GridImageTemplate(ctx, np.float32)
+    plan = template.make_fft_plan((G, G))
+    g2i = template.instantiate_grid_to_image(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+    g2i.ensure_all_bound()
+    g2i.buffer('kernel1d').set(q, k1d)
+    g2i.buffer('grid').set(q, small)
+    g2i.buffer('image').set(q, start)
+    g2i.set_w(w)
+    g2i()
+    full = np.zeros((P, G, G), np.complex64)
+    gi.middle(full, small.shape)[:] = small
+    expected = start.copy()
+    orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, w)
+    assert relerr(g2i.buffer('image').get(q), expected) < 1e-5, (G, Gg, P, w)
+    i2g = template.instantiate_image_to_grid(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+    i2g.bind(layer=g2i.buffer('layer'), kernel1d=g2i.buffer('kernel1d'))
+    i2g.ensure_all_bound()
+    model = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
+    i2g.buffer('image').set(q, model)
+    i2g.set_w(w)
+    i2g()
+    full_grid, _ = orc.image_to_grid(model, k1d, lm_scale, lm_bias, w)
+    assert relerr(i2g.buffer('grid').get(q), gi.middle(full_grid, small.shape)) < 1e-5, (G, Gg, P, w)
+
+    # weights: runs of equal cells (tracks) mixed with scattered cells, some zero weights
+    n = int(rs.choice([1, 63, 500, 3000]))
+    half = Gg // 2 - 1
+    cells = rs.randint(-half, half, (n, 2))
+    run = rs.randint(1, 12, n)
+    uv = np.repeat(cells, run, axis=0)[:n].astype(np.int16)
+    wts = rs.uniform(0.0, 2.0, (n, P)).astype(np.float32)
+    wts[rs.uniform(size=n) < 0.1] = 0
+    for wt in (weight.WeightType.NATURAL, weight.WeightType.UNIFORM, weight.WeightType.ROBUST):
+        fn = weight.WeightsTemplate(ctx, wt, P).instantiate(q, (P, Gg, Gg), 4096)
+        fn.ensure_all_bound()
+        fn.robustness = 0.5
+        fn.clear()
+        ref = np.zeros((P, Gg, Gg), np.float32)
+        if wt != weight.WeightType.NATURAL:
+            fn.buffer('uv').set_region(q, uv, (np.s_[:n], np.s_[:2]), np.s_[:])
+            fn.buffer('weights').set_region(q, wts, np.s_[:n], np.s_[:])
+            fn.grid(n)
+            orc.weights_grid_add(ref, uv, wts)
+            np.testing.assert_allclose(fn.buffer('grid').get(q), ref, rtol=1e-5, atol=1e-6)
+        rms, nrms = fn.finalize()
+        if np.any(ref) or wt == weight.WeightType.NATURAL:
+            e_rms, e_nrms = orc.weights_finalize(wt.value, ref, 0.5)
+            np.testing.assert_allclose(fn.buffer('grid').get(q), ref, rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(nrms, e_nrms, rtol=1e-4)
