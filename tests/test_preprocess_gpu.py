@@ -446,3 +446,43 @@ def test_continuum_subtraction_removes_the_sources():
     scale = np.abs(with_sources).max() / np.abs(expected).max()
     # the difference is the float32 phase error of the predicted part (2e-3 of the sources)
     assert tapered_relerr(subtracted, expected, taper) < 2e-3 * scale
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_preprocess_fuzz(seed):
+    """Seeded random collector problems (polarization counts, slices, planes, oversampling, buffer
+    sizes, channel counts, run lengths, flag / NaN rates, with and without feed angles) against the
+    restated collector: index fields bit-exact, floats bit-exact without feed angles."""
+    rng = np.random.default_rng(9000 + seed)
+    P = int(rng.integers(1, 5))
+    Q = int(rng.integers(max(P - 1, 1), 5)) if rng.random() < 0.5 else int(rng.integers(1, 5))
+    C = int(rng.integers(1, 4))
+    n = int(rng.choice([1, 2, 63, 64, 65, 1000, 7777, 30000]))
+    w_slices = int(rng.choice([1, 2, 5, 17]))
+    configs = [dict(max_w=float(rng.uniform(100, 500)), w_slices=w_slices,
+                    w_planes=int(rng.choice([1, 8, 33])), oversample=int(rng.choice([1, 4, 8])),
+                    cell_size=float(rng.uniform(0.5, 3.0))) for _ in range(C)]
+    buffer_size = int(rng.choice([1, 7, 64, 1000, 4096, 50000]))
+    if n / buffer_size > 400:
+        buffer_size = 4096
+    clustered = int(rng.choice([1, 3, 20, 500]))
+    base = rng.uniform(-300, 300, (-(-n // clustered), 3)).astype(np.float32)
+    uvw = (np.repeat(base, clustered, axis=0)[:n] + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    weights = rng.uniform(0.5, 2, (C, n, Q)).astype(np.float32)
+    weights[:, rng.random(n) < rng.choice([0.0, 0.1, 0.9]), int(rng.integers(0, Q))] = 0
+    vis = (rng.normal(size=(C, n, Q)) + 1j * rng.normal(size=(C, n, Q))).astype(np.complex64)
+    vis[:, rng.random(n) < 0.03, int(rng.integers(0, Q))] = np.nan
+    feed = rng.random() < 0.3
+    if feed:
+        stokes = (rng.normal(size=(P, 4)) + 1j * rng.normal(size=(P, 4))).astype(np.complex64)
+        circ = (rng.normal(size=(4, Q)) + 1j * rng.normal(size=(4, Q))).astype(np.complex64)
+        fa1 = rng.uniform(-3, 3, n).astype(np.float32)
+        fa2 = rng.uniform(-3, 3, n).astype(np.float32)
+        batch = (uvw, weights, vis, fa1, fa2, stokes, circ)
+    else:
+        stokes = (rng.normal(size=(P, Q)) + 1j * rng.normal(size=(P, Q))).astype(np.complex64)
+        batch = (uvw, weights, vis, None, None, stokes, None)
+    coll = _collect_device(configs, P, buffer_size, [batch])
+    ref = orc.VisibilityCollector(configs, P, buffer_size)
+    ref.add(*batch)
+    _compare(coll, ref, configs, not feed, P)
