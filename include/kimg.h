@@ -199,6 +199,19 @@ int kimg_apply_primary_beam(float *image, int64_t row_stride, int64_t pol_stride
                             int width, int height, int num_polarizations,
                             float threshold, float replacement, void *stream);
 
+/* Output statistics of the restore step (frontend.py:171-209, host loops in the reference):
+ *   kimg_image_peak:   find_peak -- max |image| over all polarizations and pixels with
+ *       |image| * pbeam[y][x] > 7.5 * noise (pbeam float32 [H][W], may be NULL = 1; NaNs never
+ *       pass).  *peak (device float32) receives the maximum, 0 when no pixel qualifies (the
+ *       reference returns NaN then; the host wrapper does the same).
+ *   kimg_image_nansum: get_totals -- sums[p] (device float64 [P], zeroed by the call) = sum of
+ *       the non-NaN pixels of polarization p. */
+int kimg_image_peak(const float *image, int64_t row_stride, int64_t pol_stride, const float *pbeam,
+                    int64_t beam_row_stride, int width, int height, int num_polarizations,
+                    float noise, float *peak, void *stream);
+int kimg_image_nansum(const float *image, int64_t row_stride, int64_t pol_stride, int width,
+                      int height, int num_polarizations, double *sums, void *stream);
+
 /* ---- CLEAN support: clean.py:123-163 PsfPatch.__call__ + psf_patch.mako
  * bound (device int32[2], zeroed by the call) receives max |x-mid_x|, max |y-mid_y| over
  * pixels in [min_x,max_x]x[min_y,max_y] where any polarization has |psf| >= threshold. */

@@ -45,6 +45,8 @@ PROTOTYPES = {
     'kimg_rfft_exec': (c_int, [P, P, P, I, P]),
     'kimg_rfft_plan_destroy': (c_int, [P]),
     'kimg_fourier_beam': (c_int, [P, L, I, I, F, F, F, F, P]),
+    'kimg_image_peak': (c_int, [P, L, L, P, L, I, I, I, F, P, P]),
+    'kimg_image_nansum': (c_int, [P, L, L, I, I, I, P, P]),
     'kimg_scale': (c_int, [P, L, L, I, I, I, ctypes.POINTER(c_float), P]),
     'kimg_add_image': (c_int, [P, L, L, P, L, L, I, I, I, P]),
     'kimg_apply_primary_beam': (c_int, [P, L, L, P, L, I, I, I, F, F, P]),

@@ -267,3 +267,89 @@ extern "C" int kimg_fourier_beam(void *data, int64_t row_stride, int width, int 
         static_cast<float2 *>(data), row_stride, amplitude, a, b, c, width, height);
     return kimg_launch_status();
 }
+
+// ---- output statistics of the restore step: frontend.py:171-209 -------------------------------
+namespace {
+// find_peak (frontend.py:171-194): max |image| over pixels with |image| * pbeam > 7.5 noise
+// (comparisons with NaN are false, as on the host).  |x| >= 0, so the float maximum is the
+// maximum of the bit patterns.
+__global__ __launch_bounds__(256) void image_peak_kernel(
+    const float *__restrict__ image, int64_t row_stride, int64_t pol_stride,
+    const float *__restrict__ pbeam, int64_t beam_row_stride, int width, int height, int P,
+    float limit, unsigned int *__restrict__ out)
+{
+    float peak = 0.0f;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < width)
+        for (int y = blockIdx.y; y < height; y += gridDim.y) {
+            const float pb = pbeam ? pbeam[(int64_t) y * beam_row_stride + x] : 1.0f;
+            for (int p = 0; p < P; p++) {
+                const float v = fabsf(image[p * pol_stride + (int64_t) y * row_stride + x]);
+                if (v > peak && v * pb > limit)
+                    peak = v;
+            }
+        }
+    peak = fmaxf(peak, __shfl_xor(peak, 32, WAVE));
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        peak = fmaxf(peak, __shfl_xor(peak, off, WAVE));
+    if ((threadIdx.x & 63) == 0 && peak > 0.0f)
+        atomicMax(out, __float_as_uint(peak));
+}
+
+// get_totals (frontend.py:197-209): per-polarization sum ignoring NaNs, in float64.
+__global__ __launch_bounds__(256) void image_nansum_kernel(
+    const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
+    int height, double *__restrict__ sums)
+{
+    const int p = blockIdx.z;
+    double acc = 0.0;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < width)
+        for (int y = blockIdx.y; y < height; y += gridDim.y) {
+            const float v = image[p * pol_stride + (int64_t) y * row_stride + x];
+            if (v == v)
+                acc += (double) v;
+        }
+    acc = wave_sum(acc);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int) (blockDim.x >> 6); w++)
+            t += part[w];
+        atomicAdd(&sums[p], t);
+    }
+}
+}  // namespace
+
+extern "C" int kimg_image_peak(const float *image, int64_t row_stride, int64_t pol_stride,
+                               const float *pbeam, int64_t beam_row_stride, int width, int height,
+                               int num_polarizations, float noise, float *peak, void *stream)
+{
+    KIMG_CHECK_ARG(image && peak && width > 0 && height > 0 && num_polarizations >= 1);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(peak, 0, sizeof(float), s));
+    int by = height < 256 ? height : 256;
+    dim3 grid(kimg_divup(width, 256), by);
+    image_peak_kernel<<<grid, 256, 0, s>>>(image, row_stride, pol_stride, pbeam, beam_row_stride,
+                                           width, height, num_polarizations, 7.5f * noise,
+                                           reinterpret_cast<unsigned int *>(peak));
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_image_nansum(const float *image, int64_t row_stride, int64_t pol_stride,
+                                 int width, int height, int num_polarizations, double *sums,
+                                 void *stream)
+{
+    KIMG_CHECK_ARG(image && sums && width > 0 && height > 0 && num_polarizations >= 1
+                   && num_polarizations <= 65535);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * num_polarizations, s));
+    int by = height < 128 ? height : 128;
+    dim3 grid(kimg_divup(width, 256), by, num_polarizations);
+    image_nansum_kernel<<<grid, 256, 0, s>>>(image, row_stride, pol_stride, width, height, sums);
+    return kimg_launch_status();
+}

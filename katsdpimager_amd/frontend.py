@@ -143,6 +143,44 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     return out
 
 
+def extract_psf(queue, psf, psf_patch):
+    """Central ``psf_patch`` = (height, width) region of the first polarization of a device
+    PSF, as a host array (frontend.py:146-168; what the reference hands to ``fit_beam``)."""
+    y0 = (psf.shape[1] - psf_patch[0]) // 2
+    x0 = (psf.shape[2] - psf_patch[1]) // 2
+    out = np.empty((psf_patch[0], psf_patch[1]), psf.dtype)
+    psf.get_region(queue, out, np.s_[0, y0:y0 + psf_patch[0], x0:x0 + psf_patch[1]], np.s_[:, :])
+    return out
+
+
+def find_peak(queue, image, pbeam, noise):
+    """frontend.find_peak (frontend.py:171-194) on device arrays: the largest |pixel| among those
+    with |pixel| * pbeam > 7.5 * noise, NaN if there is none.  ``pbeam`` is a device array of
+    shape (height, width) or None (no primary-beam correction)."""
+    from . import accel
+    from ._lib import lib, check
+    P, H, W = image.shape
+    out = accel.DeviceArray(queue.context, (1,), np.float32)
+    check(lib().kimg_image_peak(image.ptr, W, H * W, pbeam.ptr if pbeam is not None else None, W,
+                                W, H, P, float(noise), out.ptr, queue.handle), 'kimg_image_peak')
+    peak = float(out.get(queue)[0])
+    return peak if peak != 0.0 else float('nan')
+
+
+def get_totals(queue, image, restoring_beam):
+    """frontend.get_totals (frontend.py:197-209): total flux density per polarization (a list in
+    polarization order) = NaN-ignoring pixel sum / area under the restoring beam in pixels."""
+    import math
+    from . import accel
+    from ._lib import lib, check
+    P, H, W = image.shape
+    sums = accel.DeviceArray(queue.context, (P,), np.float64)
+    check(lib().kimg_image_nansum(image.ptr, W, H * W, W, H, P, sums.ptr, queue.handle),
+          'kimg_image_nansum')
+    beam_area = 2 * math.pi * restoring_beam.major * restoring_beam.minor / (8 * math.log(2))
+    return [float(x) / beam_area for x in sums.get(queue)]
+
+
 def process_channels(jobs, workers=2):
     """Image several channels of one GPU concurrently, one host thread and one HIP stream
     (command queue) per channel in flight.

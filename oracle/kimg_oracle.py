@@ -707,3 +707,24 @@ def convolve_beam(model, amplitude, x_stddev, y_stddev, theta):
     beam_ft = amp * np.exp(-2.0 * np.pi ** 2 * np.sum(rotated ** 2, axis=-1))
     out[:] = np.fft.ifftn(model_ft * beam_ft[np.newaxis, ...], axes=[1, 2]).real
     return out
+
+
+# --------------------------------------------------------------------------
+# frontend.py:171-209   output statistics of the restore step
+# --------------------------------------------------------------------------
+def find_peak(image, pbeam, noise):
+    """frontend.find_peak (frontend.py:171-194), vectorised: the loop keeps the running maximum of
+    |v| over the pixels with |v| * pbeam > 7.5 noise, i.e. the maximum over that set."""
+    v = np.abs(image)
+    with np.errstate(invalid='ignore'):
+        ok = v * pbeam[np.newaxis] > 7.5 * noise
+    if not np.any(ok):
+        return np.nan
+    return v[ok].max()
+
+
+def get_totals(image, beam_major, beam_minor):
+    """frontend.get_totals (frontend.py:197-209) without the Stokes names."""
+    sums = np.nansum(image, axis=(1, 2), dtype=np.float64)
+    beam_area = 2 * math.pi * beam_major * beam_minor / (8 * math.log(2))
+    return sums / beam_area

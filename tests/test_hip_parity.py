@@ -1144,3 +1144,43 @@ def test_grid_image_weights_fuzz(seed):
             e_rms, e_nrms = orc.weights_finalize(wt.value, ref, 0.5)
             np.testing.assert_allclose(fn.buffer('grid').get(q), ref, rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(nrms, e_nrms, rtol=1e-4)
+
+
+def test_find_peak_and_totals():
+    """frontend.find_peak on the recipe of test_frontend.py:8-27 at its full size (4096^2, 4
+    polarizations; exact) and get_totals against the restatement."""
+    from katsdpimager_amd import accel, beam, frontend
+    ctx, q = context_queue()
+    size, noise, peak = 4096, 15.0, 200.0
+    x = np.linspace(-np.pi / 2, np.pi / 2, size)
+    y = np.cos(x)
+    pbeam = (y[np.newaxis, :] * y[:, np.newaxis]).astype(np.float32)
+    pbeam[pbeam < 0.01] = np.nan
+    rs = np.random.RandomState(seed=1)
+    with np.errstate(invalid='ignore'):
+        image = (rs.normal(scale=noise, size=(4, size, size)).astype(np.float32) / pbeam)
+    d_image = accel.DeviceArray(ctx, image.shape, np.float32)
+    d_pbeam = accel.DeviceArray(ctx, pbeam.shape, np.float32)
+    d_pbeam.set(q, pbeam)
+    d_image.set(q, image)
+    assert np.isnan(frontend.find_peak(q, d_image, d_pbeam, noise))
+    assert np.isnan(orc.find_peak(image, pbeam, noise))
+    image[1, size // 2 + 5, size // 2 - 10] = peak
+    d_image.set(q, image)
+    assert frontend.find_peak(q, d_image, d_pbeam, noise) == peak
+    image *= -1                                     # negative peaks
+    d_image.set(q, image)
+    assert frontend.find_peak(q, d_image, d_pbeam, noise) == peak
+    # without a primary beam the noise itself qualifies: plain maximum above 7.5 sigma
+    clean_img = np.where(np.isnan(image), 0, image).astype(np.float32)
+    d_image.set(q, clean_img)
+    assert frontend.find_peak(q, d_image, None, noise) == np.abs(clean_img).max()
+    bm = beam.Beam(1.0, 2.0, 5.0, 1.0)
+    d_image.set(q, image)
+    got = frontend.get_totals(q, d_image, bm)
+    want = orc.get_totals(image, bm.major, bm.minor)
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    psf = rs.uniform(size=(2, 64, 80)).astype(np.float32)
+    d_psf = accel.DeviceArray(ctx, psf.shape, np.float32)
+    d_psf.set(q, psf)
+    np.testing.assert_array_equal(frontend.extract_psf(q, d_psf, (11, 7)), psf[0, 26:37, 36:43])

@@ -354,3 +354,20 @@ def test_convolve_beam_sampled_reference():
                          for p in range(model.shape[0])])
     actual = orc.convolve_beam(model, **b)
     np.testing.assert_allclose(expected, actual, rtol=1e-5, atol=1e-5)
+
+
+def test_find_peak_known():
+    """test_frontend.py:8-27 (reduced from 4096^2 to 512^2)."""
+    size, noise, peak = 512, 15.0, 200.0
+    x = np.linspace(-np.pi / 2, np.pi / 2, size)
+    y = np.cos(x)
+    pbeam = y[np.newaxis, :] * y[:, np.newaxis]
+    pbeam[pbeam < 0.01] = np.nan
+    rs = np.random.RandomState(seed=1)
+    with np.errstate(invalid='ignore'):
+        image = rs.normal(scale=noise, size=(4, size, size)) / pbeam
+    assert np.isnan(orc.find_peak(image, pbeam, noise))
+    image[1, size // 2 + 5, size // 2 - 10] = peak
+    assert orc.find_peak(image, pbeam, noise) == peak
+    image *= -1
+    assert orc.find_peak(image, pbeam, noise) == peak
