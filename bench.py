@@ -185,6 +185,9 @@ def main():
         'vis_per_launch': vb,
         'hbm_algorithmic_GBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9, 1),
         'hbm_frac_of_8TBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        # the reference bench's own figure of merit: grid-point additions per second
+        # (tests/imager_bench.py:204-208), N K^2 P / t
+        'GGAPS': round(n_vis * K * K * P / (kern_ms * 1e-3) / 1e9, 1),
     }
     traffic_file = os.path.join(ROOT, 'profiles', 'gridder_traffic.json')
     if os.path.exists(traffic_file):
