@@ -277,6 +277,18 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             }
             const int mu = rec.z, mv = rec.w;
             const bool mine = mu != INT_MIN;
+            // the visibility and weight this lane will update: fetched now, so that their latency
+            // hides behind the MFMA chain instead of ending the batch
+            float old_vis[P], old_wgt[P];
+            {
+                const int64_t r = b0 + first + b_lane;
+                const bool fetch = mine && !h && r < end;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    old_vis[p] = fetch ? vis[(r * p_total + p) * 2 + part] : 0.0f;
+                    old_wgt[p] = fetch ? weights[r * p_total + p] : 0.0f;
+                }
+            }
             unsigned long long pending = __ballot(mine);
             const bool whole = hi_u - lo_u <= Su && hi_v - lo_v <= Sv;
             while (pending) {
@@ -356,10 +368,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                 if (active && !h) {
                     const int64_t r = b0 + first + b_lane;
 #pragma unroll
-                    for (int p = 0; p < P; p++) {
-                        float *out = vis + (r * p_total + p) * 2 + part;
-                        *out = *out - weights[r * p_total + p] * sum[p];    // grid.py:1154
-                    }
+                    for (int p = 0; p < P; p++)
+                        vis[(r * p_total + p) * 2 + part] = old_vis[p] - old_wgt[p] * sum[p];   // grid.py:1154
                 }
             }
         }
