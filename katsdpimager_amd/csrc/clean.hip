@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void abs_count_le_kernel(
     int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out)
 {
     uint32_t count = 0, next = 0xffffffffu;
-    constexpr int ROWS = 4;
+    constexpr int ROWS = 8;
     const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
     const bool x_ok = x < width - border;
     for (int p = 0; p < P; p++)
@@ -693,7 +693,7 @@ extern "C" int kimg_abs_histogram(const float *image, int64_t row_stride, int64_
     KIMG_CHECK_ARG(width > 2 * border && height > 2 * border && num_polarizations >= 1);
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
-    abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border, 512), 256, 0, s>>>(
+    abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border, 2048), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist);
     return kimg_launch_status();
 }
@@ -710,7 +710,7 @@ extern "C" int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t
     union { float f; uint32_t u; } conv;
     conv.f = value;
     const uint32_t bits = conv.u;
-    abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 1024), 256, 0, s>>>(
+    abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 4096), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border,
         bits & 0x7fffffffu, out);
     return kimg_launch_status();
