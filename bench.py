@@ -227,6 +227,31 @@ def main():
             big._run()
         q.finish()
         sec['grid_single_launch_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+        # Chunk launches alternated over two HIP streams (both accumulate into the same grid with
+        # atomics): the tail of one launch overlaps the head of the next, which recovers the
+        # single-launch rate while keeping vis_block-sized launches.  Not used for `value`: the
+        # per-launch durations of overlapping kernels no longer add up to the wall time, so the
+        # roofline accounting above would not apply.
+        q2 = ctx.create_command_queue()
+        fn_b = template.instantiate(q2, ap, ip, gp, vb)
+        fn_b.bind(grid=grid_buf, weights_grid=wg)
+        fn_b.ensure_all_bound()
+        pair = (fn, fn_b)
+
+        def grid_two_streams():
+            for i, (uv_c, wp_c, vis_c, n) in enumerate(chunks):
+                g_ = pair[i & 1]
+                g_.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+                g_.num_vis = n
+                g_._run()
+            q.finish()
+            q2.finish()
+        grid_two_streams()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            grid_two_streams()
+        sec['grid_two_streams_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+        del fn_b
         # PCIe-inclusive: the reference-style host path, every chunk copied from host memory
         # (uv, w_plane, vis: 18 B per visibility at P=1) before it is gridded
         host_fn = template.instantiate(q, ap, ip, gp, vb)
