@@ -48,6 +48,8 @@ def parse_args():
     p.add_argument('--clean-cycles', type=int, default=1000)
     p.add_argument('--cpu-sample', type=int, default=16_000_000,
                    help='visibilities gridded by the CPU baseline (0 disables it)')
+    p.add_argument('--streams', type=int, default=2, choices=[1, 2],
+                   help='HIP streams per channel in the major-loop measurements')
     p.add_argument('--major-loop', action='store_true',
                    help='also time the full major-cycle loop (BASELINE config 5)')
     p.add_argument('--no-secondary', action='store_true',
@@ -471,7 +473,7 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
     wparm = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
     template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
-    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2)
+    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
     im.ensure_all_bound()
     times = {}
 
@@ -490,14 +492,22 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
             im._weights.grid(n)
         return im.finalize_weights()
 
+    from katsdpimager_amd import preprocess as _pp
+
     def grid_pass(field, predict):
         im.clear_grid()
         for uv_c, wp_c, vis_c, wt_c, n in chunks_dev:
-            im.bind_chunk(n, uv_c, wp_c, vis_c if field == 'vis' else wt_c.psf_vis, wt_c)
+            # zero-copy coordinates / weights, device-to-device copy of the visibilities; with
+            # streams=2 consecutive chunks alternate between two HIP streams
+            im.set_chunk_device(_pp.DeviceChunk(n, uv_c, wp_c, wt_c, vis_c), field)
             if predict:
                 im.predict(0.0)
             im.grid()
 
+    # first use of a kernel loads its code object (milliseconds): not part of a channel's cost
+    uv_c, wp_c, vis_c, wt_c, n = chunks_dev[0]
+    im.set_chunk_device(_pp.DeviceChunk(n, uv_c, wp_c, wt_c, vis_c), 'weights')
+    q.finish()
     timed('weights', make_weights)
     im.clear_dirty()
     timed('grid_psf', lambda: grid_pass('weights', False))
@@ -554,7 +564,7 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     out['preprocess_Mvis_per_s'] = round(n / dt / 1e6, 1)
     out['preprocess_kept_fraction'] = round(coll.num_output / coll.num_input, 4)
     out['store_MB'] = round(coll.nbytes() / 1e6, 1)
-    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2)
+    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
     im.ensure_all_bound()
     for rep in range(2):
         q.finish()
@@ -574,7 +584,7 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     jobs = []
     for _ in range(4):
         qi = ctx.create_command_queue()
-        imi = template2.instantiate(qi, ipd, gpd, args.vis_block, 0, 2)
+        imi = template2.instantiate(qi, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
         imi.ensure_all_bound()
         jobs.append(dict(reader=reader, rel_channel=0, imager=imi, image_p=ipd, grid_p=gpd,
                          clean_p=cp2, weight_type=wparm.weight_type, vis_block=args.vis_block,

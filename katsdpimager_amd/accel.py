@@ -87,6 +87,12 @@ class CommandQueue:
         ev.record(self.stream)
         return Event(ev)
 
+    def enqueue_wait_for_events(self, events):
+        """Later work on this queue starts only after `events` (of other queues) have fired;
+        the host does not wait (katsdpsigproc's AbstractCommandQueue.enqueue_wait_for_events)."""
+        for ev in events:
+            self.stream.wait_event(ev._event)
+
 
 class HostArray(np.ndarray):
     """Page-locked numpy array (falls back to pageable memory without a device)."""

@@ -819,9 +819,10 @@ def test_psf_patch_and_noise_vs_golden(golden):
         clean.NoiseEstTemplate(ctx, np.float32, 1).instantiate(q, img.shape, 0.5)
 
 
+@pytest.mark.parametrize('streams', [1, 2])
 @pytest.mark.parametrize('batched', [False, True])
 @pytest.mark.parametrize('name', list(gi.E2E_CONFIGS))
-def test_end_to_end_vs_golden(golden, name, batched):
+def test_end_to_end_vs_golden(golden, name, batched, streams):
     """G9: the whole per-channel loop (weights -> PSF -> 2 major cycles of grid / FFT / CLEAN /
     degrid-or-predict) on the Imaging facade vs the reference's ImagingHost."""
     from katsdpimager_amd import imaging, parameters, weight
@@ -833,7 +834,8 @@ def test_end_to_end_vs_golden(golden, name, batched):
     cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
                                     c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
     template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
-    im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'])
+    # streams=2: consecutive chunks alternate between two HIP streams (same results)
+    im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'], streams=streams)
     im.ensure_all_bound()
     data = gi.e2e_inputs(c)
     if batched:

@@ -287,9 +287,9 @@ def test_store_driven_channel_vs_golden(golden, name):
             return reader.iter_slice(channel, w_slice, block_size)
 
     results = []
-    for rd, batched in ((reader, True), (HostReader(), False)):
+    for rd, batched, streams in ((reader, True, 2), (HostReader(), False, 1)):
         template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
-        im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'])
+        im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'], streams=streams)
         im.ensure_all_bound()
         stats = frontend.process_channel(rd, 0, im, ip, gp, cp, wp.weight_type, c['vis_block'],
                                          c['major'], c['degrid'], batched_clean=batched)
