@@ -156,6 +156,7 @@ class Imaging(accel.OperationSequence):
         self._side_dirty = False    # the side stream has work the main stream has not waited for
         self._side_synced = True    # the side stream has waited for the latest main-stream fence
         self._prologue = None
+        self._side_num_vis = 0
         assert image_parameters.fixed == template.fixed_image_parameters
         assert grid_parameters.fixed == template.fixed_grid_parameters
         self.template = template
