@@ -70,7 +70,7 @@ def main(argv=None):
     weight_p = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
     clean_p = parameters.CleanParameters(args.minor, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
     template = imaging.ImagingTemplate(ctx, array_p, image_p.fixed, weight_p, grid_p.fixed, clean_p)
-    imager = template.instantiate(queue, image_p, grid_p, args.vis_block, 0, args.major)
+    imager = template.instantiate(queue, image_p, grid_p, args.vis_block, 0, args.major, streams=2)
     imager.ensure_all_bound()
     stats = frontend.process_channel(reader, 0, imager, image_p, grid_p, clean_p,
                                      weight_p.weight_type, args.vis_block, args.major, True)
