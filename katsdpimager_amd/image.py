@@ -5,6 +5,7 @@ ImageToLayer, Scale, AddImage, ApplyPrimaryBeam, GridImageTemplate,
 GridToImage, ImageToGrid; image.py:15-740) on libkimg.so + rocFFT.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -183,25 +184,59 @@ class ApplyPrimaryBeam(accel.Operation):
         check(rc, 'kimg_apply_primary_beam')
 
 
+class _PlanPool:
+    """Idle rocFFT plans by shape.  Creating and destroying a 2-D plan costs ~7 + ~11 ms of host
+    time, more than the device work of a small channel, so a plan released by one channel's
+    ``Imaging`` is handed to the next one instead of being destroyed.  A plan is owned by one
+    :class:`FftPlan` at a time (hipfftSetStream + exec on a shared plan is not thread safe)."""
+    MAX_IDLE = 4
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._idle = {}
+
+    def take(self, shape):
+        with self._lock:
+            handles = self._idle.get(shape)
+            return handles.pop() if handles else None
+
+    def give(self, shape, handle):
+        with self._lock:
+            handles = self._idle.setdefault(shape, [])
+            if len(handles) < self.MAX_IDLE:
+                handles.append(handle)
+                return True
+        return False
+
+
+_plan_pool = _PlanPool()
+
+
 class FftPlan:
     """rocFFT 2-D C2C plan (stands in for katsdpsigproc.fft.FftTemplate, image.py:599)."""
     def __init__(self, shape):
-        self.shape = tuple(shape)
+        self.shape = tuple(int(x) for x in shape)
         self.dtype_src = self.dtype_dest = np.dtype(np.complex64)
-        handle = ctypes.c_void_p()
-        check(lib().kimg_fft_plan_create(ctypes.byref(handle), self.shape[0], self.shape[1]),
-              'kimg_fft_plan_create')
+        handle = _plan_pool.take(self.shape)
+        if handle is None:
+            handle = ctypes.c_void_p()
+            check(lib().kimg_fft_plan_create(ctypes.byref(handle), self.shape[0], self.shape[1]),
+                  'kimg_fft_plan_create')
         self._handle = handle
+        self._queue = None
 
     def execute(self, command_queue, layer, inverse):
+        self._queue = command_queue
         check(lib().kimg_fft_exec(self._handle, layer.ptr, 1 if inverse else -1,
                                   command_queue.handle), 'kimg_fft_exec')
 
     def __del__(self):
         try:
-            if self._handle:
-                lib().kimg_fft_plan_destroy(self._handle)
-                self._handle = None
+            handle, self._handle = self._handle, None
+            if handle and self._queue is not None:
+                self._queue.finish()      # the next owner may run the plan on another stream
+            if handle and not _plan_pool.give(self.shape, handle):
+                lib().kimg_fft_plan_destroy(handle)
         except Exception:
             pass
 

@@ -289,3 +289,17 @@ def test_frontend_driver_call_sequence():
     assert out['major'] == 1 and out['minor'] == 0
     assert frontend.process_channel(_HostReader([0, 0]), 0, _Recorder(), image_p, grid_p, clean_p,
                                     weight.WeightType.UNIFORM, 4, 3, True) is None
+
+
+def test_fft_plan_pool_hands_out_each_plan_once():
+    """Idle plans are reused by shape, never shared, and the pool is bounded."""
+    from katsdpimager_amd import image
+    pool = image._PlanPool()
+    assert pool.take((8, 8)) is None
+    for h in range(pool.MAX_IDLE):
+        assert pool.give((8, 8), h)
+    assert not pool.give((8, 8), 99)          # full: the caller destroys it
+    assert pool.take((4, 4)) is None
+    got = {pool.take((8, 8)) for _ in range(pool.MAX_IDLE)}
+    assert got == set(range(pool.MAX_IDLE))
+    assert pool.take((8, 8)) is None
