@@ -42,6 +42,21 @@ int kimg_version(void);
 /* Static string describing a return code of this library. */
 const char *kimg_error_string(int code);
 
+/* ---- convolution kernel table: grid.py:235-334 antialias_w_kernel, as called for every W plane
+ * by ConvolutionKernel.__init__ (grid.py:358-389), evaluated on the device in float64.
+ *   table  complex64 [w_planes][oversample][kernel_width] (device, written)
+ *   ws     float64 [w_planes] (device): the w of each plane in wavelengths, grid.py:382-383
+ *   beta   Kaiser-Bessel shape parameter, grid.py:374-378
+ * table[w][s][t] = sample t*oversample + (oversample-1-s) of the central oversample*kernel_width
+ * samples of step * FFT(ifftshift(aa(l) exp(2 pi i (-w (-l^2/2 - 5 l^4/24) + half_subcell l)))),
+ * l on an image_oversample-times finer grid of step 1/(kernel_width cell_wavelengths
+ * image_oversample).  oversample*kernel_width must be even (KIMG_EINVAL, grid.py:268);
+ * KIMG_EUNSUPPORTED when oversample*kernel_width*image_oversample > 5120 (the plane's samples and
+ * the roots of unity are kept in LDS). */
+int kimg_kernel_table(void *table, const double *ws, int w_planes, int kernel_width,
+                      int oversample, int image_oversample, double cell_wavelengths,
+                      double antialias_width, double beta, void *stream);
+
 /* ---- gridding: grid.py:786-867 Gridder.static_run/_run + imager_kernels/grid.mako:63-197
  * grid[p][v0+j][u0+k] += vis[r][p] * weights_grid[p][v+Gg/2][u+Gg/2]
  *                        * conj(kern[w][sub_v][j] * kern[w][sub_u][k]),

@@ -8,7 +8,7 @@ and streams created by torch are then valid inside the library.
 """
 import ctypes
 import os
-from ctypes import c_int, c_int64, c_float, c_size_t, c_uint32, c_void_p, c_char_p
+from ctypes import c_int, c_int64, c_float, c_double, c_size_t, c_uint32, c_void_p, c_char_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkimg.so')
@@ -21,6 +21,7 @@ F = c_float
 PROTOTYPES = {
     'kimg_version': (c_int, []),
     'kimg_error_string': (c_char_p, [I]),
+    'kimg_kernel_table': (c_int, [P, P, I, I, I, I, c_double, c_double, c_double, P]),
     'kimg_grid_workspace_bytes': (c_size_t, [L, I, I, I, I]),
     'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, P]),
     'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, P]),

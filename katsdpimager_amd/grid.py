@@ -84,19 +84,24 @@ class ConvolutionKernel:
     """Separable convolution kernel with metadata (grid.py:344-423)."""
 
     def __init__(self, image_parameters, grid_parameters, data=None):
-        self.grid_parameters = grid_parameters
+        self._set_parameters(image_parameters, grid_parameters)
         fixed = grid_parameters.fixed
         shape = (grid_parameters.w_planes, fixed.oversample, fixed.kernel_width)
         self.data = np.empty(shape, np.complex64) if data is None else data
-        cell_wavelengths = float(image_parameters.cell_size / image_parameters.wavelength)
+        self.data[:] = make_kernel_table(self.cell_wavelengths, self.ws, fixed.kernel_width,
+                                         fixed.oversample, fixed.antialias_width,
+                                         fixed.image_oversample, self.beta)
+
+    def _set_parameters(self, image_parameters, grid_parameters):
+        """beta and the w of every plane (grid.py:374-383)."""
+        self.grid_parameters = grid_parameters
+        fixed = grid_parameters.fixed
+        self.cell_wavelengths = float(image_parameters.cell_size / image_parameters.wavelength)
         slice_wl = float(fixed.max_w / (grid_parameters.w_slices * image_parameters.wavelength))
         plane_wl = slice_wl / grid_parameters.w_planes
         self.beta = antialias_beta(fixed.antialias_width)
         w_edge = 0.5 * (slice_wl - plane_wl)
-        ws = np.linspace(-w_edge, w_edge, grid_parameters.w_planes)
-        self.data[:] = make_kernel_table(cell_wavelengths, ws, fixed.kernel_width,
-                                         fixed.oversample, fixed.antialias_width,
-                                         fixed.image_oversample, self.beta)
+        self.ws = np.linspace(-w_edge, w_edge, grid_parameters.w_planes)
 
     def taper(self, N, out=None):
         """Image-plane correction for an N-pixel image (grid.py:404-423)."""
@@ -111,22 +116,53 @@ class ConvolutionKernel:
 
 
 class ConvolutionKernelDevice(ConvolutionKernel):
-    """:class:`ConvolutionKernel` with a device copy (grid.py:426-463).  The table is
-    stored unpadded: the HIP kernels pad rows to the window width when staging to LDS."""
+    """:class:`ConvolutionKernel` whose table is generated on the device
+    (``kimg_kernel_table``) and stays there (grid.py:426-463).  ``data``, the host copy the
+    reference keeps, is downloaded on first use.  The table is stored unpadded: the HIP kernels
+    pad rows to the window width when staging to LDS.
+
+    Tables too large for the device generator (``oversample * kernel_width * image_oversample``
+    > 5120, i.e. kernel widths beyond 160) are built on the host exactly as the reference
+    builds all of its tables, and uploaded."""
 
     def __init__(self, context, image_parameters, grid_parameters, pad=0, allocator=None):
-        super().__init__(image_parameters, grid_parameters)
+        self._set_parameters(image_parameters, grid_parameters)
+        fixed = grid_parameters.fixed
         if allocator is None:
             allocator = accel.DeviceAllocator(context)
-        self.padded_data = allocator.allocate(self.data.shape, np.complex64)
-        queue = context.create_command_queue()
-        self.padded_data.set(queue, self.data)
+        shape = (grid_parameters.w_planes, fixed.oversample, fixed.kernel_width)
+        if (fixed.oversample * fixed.kernel_width) % 2:
+            raise ValueError('oversample * kernel_width must be even')
+        image_oversample = int(fixed.image_oversample)
+        if image_oversample != fixed.image_oversample:
+            raise ValueError('image_oversample must be an integer')
+        self.padded_data = allocator.allocate(shape, np.complex64)
+        self._queue = queue = context.create_command_queue()
+        self._data = None
+        if fixed.oversample * fixed.kernel_width * image_oversample <= 5120:
+            ws = allocator.allocate((len(self.ws),), np.float64)
+            ws.set(queue, self.ws)
+            check(lib().kimg_kernel_table(
+                self.padded_data.ptr, ws.ptr, shape[0], shape[2], shape[1], image_oversample,
+                self.cell_wavelengths, float(fixed.antialias_width), self.beta, queue.handle),
+                'kimg_kernel_table')
+        else:
+            self._data = make_kernel_table(
+                self.cell_wavelengths, self.ws, fixed.kernel_width, fixed.oversample,
+                fixed.antialias_width, image_oversample, self.beta).astype(np.complex64)
+            self.padded_data.set(queue, self._data)
         queue.finish()
         self.pad = 0
 
     @property
+    def data(self):
+        if self._data is None:
+            self._data = self.padded_data.get(self._queue)
+        return self._data
+
+    @property
     def bin_size(self):
-        return self.data.shape[-1]
+        return self.padded_data.shape[-1]
 
 
 _kernel_cache = collections.OrderedDict()

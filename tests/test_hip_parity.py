@@ -1186,3 +1186,75 @@ def test_find_peak_and_totals():
     d_psf = accel.DeviceArray(ctx, psf.shape, np.float32)
     d_psf.set(q, psf)
     np.testing.assert_array_equal(frontend.extract_psf(q, d_psf, (11, 7)), psf[0, 26:37, 36:43])
+
+
+# ---- kernel table generated on the device (kimg_kernel_table) -------------------------------
+def _table_close(dev, ref):
+    """float32 rounding of a float64 result computed two ways: every tap within 1.5 float32 ulps
+    of the table's peak magnitude... and, much tighter, of its own plane's scale."""
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    err = np.abs(dev - ref) / scale
+    return float(err.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(gi.KERNEL_CONFIGS))
+def test_device_kernel_table_vs_golden(golden, name):
+    """G1: the device-generated table against the table of the reference's ConvolutionKernel."""
+    from katsdpimager_amd import grid
+    c = gi.KERNEL_CONFIGS[name]
+    g = golden('g1_kernel_' + name)
+    ctx, q = context_queue()
+    ip, gp, _ = make_params(c)
+    kernel = grid.ConvolutionKernelDevice(ctx, ip, gp)
+    assert kernel.beta == g['beta']
+    data = kernel.data
+    assert data.shape == g['data'].shape and data.dtype == np.complex64
+    # tolerance: 1e-7 of the plane's peak (float32 eps is 1.2e-7; the float64 sums differ by ~1e-14)
+    assert _table_close(data, g['data']) <= 1e-7
+    same = np.mean((data.real == g['data'].real) & (data.imag == g['data'].imag))
+    assert same > 0.95          # all but rounding-boundary cases are bit-identical
+    np.testing.assert_array_equal(kernel.taper(c['pixels']), g['taper'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,W,OV', [(60, 400, 8), (28, 32, 8), (64, 37, 8), (7, 5, 6), (160, 3, 8),
+                                    (33, 9, 4)])
+def test_device_kernel_table_vs_oracle(K, W, OV):
+    """Sizes of the real defaults (hundreds of planes, width 60) and the extremes of the LDS budget."""
+    from katsdpimager_amd import grid
+    c = gi.make_config(512, 2.0e-5, 0.21, 1, K, W, w_slices=2, max_w=900.0)
+    c['oversample'] = OV
+    ctx, q = context_queue()
+    ip, gp, _ = make_params(c)
+    kernel = grid.ConvolutionKernelDevice(ctx, ip, gp)
+    ref, beta = orc.convolution_kernel(c['cell_size'], c['wavelength'], c['max_w'], c['w_slices'],
+                                       W, OV, K, c['antialias_width'], c['image_oversample'])
+    assert kernel.beta == beta
+    assert _table_close(kernel.data, ref) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_device_kernel_table_arguments():
+    from katsdpimager_amd import accel, grid
+    from katsdpimager_amd._lib import lib
+    ctx, q = context_queue()
+    table = accel.DeviceArray(ctx, (2, 8, 28), np.complex64)
+    ws = accel.DeviceArray(ctx, (2,), np.float64)
+    ws.set(q, np.zeros(2))
+    call = lib().kimg_kernel_table
+    assert call(None, ws.ptr, 2, 28, 8, 4, 2.0, 7.0, 12.6, q.handle) == -10001
+    assert call(table.ptr, ws.ptr, 2, 27, 7, 4, 2.0, 7.0, 12.6, q.handle) == -10001   # odd OV*K
+    assert call(table.ptr, ws.ptr, 2, 200, 8, 4, 2.0, 7.0, 12.6, q.handle) == -10002  # LDS budget
+    # beyond the device generator's size: host construction as in the reference, same result type
+    c = gi.make_config(512, 2.0e-5, 0.21, 1, 162, 2, w_slices=1, max_w=100.0)
+    ip, gp, _ = make_params(c)
+    kernel = grid.ConvolutionKernelDevice(ctx, ip, gp)
+    ref, _ = orc.convolution_kernel(c['cell_size'], c['wavelength'], c['max_w'], 1, 2, 8, 162,
+                                    c['antialias_width'], c['image_oversample'])
+    np.testing.assert_array_equal(kernel.data, ref)
+    c = gi.make_config(512, 2.0e-5, 0.21, 1, 27, 2, w_slices=1, max_w=100.0)
+    c['oversample'] = 7
+    ip, gp, _ = make_params(c)
+    with pytest.raises(ValueError):
+        grid.ConvolutionKernelDevice(ctx, ip, gp)
