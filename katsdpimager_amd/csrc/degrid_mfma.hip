@@ -502,14 +502,19 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
 #define LAUNCH_TG(PP, NWV, TAPSV, TWOV) rc = launch<PP, NWV, TAPSV, TWOV, true>(g, grid_row_stride, \
         grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded)
-                if (!in_lds) {
-                    if (wide) {
+                // Diagonal blocks of a wide kernel use the same taps for rows and columns: one
+                // table, handled exactly like a narrow kernel's.
+                const bool two = wide && jb != kb;
+                const bool single_in_lds = !(tenv && tenv[0])
+                    && lds_bytes(12, w_planes, oversample, 32) <= LDS_LIMIT;
+                if (two) {
+                    if (!in_lds) {
                         if (pn == 1) LAUNCH_TG(1, 12, 32, true); else LAUNCH_TG(2, 8, 32, true);
                     } else {
-                        if (pn == 1) LAUNCH_TG(1, 12, 32, false); else LAUNCH_TG(2, 8, 32, false);
+                        if (pn == 1) LAUNCH(1, 12, 32, true); else LAUNCH(2, 8, 32, true);
                     }
-                } else if (wide) {
-                    if (pn == 1) LAUNCH(1, 12, 32, true); else LAUNCH(2, 8, 32, true);
+                } else if (!single_in_lds) {
+                    if (pn == 1) LAUNCH_TG(1, 12, 32, false); else LAUNCH_TG(2, 8, 32, false);
                 } else if (pn == 1) {
                     if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
                 } else {

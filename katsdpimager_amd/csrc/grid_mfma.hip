@@ -628,9 +628,9 @@ bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_wi
            && (int64_t) w_planes * oversample * 256 * 2 < ((int64_t) 1 << 31);
 }
 
-// Where the kernel reads its table from: LDS when it fits -- except for wide kernels, whose two
-// single-row tables in LDS leave room for 8 waves only and lose to doubled rows in HBM with 12
-// (1.46 vs 1.63 Gvis/s at K = 60).  KIMG_GRID_TABLE = lds / hbm32 / hbm64 overrides (experiments).
+// Where the kernel reads its table from: LDS when it fits -- except for the off-diagonal tap
+// blocks of wide kernels, whose two single-row tables in LDS are no faster than doubled rows in
+// HBM (the diagonal blocks need one table and always take the LDS form when it fits).  KIMG_GRID_TABLE = lds / hbm32 / hbm64 overrides (experiments).
 static bool table_in_lds(int P, int w_planes, int oversample, int kernel_width)
 {
     const char *e = getenv("KIMG_GRID_TABLE");
@@ -665,6 +665,8 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
         table_env = !e ? 0 : (strcmp(e, "hbm32") == 0 ? 32 : (strcmp(e, "hbm64") == 0 ? 64 : 0));
     }
     const bool in_lds = table_in_lds(P, w_planes, oversample, kernel_width);
+    const char *tenv = getenv("KIMG_GRID_TABLE");
+    const bool lds_env_hbm = tenv && strncmp(tenv, "hbm", 3) == 0;
     if (!in_lds && (workspace == nullptr
                     || workspace_bytes < kimg_grid_mfma_workspace_bytes(P, w_planes, oversample,
                                                                        kernel_width)))
@@ -697,9 +699,16 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 #define LAUNCH(PP, ROWV, NWV, TWOV) rc = launch<PP, ROWV, NWV, TWOV>(g, grid_row_stride, \
         grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, \
         w_planes, oversample, ts, P, stream)
-                if (!in_lds) {
-                    // table(s) in HBM; 12-wave blocks (P = 1) as for the LDS form
-                    if (wide) {
+                // Diagonal blocks of a wide kernel take row and column taps from the same half of
+                // the table: one table, which fits LDS whenever a narrow kernel's would.
+                const bool two = wide && jb != kb;
+                const bool single_in_lds = two ? false
+                    : wide ? (!table_env && !lds_env_hbm
+                              && lds_bytes(pn, 8, w_planes, oversample, 32) <= LDS_LIMIT)
+                           : in_lds;
+                if (two) {
+                    // two tables: doubled rows in HBM, 12-wave blocks (P = 1) as for the LDS form
+                    if (!in_lds) {
                         if (pn == 1)
                             rc = launch<1, 64, 12, true, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
@@ -708,7 +717,16 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                             rc = launch<2, 64, 8, true, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
                                 kern, w_planes, oversample, ts, P, stream, padded);
-                    } else if (pn == 1 && table_env != 32) {
+                    } else if (pn == 1) {
+                        if (lds_bytes(1, 12, w_planes, oversample, 32, 2) <= LDS_LIMIT && nw_env != 8)
+                            LAUNCH(1, 32, 12, true);
+                        else
+                            LAUNCH(1, 32, 8, true);
+                    } else {
+                        LAUNCH(2, 32, 8, true);
+                    }
+                } else if (!single_in_lds) {
+                    if (pn == 1 && table_env != 32) {
                         // doubled rows (no wrap arithmetic): 5 % faster than single rows
                         rc = launch<1, 64, 12, false, true>(g, grid_row_stride, grid_pol_stride,
                             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
@@ -722,11 +740,6 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
                             kern, w_planes, oversample, ts, P, stream, padded);
                     }
-                } else if (wide) {
-                    if (pn == 1)
-                        LAUNCH(1, 32, 8, true);
-                    else
-                        LAUNCH(2, 32, 8, true);
                 } else if (pn == 1) {
                     // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
                     if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
