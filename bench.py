@@ -304,6 +304,26 @@ def main():
         grid_obs2()
         q.finish()
         sec['grid_256_planes_Mvis_per_s'] = round((n2 // vb) * vb / (time.perf_counter() - t0) / 1e6, 1)
+        # the reference's default geometry: kernel width 60 (frontend.py:325) on the same 256 planes
+        if K != 60:
+            del fn2
+            ip3, gp3, ap3 = synth.make_parameters(obs2, P, 60)
+            fn2 = grid.GridderTemplate(ctx, ip3.fixed, gp3.fixed, {'variant': args.variant}) \
+                .instantiate(q, ap3, ip3, gp3, vb)
+            del grid2, wg2
+            shape3 = fn2.slots['grid'].shape
+            fn2.bind(grid=accel.DeviceArray(ctx, shape3, np.complex64),
+                     weights_grid=accel.DeviceArray(ctx, shape3, np.float32,
+                                                    tensor=torch.ones(shape3, device=dev)))
+            fn2.ensure_all_bound()
+            torch.cuda.synchronize()
+            grid_obs2()
+            q.finish()
+            t0 = time.perf_counter()
+            grid_obs2()
+            q.finish()
+            sec['grid_k60_256_planes_Mvis_per_s'] = round(
+                (n2 // vb) * vb / (time.perf_counter() - t0) / 1e6, 1)
         if args.major_loop:
             # PSF pass grids the weights as visibilities (frontend.py:511)
             wt_all = padded(obs.weights)
