@@ -5,8 +5,8 @@ store -> imaging weights, PSF, major/minor cycles -> restored image, all on one 
     python examples/image_channel.py [--pixels 2048] [--vis 4000000] [--major 3]
 
 It follows the reference's per-channel flow (frontend.py:31-83 preprocess_visibilities,
-:465-658 process_channel) with the loaders, beam fit and FITS output left out: the sky is three
-point sources, the restoring beam is given instead of fitted.
+:465-658 process_channel) with the loaders and FITS output left out: the sky is three point
+sources; the restoring beam is fitted to the PSF.
 """
 import argparse
 import math
@@ -73,13 +73,15 @@ def main(argv=None):
     imager = template.instantiate(queue, image_p, grid_p, args.vis_block, 0, args.major, streams=2)
     imager.ensure_all_bound()
     stats = frontend.process_channel(reader, 0, imager, image_p, grid_p, clean_p,
-                                     weight_p.weight_type, args.vis_block, args.major, True)
+                                     weight_p.weight_type, args.vis_block, args.major, True,
+                                     fit_beam=True)
     queue.finish()
     t2 = time.perf_counter()
     print('imaged in {:.1f} ms: {} major / {} minor cycles, PSF patch {}, noise {:.3g}'.format(
         (t2 - t1) * 1e3, stats['major'], stats['minor'], stats['psf_patch'], stats['noise']))
 
-    beam.restore(imager, beam.Beam(1.0, 1.5, 1.5, 0.0))
+    print('restoring beam: {}'.format(stats['restoring_beam']))
+    beam.restore(imager, stats['restoring_beam'])
     restored = imager.get_buffer('dirty')[0]
     G = args.pixels
     for (lp, mp), flux in sources:

@@ -3,8 +3,9 @@
 Mirror of the device half of ``katsdpimager.beam`` (beam.py:204-398): ``FourierBeamTemplate``
 / ``FourierBeam`` multiply the half-complex transform of an image by the analytic transform of
 a Gaussian beam, ``ConvolveBeamTemplate`` / ``ConvolveBeam`` wrap it in an R2C and a C2R rocFFT.
-The beam *fit* (beam.py:91-155, astropy least squares on a ~100-pixel patch) stays on the host
-and is not reproduced; :class:`Beam` only carries the fitted Gaussian's parameters.
+The beam *fit* (beam.py:91-155) is a least-squares problem with three unknowns on a ~100-pixel
+patch and stays on the host: :func:`fit_beam` solves it with scipy where the reference uses
+astropy's Levenberg-Marquardt fitter; :class:`Beam` carries the fitted Gaussian's parameters.
 """
 import ctypes
 import math
@@ -51,6 +52,51 @@ class Beam:
 
     def __repr__(self):
         return 'Beam({0.major!r}, {0.minor!r}, {0.theta!r})'.format(self)
+
+
+def _gaussian2d(x, y, x_stddev, y_stddev, theta):
+    """Unit-amplitude elliptical Gaussian centred on the origin, in the parametrisation of the
+    model the reference fits (astropy ``Gaussian2D``): ``theta`` rotates the x axis towards y."""
+    c, s = math.cos(theta), math.sin(theta)
+    xr = (c * x + s * y) / x_stddev
+    yr = (-s * x + c * y) / y_stddev
+    return np.exp(-0.5 * (xr * xr + yr * yr))
+
+
+def fit_beam(psf, step=1.0, threshold=0.01, init_threshold=0.5):
+    """Fit a 2-D Gaussian (unit amplitude, centred on pixel ``shape // 2``) to a PSF patch and
+    return it as a :class:`Beam` (beam.py:91-155).  ``x`` is axis 0 of ``psf``.
+
+    As in the reference the starting point is the second moment about the origin of the samples
+    above ``init_threshold``, corrected for the truncation of a Gaussian at that level
+    (beam.py:132-145); the fit then uses all samples above ``threshold``.  The minimiser is
+    ``scipy.optimize.least_squares`` (Levenberg-Marquardt) instead of astropy's wrapper around
+    the same MINPACK routine."""
+    import scipy.optimize
+    psf = np.asarray(psf, np.float64)
+    if psf.ndim != 2:
+        raise ValueError('psf must be 2D')
+
+    def samples(level):
+        i0, i1 = np.nonzero(psf > level)
+        return (psf[i0, i1], (i0 - psf.shape[0] // 2) * float(step),
+                (i1 - psf.shape[1] // 2) * float(step))
+
+    value, x, y = samples(init_threshold)
+    total = value.sum()
+    cov = np.array([[np.sum(value * x * x), np.sum(value * x * y)],
+                    [np.sum(value * x * y), np.sum(value * y * y)]]) / total
+    r2 = -2.0 * math.log(init_threshold)
+    cov /= 1.0 - (1.0 + 0.5 * r2) * math.exp(-0.5 * r2)
+    eigenvalues, eigenvectors = np.linalg.eigh(cov)
+    start = [math.sqrt(max(eigenvalues[1], 1e-12)), math.sqrt(max(eigenvalues[0], 1e-12)),
+             math.atan2(eigenvectors[1, 1], eigenvectors[0, 1])]
+
+    value, x, y = samples(threshold)
+    fit = scipy.optimize.least_squares(
+        lambda p: _gaussian2d(x, y, p[0], p[1], p[2]) - value, start, method='lm',
+        xtol=1e-12, ftol=1e-12, gtol=1e-12)
+    return Beam(1.0, abs(float(fit.x[0])), abs(float(fit.x[1])), float(fit.x[2]))
 
 
 def beam_covariance_sqrt(beam):

@@ -77,7 +77,8 @@ def slice_mid_w(image_p, grid_p):
 
 
 def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type,
-                    vis_block, major, degrid, subtract_model=False, batched_clean=True):
+                    vis_block, major, degrid, subtract_model=False, batched_clean=True,
+                    fit_beam=False):
     """The loop of frontend.process_channel (frontend.py:497-585) from "Compute imaging
     weights" to the end of the last major cycle.
 
@@ -85,6 +86,9 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     ``noise`` (last estimate), ``major``, ``minor``, ``peaks`` (first peak metric of every
     major cycle), or None when the channel has no usable data (frontend.py:524-527).  The
     images stay in the imager's ``dirty`` (residual), ``model`` and ``psf`` buffers.
+
+    ``fit_beam`` adds ``restoring_beam``: the Gaussian fitted to the central PSF patch
+    (frontend.py:534-535), as ``beam.restore`` takes it.
 
     ``batched_clean`` runs the minor cycles of one major cycle with ``Imaging.clean_cycles``
     (no host round trip per cycle); the result is identical to the per-cycle loop.
@@ -110,6 +114,10 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
                psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
                peaks=[], noise=None)
+    if fit_beam:
+        from . import beam
+        psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
+        out['restoring_beam'] = beam.fit_beam(psf_core)
     for i in range(major):
         make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
                    i != 0, subtract_model)

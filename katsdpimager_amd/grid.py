@@ -80,6 +80,24 @@ def make_kernel_table(cell_wavelengths, ws, width, oversample, antialias_width,
     return np.ascontiguousarray(np.swapaxes(table, -1, -2))
 
 
+def antialias_w_kernel(cell_wavelengths, w, width, oversample, antialias_width,
+                       image_oversample, beta, out=None):
+    """The reference's name and signature for :func:`make_kernel_table` (grid.py:235-334):
+    ``w`` is an array of w values in wavelengths; the result is [len(w)][oversample][width]."""
+    table = make_kernel_table(cell_wavelengths, w, width, oversample, antialias_width,
+                              image_oversample, beta)
+    if out is None:
+        return table
+    out[:] = table
+    return out
+
+
+def subpixel_coord(x, oversample):
+    """(pixel, sub-pixel) index of a real-valued grid coordinate (grid.py:338-341)."""
+    fine = int(np.floor(x * oversample))
+    return fine // oversample, fine % oversample
+
+
 class ConvolutionKernel:
     """Separable convolution kernel with metadata (grid.py:344-423)."""
 

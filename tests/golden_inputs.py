@@ -481,3 +481,16 @@ def beam_cases():
     model = rs.standard_normal((1, 256, 256)).astype(np.float32)
     cases.append(('dense', model, dict(amplitude=0.7, x_stddev=1.2, y_stddev=4.1, theta=2.5)))
     return cases
+
+
+# --------------------------------------------------------------------------
+# G11: Mueller matrices between polarization bases (polarization.py:69-132)
+# --------------------------------------------------------------------------
+def polarization_cases():
+    """(outputs, inputs) in the CASA enumeration: 1-4 IQUV, 5-8 RR RL LR LL, 9-12 XX XY YX YY.
+    Includes combinations that have no solution and redundant inputs."""
+    linear, circular = [9, 10, 11, 12], [5, 6, 7, 8]
+    inputs = [linear, circular, [9, 12], [5, 8], [12, 11, 10, 9], [1, 2, 3, 4], [9, 10, 11, 12, 5],
+              [10, 11]]
+    outputs = [[1], [1, 2], [1, 2, 3, 4], [1, 4], [2, 3], [4], circular, linear]
+    return [(o, i) for o in outputs for i in inputs]

@@ -303,3 +303,81 @@ def test_fft_plan_pool_hands_out_each_plan_once():
     got = {pool.take((8, 8)) for _ in range(pool.MAX_IDLE)}
     assert got == set(range(pool.MAX_IDLE))
     assert pool.take((8, 8)) is None
+
+
+def test_polarization_matrices_vs_golden(golden):
+    """G11: every (outputs, inputs) combination of golden_inputs.polarization_cases, including
+    the unsolvable ones, against the reference's polarization_matrix (bit-identical)."""
+    import golden_inputs as gi
+    from katsdpimager_amd import polarization
+    g = golden('g11_polarization')
+    np.testing.assert_array_equal(polarization.STOKES_COEFF, g['coeff'])
+    solvable = 0
+    for idx, (outputs, inputs) in enumerate(gi.polarization_cases()):
+        expected = g['m%d' % idx]
+        if expected.size == 0:
+            with pytest.raises(ValueError):
+                polarization.polarization_matrix(outputs, inputs)
+        else:
+            got = polarization.polarization_matrix(outputs, inputs)
+            assert got.dtype == np.complex64 and got.shape == (len(outputs), len(inputs))
+            np.testing.assert_array_equal(got, expected)
+            solvable += 1
+    assert 20 < solvable < len(gi.polarization_cases())
+    from_c, to_c = polarization.polarization_matrices([1, 2, 3, 4], [9, 10, 11, 12])
+    np.testing.assert_array_equal(from_c, g['from_circular'])
+    np.testing.assert_array_equal(to_c, g['to_circular'])
+    # IQUV from linear feeds: I = (XX + YY) / 2, V = (XY - YX) / 2i
+    m = polarization.polarization_matrix(polarization.STOKES_IQUV, [9, 10, 11, 12])
+    np.testing.assert_array_equal(m[0], [0.5, 0, 0, 0.5])
+    np.testing.assert_array_equal(m[3], [0, -0.5j, 0.5j, 0])
+
+
+@pytest.mark.parametrize('sx,sy,theta', [(2.0, 5.0, 1.0), (3.0, 1.5, -0.4), (4.1, 1.2, 2.5),
+                                         (1.3, 1.3, 0.0)])
+def test_fit_beam_recovers_a_gaussian(sx, sy, theta):
+    """beam.fit_beam (beam.py:91-155) on an exactly Gaussian PSF returns that Gaussian, in the
+    normalised (major, minor, theta mod pi) form of Beam; ``step`` scales the widths."""
+    import math
+    from katsdpimager_amd import beam
+    H, W = 45, 39
+    i0, i1 = np.meshgrid(np.arange(H) - H // 2, np.arange(W) - W // 2, indexing='ij')
+    psf = beam._gaussian2d(i0.astype(float), i1.astype(float), sx, sy, theta).astype(np.float32)
+    fwhm = math.sqrt(8 * math.log(2))
+    for step in (1.0, 0.25):
+        b = beam.fit_beam(psf, step=step)
+        assert b.major == pytest.approx(max(sx, sy) * fwhm * step, rel=1e-5)
+        assert b.minor == pytest.approx(min(sx, sy) * fwhm * step, rel=1e-5)
+        if sx != sy:
+            want = (theta + (math.pi / 2 if sx < sy else 0.0)) % math.pi
+            assert abs((b.theta - want + math.pi / 2) % math.pi - math.pi / 2) < 1e-5
+        # the model that FourierBeam consumes reproduces the PSF
+        M = beam.beam_covariance_sqrt(b) / step
+        inv = np.linalg.inv(M @ M)
+        quad = inv[0, 0] * i0 * i0 + 2 * inv[0, 1] * i0 * i1 + inv[1, 1] * i1 * i1
+        assert np.max(np.abs(np.exp(-0.5 * quad) - psf)) < 1e-4
+
+
+def test_fit_beam_is_a_least_squares_stationary_point():
+    """On a PSF that is not Gaussian (sidelobes, as a real synthesised beam) the result is the
+    least-squares optimum over the samples above the threshold: no nearby parameters do better."""
+    from katsdpimager_amd import beam
+    H = W = 41
+    i0, i1 = np.meshgrid(np.arange(H) - H // 2, np.arange(W) - W // 2, indexing='ij')
+    r = np.hypot(i0 / 3.0, (i1 + 0.3 * i0) / 2.0)
+    psf = np.sinc(r / 2.5) ** 2 * (1 + 0.05 * np.cos(i0))
+    psf /= psf[H // 2, W // 2]
+    b = beam.fit_beam(psf, threshold=0.05)
+    mask = psf > 0.05
+    x, y, v = i0[mask].astype(float), i1[mask].astype(float), psf[mask]
+
+    def cost(sx, sy, th):
+        return float(np.sum((beam._gaussian2d(x, y, sx, sy, th) - v) ** 2))
+    m = b.model
+    best = cost(m.x_stddev.value, m.y_stddev.value, m.theta)
+    for d in (1e-3, -1e-3):
+        assert cost(m.x_stddev.value + d, m.y_stddev.value, m.theta) >= best
+        assert cost(m.x_stddev.value, m.y_stddev.value + d, m.theta) >= best
+        assert cost(m.x_stddev.value, m.y_stddev.value, m.theta + d) >= best
+    with pytest.raises(ValueError):
+        beam.fit_beam(np.zeros((3, 3, 3)))

@@ -364,7 +364,7 @@ def test_concurrent_channels_match_serial():
 
 def test_example_runs_and_recovers_sources():
     """examples/image_channel.py at a small size: the three synthetic sources come back at their
-    positions with their fluxes (robust weighting, 3 major cycles, restored with a 1.5-pixel beam)."""
+    positions with their fluxes (robust weighting, 3 major cycles, restored with the fitted beam)."""
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -376,7 +376,8 @@ def test_example_runs_and_recovers_sources():
                                 '--minor', '300', '--vis-block', '131072'])
     assert stats['major'] >= 2 and stats['minor'] > 10
     G = 1024
-    # a Gaussian restoring beam of amplitude 1 and sigma 1.5 px keeps the peak = flux
+    # a Gaussian restoring beam of amplitude 1 keeps the peak = flux
+    assert 1.0 < stats['restoring_beam'].minor <= stats['restoring_beam'].major < 20.0
     for (lp, mp), flux in [((40, -25), 1.0), ((-120, 60), 0.5), ((15, 200), 0.25)]:
         y, x = G // 2 + mp, G // 2 + lp
         peak = float(restored[y - 2:y + 3, x - 2:x + 3].max())
