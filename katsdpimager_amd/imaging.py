@@ -481,6 +481,15 @@ class Imaging(accel.OperationSequence):
             self._side.continuum.set_sky_arrays(lmn, flux)
 
     @_serial
+    def set_sky_model(self, sky_model, phase_centre):
+        """imaging.py:331-332: continuum model from an object with the reference's SkyModel
+        interface (``lmn(phase_centre)``, ``flux_density(wavelength)``, ``len``)."""
+        self._ready()
+        self._continuum_predict.set_sky_model(sky_model, phase_centre)
+        if self._side is not None:
+            self._side.continuum.set_sky_model(sky_model, phase_centre)
+
+    @_serial
     def grid_to_image(self, w):
         self._ready()
         self._grid_to_image.set_w(w)

@@ -34,6 +34,23 @@ def extract_sky_image(image_parameters, grid_parameters, components):
     return lmn, flux
 
 
+def extract_sky_model(image_parameters, grid_parameters, model, phase_centre):
+    """Sky model -> (lmn float32 [N][3] with n-1, flux float32 [N][P]) (predict.py:30-70).
+
+    ``model`` is any object with the two methods of the reference's ``sky_model.SkyModel``:
+    ``lmn(phase_centre)`` -> [N][3] direction cosines and ``flux_density(wavelength)`` -> [N][4]
+    Stokes IQUV in Jy.  The sub-cell quantisation taper is removed as for CLEAN components and
+    the image's polarizations are picked from IQUV."""
+    from . import polarization
+    lmn = np.array(model.lmn(phase_centre), np.float64).reshape(-1, 3)
+    lmn[:, 2] -= 1.0
+    flux = np.array(model.flux_density(image_parameters.wavelength), np.float64).reshape(-1, 4)
+    scale = float(image_parameters.image_size * grid_parameters.fixed.oversample)
+    flux = flux * (np.sinc(lmn[:, 0] / scale) * np.sinc(lmn[:, 1] / scale))[:, np.newaxis]
+    index = [polarization.STOKES_IQUV.index(pol) for pol in image_parameters.fixed.polarizations]
+    return lmn.astype(np.float32), flux[:, index].astype(np.float32)
+
+
 def uvw_scale_bias(image_parameters, grid_parameters):
     """Factors turning quantised (cell, sub-cell, plane) indices back into wavelengths
     (predict.py:122-149): uv = uv_scale*(oversample*g + s + 0.5), w = w0 + w_scale*p + w_bias."""
@@ -94,6 +111,14 @@ class Predict(grid.VisOperation):
                                           np.s_[:n], np.s_[:])
             self.buffer('flux').set_region(self.command_queue, np.asarray(flux, np.float32),
                                            np.s_[:n], np.s_[:])
+
+    def set_sky_model(self, model, phase_centre):
+        """predict.py:332-348: sources of a sky model (see :func:`extract_sky_model`)."""
+        if len(model) > self.max_sources:
+            raise ValueError('too many sources ({} > {})'.format(len(model), self.max_sources))
+        lmn, flux = extract_sky_model(self.image_parameters, self.grid_parameters, model,
+                                      phase_centre)
+        self.set_sky_arrays(lmn, flux)
 
     def set_sky_image(self, components):
         """predict.py:351-370."""

@@ -381,3 +381,41 @@ def test_fit_beam_is_a_least_squares_stationary_point():
         assert cost(m.x_stddev.value, m.y_stddev.value, m.theta + d) >= best
     with pytest.raises(ValueError):
         beam.fit_beam(np.zeros((3, 3, 3)))
+
+
+def test_extract_sky_model_matches_component_path():
+    """predict.extract_sky_model (predict.py:30-70): n-1, IQUV selection in the image's
+    polarization order, and the same sub-cell taper that extract_sky_image removes."""
+    from katsdpimager_amd import parameters, polarization, predict
+
+    class Model:
+        def __init__(self, lmn, flux):
+            self._lmn, self._flux = lmn, flux
+
+        def __len__(self):
+            return len(self._lmn)
+
+        def lmn(self, phase_centre):
+            assert phase_centre == 'centre'
+            return self._lmn
+
+        def flux_density(self, wavelength):
+            return self._flux
+
+    c = gi.make_config(256, 1e-4, 0.2, 2, 28, 8)
+    ip, gp, _ = make_params(c)
+    ip.fixed.polarizations = [polarization.STOKES_V, polarization.STOKES_I]
+    pix = float(ip.pixel_size)
+    pos = [(140, 100), (10, 250), (128, 128)]
+    l = np.array([(x - 128) * pix for y, x in pos])
+    m = np.array([(y - 128) * pix for y, x in pos])
+    lmn = np.stack([l, m, np.sqrt(1 - l * l - m * m)], axis=1)
+    lmn.flags.writeable = False           # the reference's models hand out read-only arrays
+    iquv = np.array([[1.0, 0.1, 0.2, 0.3], [2.0, 0, 0, -0.5], [0.5, 0, 0, 0]])
+    got_lmn, got_flux = predict.extract_sky_model(ip, gp, Model(lmn, iquv), 'centre')
+    comps = {p: np.array([iquv[i, 3], iquv[i, 0]], np.float32) for i, p in enumerate(pos)}
+    want_lmn, want_flux = predict.extract_sky_image(ip, gp, comps)
+    assert got_lmn.dtype == np.float32 and got_flux.dtype == np.float32
+    np.testing.assert_allclose(got_lmn, want_lmn, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got_flux, want_flux, rtol=1e-6)
+    assert np.all(lmn[:, 2] > 0.9)        # the model's array was not modified
