@@ -273,12 +273,14 @@ int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride, int64_t po
 /* Device-resident minor-cycle loop (replaces the per-cycle host round trip of
  * clean.py:848-891): runs up to `max_cycles` cycles of find-peak -> threshold test ->
  * subtract -> tile update without host synchronisation.
- *   state  device scratch, kimg_clean_state_bytes(P) bytes, zeroed by the call
+ *   state  device scratch, kimg_clean_state_bytes(P, tiles_x, tiles_y) bytes, initialised by the
+ *          call (loop state, and for the one-launch-per-cycle form used with small PSF patches
+ *          the per-tile peak pixel values and the tile records in flight between cycles)
  *   log    device float32 [max_cycles][3 + P]: (metric, y, x as float bits, loop_gain*pixel[p])
  *   After the stream is synchronised, ((int32*)state)[0] holds the number of cycles done
  *   (stops early when the peak metric < threshold, clean.py:879-880).
  */
-size_t kimg_clean_state_bytes(int num_polarizations);
+size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int tiles_y);
 int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
                       int width, int height, int num_polarizations,
                       const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,

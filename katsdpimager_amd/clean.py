@@ -366,7 +366,8 @@ class Clean(accel.OperationSequence):
         }
         super().__init__(command_queue, ops, compounds, allocator=allocator)
         self._state = accel.DeviceArray(
-            command_queue.context, (lib().kimg_clean_state_bytes(image_shape[0]) // 4,), np.int32)
+            command_queue.context, (lib().kimg_clean_state_bytes(image_shape[0], tile_shape[1], tile_shape[0]) // 4,),
+            np.int32)
         self._log = None
 
     def _run(self):

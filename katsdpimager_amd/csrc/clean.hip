@@ -326,6 +326,392 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     }
 }
 
+// ---- one launch per minor cycle ----------------------------------------------------------
+// The two-launch cycle above is a chain of dependent memory round trips with a kernel boundary
+// in the middle.  When the PSF patch touches few lattice blocks, every workgroup of the
+// subtract/update launch can afford to find the global peak ITSELF (the tile maxima are 64 KB at
+// 4096^2), so the cycle becomes one launch with no communication between its workgroups:
+//   * all workgroups read the same inputs -- the base tile arrays plus a short list of "deltas"
+//     (the tile records rewritten by the previous cycle) -- and therefore pick the same peak;
+//   * each then subtracts the PSF from its own lattice block, rescans it, and writes the new tile
+//     record to the OTHER delta list (double-buffered by cycle parity), never to the base arrays,
+//     so that slower workgroups of the same launch still see the inputs unchanged;
+//   * workgroup 0 also folds the previous cycle's deltas into the base arrays (readers override
+//     those entries with the delta values anyway, so it does not matter which version they see),
+//     writes the log entry, the model pixel and the next state.
+// Tile records carry the pixel values at the tile's peak (tile_pix), which saves the dependent
+// load of the peak pixel.  Selection and arithmetic are those of the two-launch form, bit for bit.
+constexpr int FUSED_MAX_BLOCKS = 64;
+constexpr int FUSED_ROUND = 16;                 // tile maxima per thread and round
+constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
+
+struct delta_t {
+    int tile;               // -1: the block is not a tile
+    int y_tile;             // tile / tiles_x
+    float value;
+    int y, x;
+    float pix[4];
+    int pad[3];
+};
+
+struct fused_state {
+    int count, done, limit, num_deltas;
+    int pad[12];
+};
+
+struct fused_scratch {
+    fused_state st[2];
+    delta_t deltas[2][FUSED_MAX_BLOCKS];
+    // float tile_pix[tiles][4] follows
+};
+
+__device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *tile_pos,
+                                   float *tile_pix)
+{
+    tile_max[d.tile] = d.value;
+    tile_pos[2 * d.tile] = d.y;
+    tile_pos[2 * d.tile + 1] = d.x;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+        tile_pix[4 * d.tile + p] = d.pix[p];
+}
+
+// (value, index) as one unsigned key: larger value first, then smaller index.  Values are
+// non-negative floats (never NaN: a NaN metric never replaces a tile's best), whose bit patterns
+// order like the numbers.  Key 0 = nothing.
+typedef unsigned long long key_t;
+
+__device__ inline key_t make_key(float value, int idx)
+{
+    return ((key_t) __float_as_uint(value) << 32) | (unsigned) ~idx;
+}
+
+__device__ inline key_t key_max(key_t a, key_t b) { return a > b ? a : b; }
+
+template <int CTRL>
+__device__ inline key_t key_dpp(key_t k)
+{
+    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned) k, CTRL, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned) (k >> 32), CTRL, 0xf, 0xf, true);
+    return ((key_t) hi << 32) | lo;
+}
+
+// Maximum over each 16-lane row, in every lane of the row (DPP butterflies: ALU latency only)
+__device__ inline key_t row_max_key(key_t k)
+{
+    k = key_max(k, key_dpp<0xB1>(k));       // quad_perm [1,0,3,2]
+    k = key_max(k, key_dpp<0x4E>(k));       // quad_perm [2,3,0,1]
+    k = key_max(k, key_dpp<0x141>(k));      // row_half_mirror
+    k = key_max(k, key_dpp<0x140>(k));      // row_mirror
+    return k;
+}
+
+__device__ inline key_t read_lane_key(key_t k, int lane)
+{
+    return ((key_t) (unsigned) __builtin_amdgcn_readlane((int) (k >> 32), lane) << 32)
+           | (unsigned) __builtin_amdgcn_readlane((int) k, lane);
+}
+
+// Maximum over a 1024-thread block, the same (uniform) value in every thread.  `s_keys` [16] is
+// shared scratch; two uses must be separated by a barrier.
+__device__ inline key_t block_max_key(key_t k, key_t *s_keys)
+{
+    k = row_max_key(k);
+    const key_t w = key_max(key_max(read_lane_key(k, 0), read_lane_key(k, 16)),
+                            key_max(read_lane_key(k, 32), read_lane_key(k, 48)));
+    if ((threadIdx.x & 63) == 0)
+        s_keys[threadIdx.x >> 6] = w;
+    __syncthreads();
+    k = row_max_key(s_keys[threadIdx.x & 15]);
+    return read_lane_key(k, 0);
+}
+
+#ifdef KIMG_CLEAN_STAMPS
+#define STAMP(i) do { if (bid == 0 && tid == 0) stamps[i] = (int) wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// The kernel is one chain of dependent steps executed once, so what counts is the latency of
+// every step on the chain (global round trips ~0.8 us, LDS round trips and barriers ~0.1 us),
+// not throughput: reductions use DPP and one LDS exchange, state words travel as one 16-byte load.
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_fused_kernel(
+    float *dirty, float *model, int64_t row_stride, int64_t pol_stride, int width, int height,
+    int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+    int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
+    int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain, float threshold,
+    fused_scratch *scratch, int parity, float *log)
+{
+    __shared__ int s_ptile[1024];       // per owner thread: the tile a delta rewrites, or -1
+    __shared__ float s_pval[1024];
+    __shared__ key_t s_keys[16];
+    __shared__ int s_pos[2];
+    __shared__ float s_pix[4];
+    const fused_state *cur = &scratch->st[parity];
+    fused_state *next = &scratch->st[parity ^ 1];
+    const delta_t *din = scratch->deltas[parity];
+    delta_t *dout = scratch->deltas[parity ^ 1];
+    float *tile_pix = reinterpret_cast<float *>(scratch + 1);
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+#ifdef KIMG_CLEAN_STAMPS
+    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
+
+    // ---- round trip 1: state, previous deltas, first round of tile maxima ------------------
+    // Thread (b, a) = (tid >> 5, tid & 31) owns the tiles (ty, tx) with ty % 32 == b and
+    // tx % 32 == a: a PSF patch spans fewer than 32 tiles either way, so no two deltas share
+    // an owner and a delta reaches its owner through one LDS slot.
+    const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, num_deltas
+    const int count = st.x, done = st.y, limit = st.z, nd = st.w;
+    delta_t d;
+    d.tile = -1;
+    if (tid < FUSED_MAX_BLOCKS)
+        d = din[tid];
+    const int own_x = tid & 31, own_y = tid >> 5;
+    const int sup_x = (tiles_x + 31) >> 5, sup_y = (tiles_y + 31) >> 5;
+    const int slots = sup_x * sup_y;
+    // tile index of each of this thread's slots (32x32-tile groups in row-major order), -1 if
+    // outside the lattice; advanced without divisions
+    int sx = 0, sy = 0;
+    auto next_slot = [&]() __attribute__((always_inline)) {
+        const int ty_ = own_y + 32 * sy, tx_ = own_x + 32 * sx;
+        const int i = (sy < sup_y && ty_ < tiles_y && tx_ < tiles_x) ? ty_ * tiles_x + tx_ : -1;
+        sx++;
+        if (sx == sup_x) {
+            sx = 0;
+            sy++;
+        }
+        return i;
+    };
+    int ti[FUSED_ROUND];
+    float v[FUSED_ROUND];
+#pragma unroll
+    for (int k = 0; k < FUSED_ROUND; k++) {
+        ti[k] = next_slot();
+        v[k] = tile_max[ti[k] < 0 ? 0 : ti[k]];     // (unconditional: no branch per load)
+    }
+    s_ptile[tid] = -1;
+    if (done) {
+        if (bid == 0 && tid == 0)
+            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
+        return;
+    }
+    __syncthreads();
+    const bool live = tid < nd && d.tile >= 0;
+    if (live) {
+        // (delta records carry their tile row, so that no division is needed here)
+        const int dty = d.y_tile, dtx = d.tile - d.y_tile * tiles_x;
+        const int owner = (dty & 31) * 32 + (dtx & 31);
+        s_ptile[owner] = d.tile;
+        s_pval[owner] = d.value;
+        if (bid == 0)
+            apply_delta(d, tile_max, tile_pos, tile_pix);
+    }
+    __syncthreads();
+    const int ptile = s_ptile[tid];
+    const float pval = s_pval[tid];
+    STAMP(1);
+    key_t best = 0;
+    for (int r = 0; r * FUSED_ROUND < slots; r++) {
+        if (r > 0) {
+#pragma unroll
+            for (int k = 0; k < FUSED_ROUND; k++) {
+                ti[k] = next_slot();
+                v[k] = tile_max[ti[k] < 0 ? 0 : ti[k]];
+            }
+        }
+        key_t c[FUSED_ROUND];
+#pragma unroll
+        for (int k = 0; k < FUSED_ROUND; k++) {
+            const float val = ti[k] == ptile ? pval : v[k];     // rewritten by the previous cycle
+            c[k] = ti[k] >= 0 ? make_key(val, ti[k]) : 0;
+        }
+#pragma unroll
+        for (int w = FUSED_ROUND / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; k++)
+                c[k] = key_max(c[k], c[k + w]);
+        best = key_max(best, c[0]);
+    }
+    best = block_max_key(best, s_keys);
+    STAMP(2);
+    const int t = ~(int) (unsigned) best;
+    const float value = __uint_as_float((unsigned) (best >> 32));
+    if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
+        if (bid == 0 && tid == 0)
+            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
+        return;
+    }
+
+    // ---- round trip 2: position and pixel values of the winning tile -----------------------
+    // (from the delta if the previous cycle rewrote it, from the base arrays otherwise; the
+    // deltas live in the registers of wave 0)
+    if (tid < 64) {
+        const unsigned long long hit = __ballot(live && d.tile == t);
+        if (hit) {
+            if (live && d.tile == t) {
+                s_pos[0] = d.y;
+                s_pos[1] = d.x;
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    s_pix[p] = d.pix[p];
+            }
+        } else if (tid < 6) {
+            if (tid < 2)
+                s_pos[tid] = tile_pos[2 * t + tid];
+            else
+                s_pix[tid - 2] = tile_pix[4 * t + tid - 2];
+        }
+    }
+    __syncthreads();
+    const int py = s_pos[0], px = s_pos[1];
+    if (value == 0.0f) {
+        // a tile without any positive metric won: its record holds the (x0, y0) start position
+        // of clean.py:950, whose pixel is read now, as the two-launch form does
+        __syncthreads();
+        if (tid < 4) {
+            const bool ok = py >= 0 && py < height && px >= 0 && px < width && tid < P;
+            s_pix[tid] = ok ? dirty[tid * pol_stride + (int64_t) py * row_stride + px] : 0.0f;
+        }
+        __syncthreads();
+    }
+    float scale[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+        scale[p] = loop_gain * s_pix[p];                            // clean.py:1044
+    STAMP(3);
+
+    // ---- round trip 3: this block's pixels -----------------------------------------------
+    const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
+    const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
+    const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
+    const int tx = bx0 + (int) blockIdx.x, ty = by0 + (int) blockIdx.y;
+    const int ox = tx * TILE + border, oy = ty * TILE + border;
+    const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;
+    const bool is_tile = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;
+    const int x = ox + (tid & 31), y = oy + (tid >> 5);
+    const bool inside = x >= 0 && x < width && y >= 0 && y < height;
+    const int64_t ia = (int64_t) y * row_stride + x;
+    const bool in_patch = inside && x >= x0 && x < x0 + patch_w && y >= y0 && y < y0 + patch_h;
+    const bool in_tile = inside && is_tile && x < width - border && y < height - border;
+    float dv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float mod = 0.0f;
+    const bool logger = bid == 0 && tid < P;
+    if (inside)
+        for (int p = 0; p < P; p++)
+            dv[p] = dirty[p * pol_stride + ia];
+    if (in_patch)
+        for (int p = 0; p < P; p++)
+            pv[p] = psf[p * psf_pol_stride + (int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
+    if (logger)
+        mod = model[tid * pol_stride + (int64_t) py * row_stride + px];
+    float metric = 0.0f;
+#ifdef KIMG_CLEAN_STAMPS
+    if (dv[0] + pv[0] + mod == 12345.678f)
+        stamps[7] = 1;
+    STAMP(4);
+#endif
+    for (int p = 0; p < P; p++) {
+        if (in_patch) {
+            const float tp = scale[p] * pv[p];
+            dv[p] -= tp;
+            dirty[p * pol_stride + ia] = dv[p];
+        }
+        if (MODE == KIMG_CLEAN_I) {
+            if (p == 0)
+                metric = fabsf(dv[0]);
+        } else {
+            metric += dv[p] * dv[p];
+        }
+    }
+    if (logger) {
+        float *entry = log + (int64_t) count * (3 + P);
+        if (tid == 0) {
+            entry[0] = value;
+            entry[1] = __int_as_float(py);
+            entry[2] = __int_as_float(px);
+            *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, gridDim.x * gridDim.y);
+        }
+        entry[3 + tid] = scale[tid];
+        model[tid * pol_stride + (int64_t) py * row_stride + px] = mod + scale[tid];   // clean.py:1047
+    }
+    if (!is_tile) {
+        if (tid == 0)
+            dout[bid].tile = -1;
+        return;
+    }
+    // first strict maximum in row-major order; only positive metrics count (clean.py:953-958)
+    const key_t tb = block_max_key((in_tile && metric > 0.0f) ? make_key(metric, tid) : 0, s_keys);
+    const int widx = ~(int) (unsigned) tb;
+#ifdef KIMG_CLEAN_STAMPS
+    STAMP(5);
+    if (bid == 0 && tid == 0)
+        for (int i = 0; i < 8; i++)
+            next->pad[i] = stamps[i];
+#endif
+    if (tb == 0) {
+        // no positive metric: value 0 and the (x0, y0) initial position of clean.py:950
+        if (tid == 0) {
+            delta_t o;
+            o.tile = ty * tiles_x + tx;
+            o.y_tile = ty;
+            o.value = 0.0f;
+            o.y = ox;
+            o.x = oy;
+            for (int p = 0; p < 4; p++)
+                o.pix[p] = 0.0f;        // read when (if ever) this tile wins, see above
+            dout[bid] = o;
+        }
+    } else if (tid == widx) {
+        delta_t o;
+        o.tile = ty * tiles_x + tx;
+        o.y_tile = ty;
+        o.value = metric;
+        o.y = y;
+        o.x = x;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            o.pix[p] = dv[p];
+        dout[bid] = o;
+    }
+}
+
+// Pixel values at every tile's peak position (the part of a tile record the tile scan of
+// kimg_update_tiles does not produce); once per kimg_clean_cycles call.
+__global__ __launch_bounds__(256) void tile_pix_kernel(
+    const float *__restrict__ dirty, int64_t row_stride, int64_t pol_stride, int width,
+    int height, int P, const int32_t *__restrict__ tile_pos, int num_tiles,
+    fused_scratch *scratch)
+{
+    float *tile_pix = reinterpret_cast<float *>(scratch + 1);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= num_tiles)
+        return;
+    const int y = tile_pos[2 * t], x = tile_pos[2 * t + 1];
+    const bool ok = y >= 0 && y < height && x >= 0 && x < width;
+    for (int p = 0; p < 4; p++)
+        tile_pix[4 * t + p] = (ok && p < P) ? dirty[p * pol_stride + (int64_t) y * row_stride + x] : 0.0f;
+}
+
+// Fold the deltas of the last cycle into the base tile arrays (the state left by an even number
+// of cycle launches is st[0], its pending deltas are deltas[0]).
+__global__ void apply_deltas_kernel(fused_scratch *scratch, float *tile_max, int32_t *tile_pos)
+{
+    float *tile_pix = reinterpret_cast<float *>(scratch + 1);
+    const int nd = scratch->st[0].num_deltas;
+    if ((int) threadIdx.x < nd) {
+        const delta_t d = scratch->deltas[0][threadIdx.x];
+        if (d.tile >= 0)
+            apply_delta(d, tile_max, tile_pos, tile_pix);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        scratch->st[0].num_deltas = 0;
+}
+
 // ---- PSF patch bound ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void psf_patch_kernel(
     const float *__restrict__ psf, int64_t row_stride, int64_t pol_stride, int P,
@@ -531,10 +917,13 @@ extern "C" int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride,
     return kimg_launch_status();
 }
 
-extern "C" size_t kimg_clean_state_bytes(int num_polarizations)
+extern "C" size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int tiles_y)
 {
     (void) num_polarizations;
-    return sizeof(clean_state);
+    static_assert(sizeof(fused_scratch) >= sizeof(clean_state), "the two forms share the scratch");
+    if (tiles_x <= 0 || tiles_y <= 0)
+        return 0;
+    return sizeof(fused_scratch) + (size_t) tiles_x * tiles_y * 4 * sizeof(float);
 }
 
 namespace {
@@ -557,13 +946,30 @@ struct cycle_args {
     int tiles_x, tiles_y;
     clean_state *state;
     float *log;
+    int fused;              // one launch per cycle (state is then a fused_scratch)
 };
 
 // One minor cycle = two dependent launches (peak + threshold test, then subtract + tile update).
-int enqueue_cycle(const cycle_args &a, hipStream_t s)
+int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 {
     dim3 g(kimg_divup(a.patch_width, TILE) + 1, kimg_divup(a.patch_height, TILE) + 1);
     const int num_tiles = a.tiles_x * a.tiles_y;
+    if (a.fused) {
+        fused_scratch *fs = reinterpret_cast<fused_scratch *>(a.state);
+        if (a.mode == KIMG_CLEAN_I)
+            cycle_fused_kernel<KIMG_CLEAN_I><<<g, 1024, 0, s>>>(
+                a.dirty, a.model, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf,
+                a.psf_row_stride, a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width,
+                a.patch_height, a.border, a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y,
+                a.loop_gain, a.threshold, fs, index & 1, a.log);
+        else
+            cycle_fused_kernel<KIMG_CLEAN_SUMSQ><<<g, 1024, 0, s>>>(
+                a.dirty, a.model, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf,
+                a.psf_row_stride, a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width,
+                a.patch_height, a.border, a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y,
+                a.loop_gain, a.threshold, fs, index & 1, a.log);
+        return kimg_launch_status();
+    }
     if (a.mode == KIMG_CLEAN_I) {
         cycle_find_peak_kernel<KIMG_CLEAN_I><<<1, 1024, 0, s>>>(
             a.dirty, a.model, a.row_stride, a.pol_stride, a.P, a.tile_max, a.tile_pos, num_tiles,
@@ -610,7 +1016,7 @@ hipGraphExec_t cycles_graph(const cycle_args &a, hipStream_t s)
         return nullptr;
     int rc = 0;
     for (int i = 0; i < GRAPH_CYCLES && rc == 0; i++)
-        rc = enqueue_cycle(a, s);
+        rc = enqueue_cycle(a, s, i);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || rc != 0)
         return nullptr;
     hipGraphExec_t exec = nullptr;
@@ -644,8 +1050,19 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
     hipStream_t s = (hipStream_t) stream;
-    KIMG_HIP(hipMemsetAsync(state, 0, sizeof(clean_state), s));
+    // one launch per cycle when the patch touches few lattice blocks (every workgroup then
+    // repeats the global peak search); KIMG_CLEAN_FUSED=0 forces the two-launch form
+    const char *fenv = getenv("KIMG_CLEAN_FUSED");
+    const int bx = kimg_divup(patch_width, TILE) + 1, by = kimg_divup(patch_height, TILE) + 1;
+    const bool fused = bx * by <= FUSED_MAX_BLOCKS && bx <= 32 && by <= 32
+                       && kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) <= FUSED_MAX_SLOTS
+                       && !(fenv && fenv[0] == '0');
+    KIMG_HIP(hipMemsetAsync(state, 0, sizeof(fused_scratch), s));
     init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(state), max_cycles);
+    if (fused)
+        tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
+            dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
+            tiles_x * tiles_y, static_cast<fused_scratch *>(state));
     cycle_args a;
     memset(&a, 0, sizeof(a));       // padding bytes take part in the cache key comparison
     a.dirty = dirty; a.model = model; a.row_stride = row_stride; a.pol_stride = pol_stride;
@@ -655,21 +1072,27 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     a.patch_height = patch_height; a.border = border; a.mode = mode; a.loop_gain = loop_gain;
     a.threshold = threshold; a.tile_max = tile_max; a.tile_pos = tile_pos; a.tiles_x = tiles_x;
     a.tiles_y = tiles_y; a.state = static_cast<clean_state *>(state); a.log = log;
+    a.fused = fused;
     int done = 0;
     if (max_cycles >= GRAPH_CYCLES / 2) {
         hipGraphExec_t exec = cycles_graph(a, s);
         if (exec) {
             for (; done < max_cycles; done += GRAPH_CYCLES)
                 KIMG_HIP(hipGraphLaunch(exec, s));
-            return 0;
+            done = max_cycles;
         }
     }
-    for (; done < max_cycles; done++) {
-        int rc = enqueue_cycle(a, s);
+    // (an even number of launches, so that the fused form leaves its state in st[0]; the
+    // device-side limit makes the surplus one a no-op)
+    for (int i = 0; done < max_cycles || (i & 1); done++, i++) {
+        int rc = enqueue_cycle(a, s, i);
         if (rc)
             return rc;
     }
-    return 0;
+    if (fused)
+        apply_deltas_kernel<<<1, FUSED_MAX_BLOCKS, 0, s>>>(static_cast<fused_scratch *>(state),
+                                                           tile_max, tile_pos);
+    return kimg_launch_status();
 }
 
 extern "C" int kimg_psf_patch(const float *psf, int64_t row_stride, int64_t pol_stride,

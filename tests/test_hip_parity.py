@@ -1258,3 +1258,60 @@ def test_device_kernel_table_arguments():
     ip, gp, _ = make_params(c)
     with pytest.raises(ValueError):
         grid.ConvolutionKernelDevice(ctx, ip, gp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('G,P,mode,border,patch', [
+    (1512, 1, 0, 0.02, (111, 133)),      # 46 x 46 tiles: 2 x 2 groups of 32 x 32 tiles per thread
+    (1200, 4, 1, 0.0, (65, 97)),         # sum of squares over 4 polarizations, no border
+    (2592, 1, 0, 0.1, (31, 31)),         # 3 x 3 groups, wide border, tiny patch
+    (1120, 2, 0, 0.02, (225, 193)),      # 9 x 8 = 72 lattice blocks: too many, two-launch form
+])
+def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
+    """The one-launch-per-cycle form (every workgroup repeats the peak search, tile records in
+    flight as deltas) against the two-launch form on the same problem: log, images and the tile
+    arrays left behind are bit-identical, over consecutive calls and mixed with single cycles."""
+    import os
+    from katsdpimager_amd import clean, parameters
+    ctx, q = context_queue()
+    rs = np.random.RandomState(G + P)
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2)
+    psf = np.repeat((np.outer(g1, g1) + 0.02 * np.cos(np.arange(G) / 7.0)[None, :] * g1[:, None])
+                    [None].astype(np.float32), P, axis=0)
+    dirty = (0.05 * rs.standard_normal((P, G, G))).astype(np.float32)
+    for _ in range(60):
+        y, x = rs.randint(0, G, 2)
+        dirty[:, y, x] += rs.uniform(1.0, 5.0, P).astype(np.float32) * rs.choice([-1, 1])
+    dirty[:, 3, 5] = 40.0                # inside the border zone: must never be picked
+    dirty[:, G // 2, G // 2] = dirty[:, G // 2 + 40, G // 2 - 64] = 7.0     # an exact tie
+    fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
+    cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, mode, 0.01, 0.5, border)
+    full_patch = (P,) + patch
+
+    def run(fused):
+        os.environ['KIMG_CLEAN_FUSED'] = '1' if fused else '0'
+        try:
+            fn = clean.CleanTemplate(ctx, cp, np.float32, P).instantiate(q, ip)
+            fn.ensure_all_bound()
+            fn.buffer('dirty').set(q, dirty)
+            fn.buffer('psf').set(q, psf)
+            fn.buffer('model').zero(q)
+            fn.reset()
+            log = fn.run_cycles(full_patch, 0.0, 150)
+            log.append(fn(full_patch, 0.0))                  # a single cycle on the tiles left behind
+            log += fn.run_cycles(full_patch, 0.0, 37)        # odd count, below the graph size
+            first = log[0][0]
+            log += fn.run_cycles(full_patch, 0.7 * first, 500)        # stops at the threshold
+            return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
+                    fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
+        finally:
+            os.environ.pop('KIMG_CLEAN_FUSED', None)
+    a, b = run(True), run(False)
+    assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 688
+    for u, w in zip(a[0], b[0]):
+        assert u[0] == w[0] and tuple(u[1]) == tuple(w[1])
+        np.testing.assert_array_equal(u[2], w[2])
+    for u, w in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(u, w)
+    assert border == 0.0 or (3, 5) not in [tuple(e[1]) for e in a[0]]
