@@ -1,6 +1,6 @@
 // How long does a dependent kernel in a hipGraph take as a function of the straight-line code
 // it executes?  One wave per kernel, N unrolled dependent FMAs (8 bytes of code each, ~8 cycles
-// of execution each), 256 kernels per graph.  Build: hipcc -O3 --offload-arch=gfx950
+// of execution each), 256 kernels per graph.  Build: hipcc -O3 --offload-arch=gfx950 -o tools/graph_chain_latency tools/graph_chain_latency.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
