@@ -423,6 +423,19 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
         q.finish()
         out['clean_%s_cycles_per_s' % label] = round(done / (time.perf_counter() - t0), 1)
     out['clean_psf_patch'] = list(patch)
+    # the same with the patch of a measured PSF (111 x 133, the --major-loop case): few lattice
+    # blocks, so the cycle is ONE launch (every workgroup repeats the peak search)
+    small = (P, min(111, patch[1]), min(133, patch[2]))
+    for label in ('warm', 'timed'):
+        cl.buffer('dirty').set(q, sky)
+        cl.buffer('model').zero(q)
+        cl.reset()
+        q.finish()
+        t0 = time.perf_counter()
+        done = len(cl.run_cycles(small, 0.0, args.clean_cycles))
+        q.finish()
+        out['clean_small_patch_cycles_per_s'] = round(done / (time.perf_counter() - t0), 1)
+    out['clean_small_patch'] = list(small)
 
     # degridder over every chunk of the channel (hot loop of the 2nd+ major cycles with --degrid,
     # frontend.py:128-139): vis -= weights * degrid(model grid)

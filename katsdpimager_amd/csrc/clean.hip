@@ -345,9 +345,12 @@ constexpr int FUSED_MAX_BLOCKS = 64;
 constexpr int FUSED_ROUND = 16;                 // tile maxima per thread and round
 constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
 
+// A tile record rewritten by one cycle and consumed by the next, stored at the slot of the thread
+// that owns the tile in the peak search (see cycle_fused_kernel).  `tag` = 2 + the cycle that wrote
+// it: a record is live for exactly the cycle after (0 = never written; the table is cleared per call).
 struct delta_t {
-    int tile;               // -1: the block is not a tile
-    int y_tile;             // tile / tiles_x
+    int tag;
+    int tile;
     float value;
     int y, x;
     float pix[4];
@@ -355,13 +358,13 @@ struct delta_t {
 };
 
 struct fused_state {
-    int count, done, limit, num_deltas;
+    int count, done, limit, unused;
     int pad[12];
 };
 
 struct fused_scratch {
     fused_state st[2];
-    delta_t deltas[2][FUSED_MAX_BLOCKS];
+    delta_t deltas[2][1024];
     // float tile_pix[tiles][4] follows
 };
 
@@ -443,8 +446,6 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain, float threshold,
     fused_scratch *scratch, int parity, float *log)
 {
-    __shared__ int s_ptile[1024];       // per owner thread: the tile a delta rewrites, or -1
-    __shared__ float s_pval[1024];
     __shared__ key_t s_keys[16];
     __shared__ int s_pos[2];
     __shared__ float s_pix[4];
@@ -460,85 +461,80 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
 #endif
     STAMP(0);
 
-    // ---- round trip 1: state, previous deltas, first round of tile maxima ------------------
+    // ---- round trip 1: state, this thread's delta, first round of tile maxima --------------
     // Thread (b, a) = (tid >> 5, tid & 31) owns the tiles (ty, tx) with ty % 32 == b and
-    // tx % 32 == a: a PSF patch spans fewer than 32 tiles either way, so no two deltas share
-    // an owner and a delta reaches its owner through one LDS slot.
-    const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, num_deltas
-    const int count = st.x, done = st.y, limit = st.z, nd = st.w;
-    delta_t d;
-    d.tile = -1;
-    if (tid < FUSED_MAX_BLOCKS)
-        d = din[tid];
-    const int own_x = tid & 31, own_y = tid >> 5;
+    // tx % 32 == a, in slots = 32x32-tile groups in row-major order.  A PSF patch spans fewer than
+    // 32 tiles either way, so a cycle rewrites at most one tile per owner: the delta table has one
+    // slot per thread and needs no search.
+    const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, -
+    const int count = st.x, done = st.y, limit = st.z;
+    const delta_t d = din[tid];
     const int sup_x = (tiles_x + 31) >> 5, sup_y = (tiles_y + 31) >> 5;
     const int slots = sup_x * sup_y;
-    // tile index of each of this thread's slots (32x32-tile groups in row-major order), -1 if
-    // outside the lattice; advanced without divisions
-    int sx = 0, sy = 0;
-    auto next_slot = [&]() __attribute__((always_inline)) {
-        const int ty_ = own_y + 32 * sy, tx_ = own_x + 32 * sx;
-        const int i = (sy < sup_y && ty_ < tiles_y && tx_ < tiles_x) ? ty_ * tiles_x + tx_ : -1;
+    const int last = tiles_x * tiles_y - 1;
+    const int own = (tid >> 5) * tiles_x + (tid & 31);
+    const int own_x = tid & 31, own_y = tid >> 5;
+    // (uniform) per slot: tile-index offset and how many owner columns / rows are on the lattice
+    int sx = 0, off = 0, lim_x = tiles_x, lim_y = tiles_y;
+    auto next_slot = [&](bool &valid) __attribute__((always_inline)) {
+        const int i = min(own + off, last);
+        valid = own_x < lim_x && own_y < lim_y;
         sx++;
+        off += 32;
+        lim_x -= 32;
         if (sx == sup_x) {
             sx = 0;
-            sy++;
+            off += 32 * tiles_x - 32 * sup_x;
+            lim_x = tiles_x;
+            lim_y -= 32;
         }
         return i;
     };
     int ti[FUSED_ROUND];
     float v[FUSED_ROUND];
+    bool ok[FUSED_ROUND];
 #pragma unroll
     for (int k = 0; k < FUSED_ROUND; k++) {
-        ti[k] = next_slot();
-        v[k] = tile_max[ti[k] < 0 ? 0 : ti[k]];     // (unconditional: no branch per load)
+        ti[k] = next_slot(ok[k]);
+        v[k] = tile_max[ti[k]];
     }
-    s_ptile[tid] = -1;
     if (done) {
         if (bid == 0 && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
         return;
     }
-    __syncthreads();
-    const bool live = tid < nd && d.tile >= 0;
-    if (live) {
-        // (delta records carry their tile row, so that no division is needed here)
-        const int dty = d.y_tile, dtx = d.tile - d.y_tile * tiles_x;
-        const int owner = (dty & 31) * 32 + (dtx & 31);
-        s_ptile[owner] = d.tile;
-        s_pval[owner] = d.value;
-        if (bid == 0)
-            apply_delta(d, tile_max, tile_pos, tile_pix);
-    }
-    __syncthreads();
-    const int ptile = s_ptile[tid];
-    const float pval = s_pval[tid];
+    const bool live = d.tag == count + 1;
+    const int ptile = live ? d.tile : -1;
+    if (live && bid == 0)
+        apply_delta(d, tile_max, tile_pos, tile_pix);
     STAMP(1);
-    key_t best = 0;
+    float bv = -1.0f;
+    int bi = 0;
     for (int r = 0; r * FUSED_ROUND < slots; r++) {
         if (r > 0) {
 #pragma unroll
             for (int k = 0; k < FUSED_ROUND; k++) {
-                ti[k] = next_slot();
-                v[k] = tile_max[ti[k] < 0 ? 0 : ti[k]];
+                ti[k] = next_slot(ok[k]);
+                v[k] = tile_max[ti[k]];
             }
         }
-        key_t c[FUSED_ROUND];
+        // slots come in non-decreasing tile order: the first strict maximum has the lowest index
 #pragma unroll
         for (int k = 0; k < FUSED_ROUND; k++) {
-            const float val = ti[k] == ptile ? pval : v[k];     // rewritten by the previous cycle
-            c[k] = ti[k] >= 0 ? make_key(val, ti[k]) : 0;
+            const float val = ti[k] == ptile ? d.value : v[k];  // rewritten by the previous cycle
+            if (r * FUSED_ROUND + k < slots && ok[k] && val > bv) {
+                bv = val;
+                bi = ti[k];
+            }
         }
-#pragma unroll
-        for (int w = FUSED_ROUND / 2; w > 0; w >>= 1)
-#pragma unroll
-            for (int k = 0; k < w; k++)
-                c[k] = key_max(c[k], c[k + w]);
-        best = key_max(best, c[0]);
     }
+    // low word: ~index above a flag "this record is the thread's delta"
+    key_t best = bv < 0.0f ? 0
+        : ((key_t) __float_as_uint(bv) << 32) | ((unsigned) ~bi << 1) | (unsigned) (bi == ptile);
     best = block_max_key(best, s_keys);
     STAMP(2);
-    const int t = ~(int) (unsigned) best;
+    const int t = (int) (~((unsigned) best >> 1) & 0x7fffffffu);
+    const bool from_delta = (unsigned) best & 1u;
     const float value = __uint_as_float((unsigned) (best >> 32));
     if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
         if (bid == 0 && tid == 0)
@@ -547,24 +543,20 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     }
 
     // ---- round trip 2: position and pixel values of the winning tile -----------------------
-    // (from the delta if the previous cycle rewrote it, from the base arrays otherwise; the
-    // deltas live in the registers of wave 0)
-    if (tid < 64) {
-        const unsigned long long hit = __ballot(live && d.tile == t);
-        if (hit) {
-            if (live && d.tile == t) {
-                s_pos[0] = d.y;
-                s_pos[1] = d.x;
+    // (in its owner's registers if the previous cycle rewrote it, in the base arrays otherwise)
+    if (from_delta) {
+        if (ptile == t) {
+            s_pos[0] = d.y;
+            s_pos[1] = d.x;
 #pragma unroll
-                for (int p = 0; p < 4; p++)
-                    s_pix[p] = d.pix[p];
-            }
-        } else if (tid < 6) {
-            if (tid < 2)
-                s_pos[tid] = tile_pos[2 * t + tid];
-            else
-                s_pix[tid - 2] = tile_pix[4 * t + tid - 2];
+            for (int p = 0; p < 4; p++)
+                s_pix[p] = d.pix[p];
         }
+    } else if (tid < 6) {
+        if (tid < 2)
+            s_pos[tid] = tile_pos[2 * t + tid];
+        else
+            s_pix[tid - 2] = tile_pix[4 * t + tid - 2];
     }
     __syncthreads();
     const int py = s_pos[0], px = s_pos[1];
@@ -633,16 +625,13 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
             entry[0] = value;
             entry[1] = __int_as_float(py);
             entry[2] = __int_as_float(px);
-            *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, gridDim.x * gridDim.y);
+            *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, 0);
         }
         entry[3 + tid] = scale[tid];
         model[tid * pol_stride + (int64_t) py * row_stride + px] = mod + scale[tid];   // clean.py:1047
     }
-    if (!is_tile) {
-        if (tid == 0)
-            dout[bid].tile = -1;
+    if (!is_tile)
         return;
-    }
     // first strict maximum in row-major order; only positive metrics count (clean.py:953-958)
     const key_t tb = block_max_key((in_tile && metric > 0.0f) ? make_key(metric, tid) : 0, s_keys);
     const int widx = ~(int) (unsigned) tb;
@@ -652,30 +641,28 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
         for (int i = 0; i < 8; i++)
             next->pad[i] = stamps[i];
 #endif
-    if (tb == 0) {
-        // no positive metric: value 0 and the (x0, y0) initial position of clean.py:950
-        if (tid == 0) {
-            delta_t o;
-            o.tile = ty * tiles_x + tx;
-            o.y_tile = ty;
+    if (tb == 0 ? tid == 0 : tid == widx) {
+        delta_t o;
+        o.tag = count + 2;
+        o.tile = ty * tiles_x + tx;
+        if (tb == 0) {
+            // no positive metric: value 0 and the (x0, y0) initial position of clean.py:950; the
+            // pixel there is read when (if ever) this tile wins, see above
             o.value = 0.0f;
             o.y = ox;
             o.x = oy;
-            for (int p = 0; p < 4; p++)
-                o.pix[p] = 0.0f;        // read when (if ever) this tile wins, see above
-            dout[bid] = o;
-        }
-    } else if (tid == widx) {
-        delta_t o;
-        o.tile = ty * tiles_x + tx;
-        o.y_tile = ty;
-        o.value = metric;
-        o.y = y;
-        o.x = x;
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-            o.pix[p] = dv[p];
-        dout[bid] = o;
+            for (int p = 0; p < 4; p++)
+                o.pix[p] = 0.0f;
+        } else {
+            o.value = metric;
+            o.y = y;
+            o.x = x;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                o.pix[p] = dv[p];
+        }
+        dout[(ty & 31) * 32 + (tx & 31)] = o;
     }
 }
 
@@ -698,18 +685,13 @@ __global__ __launch_bounds__(256) void tile_pix_kernel(
 
 // Fold the deltas of the last cycle into the base tile arrays (the state left by an even number
 // of cycle launches is st[0], its pending deltas are deltas[0]).
-__global__ void apply_deltas_kernel(fused_scratch *scratch, float *tile_max, int32_t *tile_pos)
+__global__ __launch_bounds__(1024) void apply_deltas_kernel(fused_scratch *scratch, float *tile_max,
+                                                            int32_t *tile_pos)
 {
     float *tile_pix = reinterpret_cast<float *>(scratch + 1);
-    const int nd = scratch->st[0].num_deltas;
-    if ((int) threadIdx.x < nd) {
-        const delta_t d = scratch->deltas[0][threadIdx.x];
-        if (d.tile >= 0)
-            apply_delta(d, tile_max, tile_pos, tile_pix);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        scratch->st[0].num_deltas = 0;
+    const delta_t d = scratch->deltas[0][threadIdx.x];
+    if (d.tag == scratch->st[0].count + 1)
+        apply_delta(d, tile_max, tile_pos, tile_pix);
 }
 
 // ---- PSF patch bound ---------------------------------------------------------------------
@@ -1090,8 +1072,8 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
             return rc;
     }
     if (fused)
-        apply_deltas_kernel<<<1, FUSED_MAX_BLOCKS, 0, s>>>(static_cast<fused_scratch *>(state),
-                                                           tile_max, tile_pos);
+        apply_deltas_kernel<<<1, 1024, 0, s>>>(static_cast<fused_scratch *>(state), tile_max,
+                                               tile_pos);
     return kimg_launch_status();
 }
 
