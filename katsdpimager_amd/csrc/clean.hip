@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
 // in the middle.  When the PSF patch touches few lattice blocks, every workgroup of the
 // subtract/update launch can afford to find the global peak ITSELF (the tile maxima are 64 KB at
 // 4096^2), so the cycle becomes one launch with no communication between its workgroups:
+//     (measured at 4096^2: 7.7 us per cycle up to 64 blocks, 8.5 at 256 = one block per CU, 11.5 at
+//     441 -- two rounds of workgroups -- against 11-12.2 for two launches; 15.4 vs 12.8 at 552)
 //   * all workgroups read the same inputs -- the base tile arrays plus a short list of "deltas"
 //     (the tile records rewritten by the previous cycle) -- and therefore pick the same peak;
 //   * each then subtracts the PSF from its own lattice block, rescans it, and writes the new tile
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
 //     writes the log entry, the model pixel and the next state.
 // Tile records carry the pixel values at the tile's peak (tile_pix), which saves the dependent
 // load of the peak pixel.  Selection and arithmetic are those of the two-launch form, bit for bit.
-constexpr int FUSED_MAX_BLOCKS = 64;
+constexpr int FUSED_MAX_BLOCKS = 448;     // measured break-even with the two-launch form (see below)
 constexpr int FUSED_ROUND = 16;                 // tile maxima per thread and round
 constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
 
@@ -1036,7 +1038,9 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     // repeats the global peak search); KIMG_CLEAN_FUSED=0 forces the two-launch form
     const char *fenv = getenv("KIMG_CLEAN_FUSED");
     const int bx = kimg_divup(patch_width, TILE) + 1, by = kimg_divup(patch_height, TILE) + 1;
-    const bool fused = bx * by <= FUSED_MAX_BLOCKS && bx <= 32 && by <= 32
+    const char *benv = getenv("KIMG_CLEAN_FUSED_BLOCKS");       // timing experiments only
+    const int max_blocks = benv ? atoi(benv) : FUSED_MAX_BLOCKS;
+    const bool fused = bx * by <= max_blocks && bx <= 32 && by <= 32
                        && kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) <= FUSED_MAX_SLOTS
                        && !(fenv && fenv[0] == '0');
     KIMG_HIP(hipMemsetAsync(state, 0, sizeof(fused_scratch), s));

@@ -1265,7 +1265,7 @@ def test_device_kernel_table_arguments():
     (1512, 1, 0, 0.02, (111, 133)),      # 46 x 46 tiles: 2 x 2 groups of 32 x 32 tiles per thread
     (1200, 4, 1, 0.0, (65, 97)),         # sum of squares over 4 polarizations, no border
     (2592, 1, 0, 0.1, (31, 31)),         # 3 x 3 groups, wide border, tiny patch
-    (1120, 2, 0, 0.02, (225, 193)),      # 9 x 8 = 72 lattice blocks: too many, two-launch form
+    (1120, 2, 0, 0.02, (225, 193)),      # 9 x 8 = 72 lattice blocks, more than one per tile column group
 ])
 def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
     """The one-launch-per-cycle form (every workgroup repeats the peak search, tile records in
