@@ -530,35 +530,31 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
             }
         }
     }
-    // low word: ~index above a flag "this record is the thread's delta"
-    key_t best = bv < 0.0f ? 0
-        : ((key_t) __float_as_uint(bv) << 32) | ((unsigned) ~bi << 1) | (unsigned) (bi == ptile);
-    best = block_max_key(best, s_keys);
+    // The record of this thread's candidate is fetched now, before it is known whether the
+    // candidate wins: the loads overlap the block reduction instead of following it.
+    const bool mine_delta = bi == ptile;
+    int2 cpos = make_int2(d.y, d.x);
+    float4 cpix = make_float4(d.pix[0], d.pix[1], d.pix[2], d.pix[3]);
+    if (bv >= 0.0f && !mine_delta) {
+        cpos = *reinterpret_cast<const int2 *>(tile_pos + 2 * bi);
+        cpix = *reinterpret_cast<const float4 *>(tile_pix + 4 * bi);
+    }
+    const key_t mykey = bv < 0.0f ? 0 : make_key(bv, bi);
+    const key_t best = block_max_key(mykey, s_keys);
     STAMP(2);
-    const int t = (int) (~((unsigned) best >> 1) & 0x7fffffffu);
-    const bool from_delta = (unsigned) best & 1u;
     const float value = __uint_as_float((unsigned) (best >> 32));
     if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
         if (bid == 0 && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
         return;
     }
-
-    // ---- round trip 2: position and pixel values of the winning tile -----------------------
-    // (in its owner's registers if the previous cycle rewrote it, in the base arrays otherwise)
-    if (from_delta) {
-        if (ptile == t) {
-            s_pos[0] = d.y;
-            s_pos[1] = d.x;
-#pragma unroll
-            for (int p = 0; p < 4; p++)
-                s_pix[p] = d.pix[p];
-        }
-    } else if (tid < 6) {
-        if (tid < 2)
-            s_pos[tid] = tile_pos[2 * t + tid];
-        else
-            s_pix[tid - 2] = tile_pix[4 * t + tid - 2];
+    if (mykey == best) {        // exactly one thread: every tile has one owner
+        s_pos[0] = cpos.x;
+        s_pos[1] = cpos.y;
+        s_pix[0] = cpix.x;
+        s_pix[1] = cpix.y;
+        s_pix[2] = cpix.z;
+        s_pix[3] = cpix.w;
     }
     __syncthreads();
     const int py = s_pos[0], px = s_pos[1];
