@@ -270,6 +270,16 @@ int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride, int64_t po
                       const float *peak_pixel, int pos_x, int pos_y, float loop_gain,
                       void *stream);
 
+/* The whole noise estimate of NoiseEst.__call__ / noise_est_host (clean.py:305-353, :938-943) without
+ * host round trips: four radix-select passes with the byte chosen on the device, the counting pass
+ * when the number of samples is even, then out[0] = median(|x| inside the border) * median_to_rms
+ * (float32 arithmetic as numpy's: (lo + hi) / 2 * scale).  scratch: kimg_noise_est_scratch_bytes()
+ * bytes of device memory, initialised by the call; out: device float32[1]. */
+size_t kimg_noise_est_scratch_bytes(void);
+int kimg_noise_est(const float *image, int64_t row_stride, int64_t pol_stride,
+                   int width, int height, int num_polarizations, int border,
+                   float median_to_rms, void *scratch, float *out, void *stream);
+
 /* Device-resident minor-cycle loop (replaces the per-cycle host round trip of
  * clean.py:848-891): runs up to `max_cycles` cycles of find-peak -> threshold test ->
  * subtract -> tile update without host synchronisation.

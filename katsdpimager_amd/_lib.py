@@ -57,6 +57,8 @@ PROTOTYPES = {
     'kimg_update_tiles': (c_int, [P, L, L, I, I, I, I, I, P, P, I, I, I, I, I, I, P]),
     'kimg_find_peak': (c_int, [P, L, L, I, P, P, I, I, P, P, P, P]),
     'kimg_subtract_psf': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, P, I, I, F, P]),
+    'kimg_noise_est_scratch_bytes': (c_size_t, []),
+    'kimg_noise_est': (c_int, [P, L, L, I, I, I, I, F, P, P, P]),
     'kimg_clean_state_bytes': (c_size_t, [I, I, I]),
     'kimg_clean_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, F,
                                   P, P, I, I, I, P, P, P]),

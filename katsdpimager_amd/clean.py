@@ -139,6 +139,8 @@ class NoiseEst(accel.Operation):
         self.border_pixels = round(border * min(image_shape[1], image_shape[2]))
         self.slots['dirty'] = accel.IOSlot(image_shape, template.dtype)
         self.slots['rank'] = accel.IOSlot((256,), np.uint32)
+        self._scratch = None
+        self._result = None
 
     def _run(self):
         pass
@@ -159,7 +161,25 @@ class NoiseEst(accel.Operation):
         return prefix
 
     def __call__(self, **kwargs):
+        """One call, one 4-byte read-back: the radix-select passes pick their byte on the device
+        (``kimg_noise_est``)."""
         self.bind(**kwargs)
+        self.ensure_all_bound()
+        dirty = self.buffer('dirty')
+        if self._scratch is None:
+            ctx = self.command_queue.context
+            self._scratch = accel.DeviceArray(
+                ctx, (lib().kimg_noise_est_scratch_bytes() // 4,), np.uint32)
+            self._result = accel.DeviceArray(ctx, (1,), np.float32)
+        rc = lib().kimg_noise_est(*_image_args(dirty), self.border_pixels,
+                                  float(np.float32(_MEDIAN_TO_RMS)), self._scratch.ptr,
+                                  self._result.ptr, self.command_queue.handle)
+        check(rc, 'kimg_noise_est')
+        return self._result.get(self.command_queue)[0]
+
+    def host_select(self):
+        """The same estimate with the byte selection on the host (one round trip per pass); kept
+        as the reference implementation of the device selection (tests)."""
         self.ensure_all_bound()
         dirty = self.buffer('dirty')
         P, H, W = dirty.shape

@@ -724,10 +724,13 @@ __global__ __launch_bounds__(256) void psf_patch_kernel(
 // ---- noise estimate: radix select on the bit pattern of |x| ------------------------------
 __global__ __launch_bounds__(256) void abs_histogram_kernel(
     const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
-    int height, int P, int border, int pass, uint32_t prefix, uint32_t *__restrict__ hist)
+    int height, int P, int border, int pass, uint32_t prefix, uint32_t *__restrict__ hist,
+    const uint32_t *__restrict__ dev_prefix)
 {
     __shared__ uint32_t local[256];
     local[threadIdx.x] = 0;
+    if (dev_prefix)
+        prefix = *dev_prefix;       // (kimg_noise_est: the prefix is chosen on the device)
     __syncthreads();
     const int shift = 8 * pass;
     // Run-length accumulation: in the first pass (sign-less exponent byte) nearly every pixel
@@ -774,8 +777,11 @@ __global__ __launch_bounds__(256) void abs_histogram_kernel(
 
 __global__ __launch_bounds__(256) void abs_count_le_kernel(
     const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
-    int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out)
+    int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ dev_value)
 {
+    if (dev_value)
+        value_bits = *dev_value;
     uint32_t count = 0, next = 0xffffffffu;
     constexpr int ROWS = 8;
     const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,7 +1105,8 @@ extern "C" int kimg_abs_histogram(const float *image, int64_t row_stride, int64_
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
     abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border, 2048), 256, 0, s>>>(
-        image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist);
+        image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist,
+        nullptr);
     return kimg_launch_status();
 }
 
@@ -1117,6 +1124,88 @@ extern "C" int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t
     const uint32_t bits = conv.u;
     abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 4096), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border,
-        bits & 0x7fffffffu, out);
+        bits & 0x7fffffffu, out, nullptr);
+    return kimg_launch_status();
+}
+
+// ---- whole noise estimate without host round trips ------------------------------------------
+namespace {
+
+struct noise_state {
+    uint32_t prefix;        // bytes of the k-th smallest |x| chosen so far
+    uint32_t k;             // rank still to resolve inside the current prefix
+    uint32_t count_le;      // number of |x| <= lower median (kimg_abs_count_le's out[0])
+    uint32_t next_bits;     // smallest |x| above it
+    uint32_t hist[256];
+};
+
+// Pick the byte whose bin holds rank k, descend into it, clear the histogram for the next pass.
+__global__ __launch_bounds__(256) void radix_select_kernel(noise_state *st)
+{
+    __shared__ uint32_t cum[256];
+    const int t = threadIdx.x;
+    const uint32_t mine = st->hist[t];
+    cum[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = t >= off ? cum[t - off] : 0;
+        __syncthreads();
+        cum[t] += add;
+        __syncthreads();
+    }
+    const uint32_t k = st->k, prefix = st->prefix;
+    const uint32_t below = cum[t] - mine;
+    __syncthreads();
+    st->hist[t] = 0;
+    if (below <= k && k < cum[t]) {         // exactly one bin
+        st->k = k - below;
+        st->prefix = (prefix << 8) | (uint32_t) t;
+        st->count_le = 0;
+        st->next_bits = 0xffffffffu;
+    }
+}
+
+__global__ void noise_init_kernel(noise_state *st, uint32_t k) { st->k = k; }
+
+__global__ void noise_result_kernel(const noise_state *st, uint32_t n, float median_to_rms,
+                                    float *out)
+{
+    const float lo = __uint_as_float(st->prefix);
+    float hi = lo;
+    if (n % 2 == 0 && st->count_le <= n / 2)   // the upper middle element is the next value up
+        hi = __uint_as_float(st->next_bits);
+    const float median = (lo + hi) / 2.0f;      // np.median of float32 data (clean.py:942)
+    *out = median * median_to_rms;
+}
+
+} // namespace
+
+extern "C" size_t kimg_noise_est_scratch_bytes(void) { return sizeof(noise_state); }
+
+extern "C" int kimg_noise_est(const float *image, int64_t row_stride, int64_t pol_stride,
+                              int width, int height, int num_polarizations, int border,
+                              float median_to_rms, void *scratch, float *out, void *stream)
+{
+    KIMG_CHECK_ARG(image && scratch && out && border >= 0 && num_polarizations >= 1);
+    KIMG_CHECK_ARG(width > 2 * border && height > 2 * border);
+    const int64_t n64 = (int64_t) (width - 2 * border) * (height - 2 * border) * num_polarizations;
+    KIMG_CHECK_ARG(n64 < ((int64_t) 1 << 32));
+    const uint32_t n = (uint32_t) n64;
+    hipStream_t s = (hipStream_t) stream;
+    noise_state *st = static_cast<noise_state *>(scratch);
+    KIMG_HIP(hipMemsetAsync(st, 0, sizeof(noise_state), s));
+    noise_init_kernel<<<1, 1, 0, s>>>(st, (n - 1) / 2);      // lower median, clean.py:938-943
+    const dim3 gh = region_grid(width - 2 * border, height - 2 * border, 2048);
+    for (int pass = 3; pass >= 0; pass--) {
+        abs_histogram_kernel<<<gh, 256, 0, s>>>(image, row_stride, pol_stride, width, height,
+                                                num_polarizations, border, pass, 0, st->hist,
+                                                &st->prefix);
+        radix_select_kernel<<<1, 256, 0, s>>>(st);
+    }
+    if (n % 2 == 0)
+        abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 4096), 256, 0, s>>>(
+            image, row_stride, pol_stride, width, height, num_polarizations, border, 0,
+            &st->count_le, &st->prefix);
+    noise_result_kernel<<<1, 1, 0, s>>>(st, n, median_to_rms, out);
     return kimg_launch_status();
 }

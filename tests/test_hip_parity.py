@@ -1315,3 +1315,33 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
     for u, w in zip(a[1:], b[1:]):
         np.testing.assert_array_equal(u, w)
     assert border == 0.0 or (3, 5) not in [tuple(e[1]) for e in a[0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,P,border', [(96, 96, 1, 0.0), (97, 64, 1, 0.0), (200, 144, 4, 0.1),
+                                          (255, 255, 1, 0.02), (64, 1000, 2, 0.05)])
+def test_noise_est_device_selection(H, W, P, border):
+    """kimg_noise_est (radix-select bytes chosen on the device, no host round trips) is the exact
+    median * 1.4826 in float32: equal to numpy's median of |x| inside the border, and to the
+    host-driven selection, for odd and even sample counts, ties, zeros, huge and tiny values."""
+    from katsdpimager_amd import clean
+    ctx, q = context_queue()
+    rs = np.random.RandomState(H * 7 + W + P)
+    for case in range(4):
+        img = rs.standard_normal((P, H, W)).astype(np.float32)
+        if case == 1:
+            img = np.round(img * 3) / 3               # many exact ties around the median
+        elif case == 2:
+            img[rs.random_sample(img.shape) < 0.6] = 0.0       # the median itself is zero
+        elif case == 3:
+            img *= np.float32(10.0) ** rs.randint(-30, 30, img.shape).astype(np.float32)
+        op = clean.NoiseEstTemplate(ctx, np.float32, P).instantiate(q, (P, H, W), border)
+        op.ensure_all_bound()
+        op.buffer('dirty').set(q, img)
+        got = op()
+        bp = op.border_pixels
+        inner = np.abs(img[:, bp:H - bp, bp:W - bp])
+        want = np.median(inner) * np.float32(clean._MEDIAN_TO_RMS)
+        assert got.dtype == np.float32
+        assert got == np.float32(want), (case, got, want)
+        assert got == op.host_select()
