@@ -609,7 +609,7 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     out['store_driver_total_s'] = round(dt, 4)
     out['store_driver_minor_cycles'] = int(stats['minor']) if stats else None
 
-    # Four channels (here: the same stored channel imaged four times) with 1, 2 and 4 of them in
+    # Four channels (here: the same stored channel imaged four times) with 1, 2, 3 and 4 of them in
     # flight on their own streams; CLEAN thresholds forced low so that every major
     # cycle runs its full 1000 minor cycles, as in the staged loop above.
     cp2 = parameters.CleanParameters(args.clean_cycles, 0.1, 1.0, 0.0, 0, 0.01, 0.5, 0.02)
@@ -617,13 +617,15 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     jobs = []
     for _ in range(4):
         qi = ctx.create_command_queue()
-        imi = template2.instantiate(qi, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
+        # one stream per channel: the device maps streams onto four hardware queues, and a
+        # channel whose chain of CLEAN launches shares a queue with another one waits for it
+        imi = template2.instantiate(qi, ipd, gpd, args.vis_block, 0, 2, streams=1)
         imi.ensure_all_bound()
         jobs.append(dict(reader=reader, rel_channel=0, imager=imi, image_p=ipd, grid_p=gpd,
                          clean_p=cp2, weight_type=wparm.weight_type, vis_block=args.vis_block,
                          major=2, degrid=True))
     frontend.process_channels(jobs, workers=4)          # warm-up (graph capture per imager)
-    for workers in (1, 2, 4):
+    for workers in (1, 2, 3, 4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = frontend.process_channels(jobs, workers=workers)
