@@ -364,10 +364,95 @@ struct fused_state {
     int pad[12];
 };
 
+// The best two tiles among those a thread owns, ordered by (larger value, lower tile index);
+// value -1 = none.  Two, because when one owned tile gets a new value the owner's new BEST is
+// then known without looking at the other tiles: it is the better of the new record and of the
+// best of the others, which is the first of the two that is not the rewritten tile.
+struct owner_best_t {
+    float v1;
+    int t1;
+    float v2;
+    int t2;
+};
+
 struct fused_scratch {
     fused_state st[2];
     delta_t deltas[2][1024];
+    owner_best_t owner_best[1024];
     // float tile_pix[tiles][4] follows
+};
+
+// The tiles owned by thread (b, a) = (tid >> 5, tid & 31) of a 1024-thread block: (ty, tx) with
+// ty % 32 == b and tx % 32 == a, visited as "slots" = 32x32-tile groups in row-major order (i.e.
+// in increasing tile index).  Uniform bookkeeping, no divisions.
+struct owned_tiles {
+    int own, last, own_x, own_y, sup_x, tiles_x, sx, off, lim_x, lim_y, slots;
+
+    __device__ owned_tiles(int tid, int tiles_x_, int tiles_y)
+    {
+        tiles_x = tiles_x_;
+        sup_x = (tiles_x + 31) >> 5;
+        slots = sup_x * ((tiles_y + 31) >> 5);
+        last = tiles_x * tiles_y - 1;
+        own_x = tid & 31;
+        own_y = tid >> 5;
+        own = own_y * tiles_x + own_x;
+        sx = 0;
+        off = 0;
+        lim_x = tiles_x;
+        lim_y = tiles_y;
+    }
+
+    // Tile index of the next slot (clamped into the array) and whether the slot is on the lattice
+    __device__ int next(bool &valid)
+    {
+        const int i = min(own + off, last);
+        valid = own_x < lim_x && own_y < lim_y;
+        sx++;
+        off += 32;
+        lim_x -= 32;
+        if (sx == sup_x) {
+            sx = 0;
+            off += 32 * tiles_x - 32 * sup_x;
+            lim_x = tiles_x;
+            lim_y -= 32;
+        }
+        return i;
+    }
+
+    // The best two owned tiles, with tile `ptile` (if >= 0) taking the value `pvalue` instead of
+    // the stored one.
+    __device__ owner_best_t best(const float *tile_max, int ptile, float pvalue)
+    {
+        owner_best_t b = {-1.0f, 0, -1.0f, 0};
+        for (int r = 0; r * FUSED_ROUND < slots; r++) {
+            int ti[FUSED_ROUND];
+            float v[FUSED_ROUND];
+            bool ok[FUSED_ROUND];
+#pragma unroll
+            for (int k = 0; k < FUSED_ROUND; k++) {
+                ti[k] = next(ok[k]);
+                v[k] = tile_max[ti[k]];
+            }
+            // slots come in increasing tile order, so a strict comparison keeps the lowest index
+#pragma unroll
+            for (int k = 0; k < FUSED_ROUND; k++) {
+                const float val = ti[k] == ptile ? pvalue : v[k];
+                if (r * FUSED_ROUND + k < slots && ok[k]) {
+                    if (val > b.v1) {
+                        b.v2 = b.v1;
+                        b.t2 = b.t1;
+                        b.v1 = val;
+                        b.t1 = ti[k];
+                    } else if (val > b.v2) {
+                        b.v2 = val;
+                        b.t2 = ti[k];
+                    }
+                }
+            }
+        }
+        return b;
+    }
 };
 
 __device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *tile_pos,
@@ -457,77 +542,54 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     delta_t *dout = scratch->deltas[parity ^ 1];
     float *tile_pix = reinterpret_cast<float *>(scratch + 1);
     const int tid = threadIdx.x;
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    // The last row of the grid holds the one workgroup that does the bookkeeping instead of a
+    // lattice block (its other members have nothing to do).
+    const bool keeper = blockIdx.y == gridDim.y - 1;
+    if (keeper && blockIdx.x != 0)
+        return;
 #ifdef KIMG_CLEAN_STAMPS
+    const int bid = (!keeper && blockIdx.x == 0 && blockIdx.y == 0) ? 0 : 1;   // stamps: one lattice block
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
 
-    // ---- round trip 1: state, this thread's delta, first round of tile maxima --------------
-    // Thread (b, a) = (tid >> 5, tid & 31) owns the tiles (ty, tx) with ty % 32 == b and
-    // tx % 32 == a, in slots = 32x32-tile groups in row-major order.  A PSF patch spans fewer than
-    // 32 tiles either way, so a cycle rewrites at most one tile per owner: the delta table has one
-    // slot per thread and needs no search.
+    // ---- round trip 1: state, this thread's delta, this thread's best tiles ------------------
+    // Thread (b, a) owns the tiles with (ty % 32, tx % 32) = (b, a) (`owned_tiles`).  A PSF patch
+    // spans fewer than 32 tiles either way, so a cycle rewrites at most one tile per owner: the
+    // delta table has one slot per thread and needs no search, and `owner_best` (each owner's best
+    // two tiles) turns into the owner's candidate without touching the tile maxima.
     const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, -
     const int count = st.x, done = st.y, limit = st.z;
     const delta_t d = din[tid];
-    const int sup_x = (tiles_x + 31) >> 5, sup_y = (tiles_y + 31) >> 5;
-    const int slots = sup_x * sup_y;
-    const int last = tiles_x * tiles_y - 1;
-    const int own = (tid >> 5) * tiles_x + (tid & 31);
-    const int own_x = tid & 31, own_y = tid >> 5;
-    // (uniform) per slot: tile-index offset and how many owner columns / rows are on the lattice
-    int sx = 0, off = 0, lim_x = tiles_x, lim_y = tiles_y;
-    auto next_slot = [&](bool &valid) __attribute__((always_inline)) {
-        const int i = min(own + off, last);
-        valid = own_x < lim_x && own_y < lim_y;
-        sx++;
-        off += 32;
-        lim_x -= 32;
-        if (sx == sup_x) {
-            sx = 0;
-            off += 32 * tiles_x - 32 * sup_x;
-            lim_x = tiles_x;
-            lim_y -= 32;
-        }
-        return i;
-    };
-    int ti[FUSED_ROUND];
-    float v[FUSED_ROUND];
-    bool ok[FUSED_ROUND];
-#pragma unroll
-    for (int k = 0; k < FUSED_ROUND; k++) {
-        ti[k] = next_slot(ok[k]);
-        v[k] = tile_max[ti[k]];
-    }
+    const owner_best_t ob = scratch->owner_best[tid];
     if (done) {
-        if (bid == 0 && tid == 0)
+        if (keeper && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
         return;
     }
     const bool live = d.tag == count + 1;
     const int ptile = live ? d.tile : -1;
-    if (live && bid == 0)
-        apply_delta(d, tile_max, tile_pos, tile_pix);
     STAMP(1);
-    float bv = -1.0f;
-    int bi = 0;
-    for (int r = 0; r * FUSED_ROUND < slots; r++) {
-        if (r > 0) {
-#pragma unroll
-            for (int k = 0; k < FUSED_ROUND; k++) {
-                ti[k] = next_slot(ok[k]);
-                v[k] = tile_max[ti[k]];
-            }
-        }
-        // slots come in non-decreasing tile order: the first strict maximum has the lowest index
-#pragma unroll
-        for (int k = 0; k < FUSED_ROUND; k++) {
-            const float val = ti[k] == ptile ? d.value : v[k];  // rewritten by the previous cycle
-            if (r * FUSED_ROUND + k < slots && ok[k] && val > bv) {
-                bv = val;
-                bi = ti[k];
-            }
+    float bv = ob.v1;
+    int bi = ob.t1;
+    if (live) {
+        // best of the owner's other tiles, then the rewritten one against it
+        const bool first = ob.t1 == d.tile && ob.v1 >= 0.0f;
+        const float ov = first ? ob.v2 : ob.v1;
+        const int ot = first ? ob.t2 : ob.t1;
+        const bool take = ov < 0.0f || d.value > ov || (d.value == ov && d.tile < ot);
+        bv = take ? d.value : ov;
+        bi = take ? d.tile : ot;
+    }
+    if (keeper && __any(live)) {
+        // off the critical path of the lattice workgroups: fold the previous cycle's records into
+        // the base arrays (readers of this launch override those entries with the deltas, so it
+        // does not matter which version they see) and bring the owners' best-two up to date
+        owned_tiles walk(tid, tiles_x, tiles_y);
+        const owner_best_t nb = walk.best(tile_max, ptile, d.value);
+        if (live) {
+            apply_delta(d, tile_max, tile_pos, tile_pix);
+            scratch->owner_best[tid] = nb;
         }
     }
     // The record of this thread's candidate is fetched now, before it is known whether the
@@ -544,7 +606,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     STAMP(2);
     const float value = __uint_as_float((unsigned) (best >> 32));
     if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
-        if (bid == 0 && tid == 0)
+        if (keeper && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
         return;
     }
@@ -573,6 +635,22 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     for (int p = 0; p < 4; p++)
         scale[p] = loop_gain * s_pix[p];                            // clean.py:1044
     STAMP(3);
+    if (keeper) {
+        if (tid < P) {
+            float *entry = log + (int64_t) count * (3 + P);
+            float *mp = model + tid * pol_stride + (int64_t) py * row_stride + px;
+            const float mod = *mp;
+            if (tid == 0) {
+                entry[0] = value;
+                entry[1] = __int_as_float(py);
+                entry[2] = __int_as_float(px);
+                *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, 0);
+            }
+            entry[3 + tid] = scale[tid];
+            *mp = mod + scale[tid];                                 // clean.py:1047
+        }
+        return;
+    }
 
     // ---- round trip 3: this block's pixels -----------------------------------------------
     const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
@@ -588,19 +666,15 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     const bool in_patch = inside && x >= x0 && x < x0 + patch_w && y >= y0 && y < y0 + patch_h;
     const bool in_tile = inside && is_tile && x < width - border && y < height - border;
     float dv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float mod = 0.0f;
-    const bool logger = bid == 0 && tid < P;
     if (inside)
         for (int p = 0; p < P; p++)
             dv[p] = dirty[p * pol_stride + ia];
     if (in_patch)
         for (int p = 0; p < P; p++)
             pv[p] = psf[p * psf_pol_stride + (int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
-    if (logger)
-        mod = model[tid * pol_stride + (int64_t) py * row_stride + px];
     float metric = 0.0f;
 #ifdef KIMG_CLEAN_STAMPS
-    if (dv[0] + pv[0] + mod == 12345.678f)
+    if (dv[0] + pv[0] == 12345.678f)
         stamps[7] = 1;
     STAMP(4);
 #endif
@@ -616,17 +690,6 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
         } else {
             metric += dv[p] * dv[p];
         }
-    }
-    if (logger) {
-        float *entry = log + (int64_t) count * (3 + P);
-        if (tid == 0) {
-            entry[0] = value;
-            entry[1] = __int_as_float(py);
-            entry[2] = __int_as_float(px);
-            *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, 0);
-        }
-        entry[3 + tid] = scale[tid];
-        model[tid * pol_stride + (int64_t) py * row_stride + px] = mod + scale[tid];   // clean.py:1047
     }
     if (!is_tile)
         return;
@@ -679,6 +742,15 @@ __global__ __launch_bounds__(256) void tile_pix_kernel(
     const bool ok = y >= 0 && y < height && x >= 0 && x < width;
     for (int p = 0; p < 4; p++)
         tile_pix[4 * t + p] = (ok && p < P) ? dirty[p * pol_stride + (int64_t) y * row_stride + x] : 0.0f;
+}
+
+// Every owner's best tile (see cycle_fused_kernel); once per kimg_clean_cycles call.
+__global__ __launch_bounds__(1024) void owner_best_kernel(const float *__restrict__ tile_max,
+                                                          int tiles_x, int tiles_y,
+                                                          fused_scratch *scratch)
+{
+    owned_tiles walk(threadIdx.x, tiles_x, tiles_y);
+    scratch->owner_best[threadIdx.x] = walk.best(tile_max, -1, 0.0f);
 }
 
 // Fold the deltas of the last cycle into the base tile arrays (the state left by an even number
@@ -942,6 +1014,7 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
     const int num_tiles = a.tiles_x * a.tiles_y;
     if (a.fused) {
         fused_scratch *fs = reinterpret_cast<fused_scratch *>(a.state);
+        g.y += 1;               // the bookkeeping workgroup's row
         if (a.mode == KIMG_CLEAN_I)
             cycle_fused_kernel<KIMG_CLEAN_I><<<g, 1024, 0, s>>>(
                 a.dirty, a.model, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf,
@@ -1051,6 +1124,9 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
         tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
             dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
             tiles_x * tiles_y, static_cast<fused_scratch *>(state));
+    if (fused)
+        owner_best_kernel<<<1, 1024, 0, s>>>(tile_max, tiles_x, tiles_y,
+                                             static_cast<fused_scratch *>(state));
     cycle_args a;
     memset(&a, 0, sizeof(a));       // padding bytes take part in the cache key comparison
     a.dirty = dirty; a.model = model; a.row_stride = row_stride; a.pol_stride = pol_stride;
