@@ -328,23 +328,24 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
 
 // ---- one launch per minor cycle ----------------------------------------------------------
 // The two-launch cycle above is a chain of dependent memory round trips with a kernel boundary
-// in the middle.  When the PSF patch touches few lattice blocks, every workgroup of the
-// subtract/update launch can afford to find the global peak ITSELF (the tile maxima are 64 KB at
-// 4096^2), so the cycle becomes one launch with no communication between its workgroups:
-//     (measured at 4096^2: 7.7 us per cycle up to 64 blocks, 8.5 at 256 = one block per CU, 11.5 at
-//     441 -- two rounds of workgroups -- against 11-12.2 for two launches; 15.4 vs 12.8 at 552)
-//   * all workgroups read the same inputs -- the base tile arrays plus a short list of "deltas"
-//     (the tile records rewritten by the previous cycle) -- and therefore pick the same peak;
+// in the middle.  Here every workgroup of the subtract/update launch finds the global peak
+// ITSELF, so the cycle is one launch with no communication between its workgroups:
+//   * all workgroups read the same inputs -- per owner thread its best two tiles (`owner_best`)
+//     and the tile record the previous cycle rewrote, if any (a "delta") -- and therefore pick
+//     the same peak;
 //   * each then subtracts the PSF from its own lattice block, rescans it, and writes the new tile
-//     record to the OTHER delta list (double-buffered by cycle parity), never to the base arrays,
+//     record to the OTHER delta table (double-buffered by cycle parity), never to the base arrays,
 //     so that slower workgroups of the same launch still see the inputs unchanged;
-//   * workgroup 0 also folds the previous cycle's deltas into the base arrays (readers override
-//     those entries with the delta values anyway, so it does not matter which version they see),
-//     writes the log entry, the model pixel and the next state.
+//   * one more workgroup (the "keeper") folds the previous cycle's deltas into the base arrays
+//     (readers override those entries with the delta values anyway, so it does not matter which
+//     version they see), refreshes the best-two of the owners concerned, and writes the log
+//     entry, the model pixel and the next state.
 // Tile records carry the pixel values at the tile's peak (tile_pix), which saves the dependent
 // load of the peak pixel.  Selection and arithmetic are those of the two-launch form, bit for bit.
-constexpr int FUSED_MAX_BLOCKS = 448;     // measured break-even with the two-launch form (see below)
-constexpr int FUSED_ROUND = 16;                 // tile maxima per thread and round
+// Measured at 4096^2: 6.5 us per cycle up to ~150 lattice blocks, 10.2 at 256 (more workgroups
+// than CUs), 11.6 at 441, against 11.1-12.2 for two launches; 14.7 vs 12.5 at 529.
+constexpr int FUSED_MAX_BLOCKS = 448;     // measured break-even with the two-launch form
+constexpr int FUSED_ROUND = 16;           // tile maxima per thread and round of a rescan
 constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
 
 // A tile record rewritten by one cycle and consumed by the next, stored at the slot of the thread
