@@ -33,6 +33,7 @@ def main(argv=None):
     ap.add_argument('--kernel-width', type=int, default=28)
     args = ap.parse_args(argv)
     import torch
+    import scipy.optimize       # noqa: F401  (used by beam.fit_beam; imported here, outside the timings)
     import synth
     from katsdpimager_amd import accel, beam, frontend, imaging, parameters, preprocess, weight
 
