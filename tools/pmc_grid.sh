@@ -7,7 +7,7 @@ mkdir -p $OUT
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --no-secondary > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --no-secondary $BENCH_ARGS > $OUT/p$i.log 2>&1
   f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections
