@@ -583,6 +583,17 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     d_vis = accel.DeviceArray(ctx, (1, n, P), np.complex64, tensor=raw_vis[None].contiguous())
     ident = np.identity(P, np.complex64)
     torch.cuda.synchronize()
+    # the collector's buffer size is the user's choice (the reference passes --vis-block); each
+    # buffer is a chain of ~13 small dependent launches, so larger buffers amortise it
+    for rep in range(2):
+        big = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], 16 * args.vis_block)
+        q.finish()
+        t0 = time.perf_counter()
+        big.add(d_uvw, d_wts, d_vis, None, None, ident, None)
+        q.finish()
+        dt_big = time.perf_counter() - t0
+        del big
+    out['preprocess_16x_buffer_Mvis_per_s'] = round(n / dt_big / 1e6, 1)
     for rep in range(2):            # the first pass warms up the kernels and the allocator
         coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], args.vis_block)
         q.finish()
