@@ -206,3 +206,46 @@ def test_grid_degrid_adjoint(pixels, w_planes, P, n_vis, vis_block):
     scale = float(torch.sum(pred.abs().to(torch.float64) * v.abs().to(torch.float64)))
     err = float((lhs - rhs).abs().max()) / scale * P
     assert float(pred.abs().max()) > 0 and err < 1e-6
+
+
+@pytest.mark.parametrize('G,P', [(4096, 1), (2048, 4)])
+def test_full_size_noise_estimate_and_clean_rate_invariants(G, P):
+    """At BASELINE image sizes: the device noise estimate is numpy's median exactly, and a run of
+    minor cycles conserves flux: sum(model) == sum of the logged loop_gain * pixel values == what the
+    residual image lost (divided by the PSF volume)."""
+    from katsdpimager_amd import clean, parameters
+    ctx, q = context_queue()
+    rs = np.random.RandomState(G + P)
+    img = (0.05 * rs.standard_normal((P, G, G))).astype(np.float32)
+    for _ in range(50):
+        y, x = rs.randint(200, G - 200, 2)
+        img[:, y, x] += rs.uniform(1.0, 3.0)
+    fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
+    ne = clean.NoiseEstTemplate(ctx, np.float32, P).instantiate(q, (P, G, G), 0.02)
+    ne.ensure_all_bound()
+    ne.buffer('dirty').set(q, img)
+    bp = ne.border_pixels
+    want = np.median(np.abs(img[:, bp:G - bp, bp:G - bp])) * np.float32(clean._MEDIAN_TO_RMS)
+    assert ne() == np.float32(want)
+
+    cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, 1 if P > 1 else 0, 0.01, 0.5, 0.02)
+    fn = clean.CleanTemplate(ctx, cp, np.float32, P).instantiate(q, ip)
+    fn.ensure_all_bound()
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 3.0) ** 2).astype(np.float32)
+    psf = np.repeat(np.outer(g1, g1)[None], P, axis=0)
+    fn.buffer('dirty').set(q, img)
+    fn.buffer('psf').set(q, psf)
+    fn.buffer('model').zero(q)
+    fn.reset()
+    log = fn.run_cycles((P, 65, 65), 0.0, 1000)
+    assert len(log) == 1000
+    model = fn.buffer('model').get(q)
+    total = np.sum([e[2] for e in log], axis=0, dtype=np.float64)
+    np.testing.assert_allclose(model.sum(axis=(1, 2), dtype=np.float64), total, rtol=1e-5)
+    # the residual really lost what the model gained (PSF of unit peak, everything inside the patch)
+    resid = fn.buffer('dirty').get(q)
+    np.testing.assert_allclose((img.sum(axis=(1, 2), dtype=np.float64)
+                                - resid.sum(axis=(1, 2), dtype=np.float64)),
+                               total * psf[0, G // 2 - 32:G // 2 + 33, G // 2 - 32:G // 2 + 33].sum(dtype=np.float64),
+                               rtol=1e-3)
