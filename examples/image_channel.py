@@ -31,6 +31,7 @@ def main(argv=None):
     ap.add_argument('--w-planes', type=int, default=32,
                     help='W planes per slice (more than 64: the kernel table is read from HBM)')
     ap.add_argument('--kernel-width', type=int, default=28)
+    ap.add_argument('--output', help='write the restored image to this FITS file')
     args = ap.parse_args(argv)
     import torch
     import scipy.optimize       # noqa: F401  (used by beam.fit_beam; imported here, outside the timings)
@@ -90,6 +91,12 @@ def main(argv=None):
         box = restored[y - 3:y + 4, x - 3:x + 4]
         print('source at (l, m) = ({:5d}, {:5d}) px, {:.2f} Jy: restored peak {:.3f}'.format(
             lp, mp, flux, float(box.max())))
+    if args.output:
+        from katsdpimager_amd import io, polarization
+        image_p.fixed.polarizations = [polarization.STOKES_I]
+        io.write_fits_image(imager.get_buffer('dirty'), image_p, args.output, 0,
+                            (0.0, math.radians(-45.0)), beam=stats['restoring_beam'])
+        print('wrote', args.output)
     return restored, stats
 
 

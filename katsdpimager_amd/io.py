@@ -1,0 +1,133 @@
+"""Writing images as FITS files, without astropy.
+
+``write_fits_image`` produces the file that ``katsdpimager.io.write_fits_image`` (io.py:88-204)
+produces — same header keywords and values, same axis order (RA reversed, a degenerate frequency
+axis added), big-endian float32 data — from plain numbers instead of a loader object: the phase
+centre is passed as (RA, Dec) in radians.  The FITS container itself (80-character cards, 2880-byte
+blocks) is written directly; it is a fixed, simple format (FITS standard 4.0, sections 3-4).
+"""
+import datetime
+import math
+
+import numpy as np
+
+from . import polarization
+
+_BLOCK = 2880
+
+#: FITS codes of the polarization products (io.py:18-35; X and Y swapped relative to IEEE)
+_FITS_POLARIZATIONS = {
+    polarization.STOKES_I: 1, polarization.STOKES_Q: 2, polarization.STOKES_U: 3,
+    polarization.STOKES_V: 4, polarization.STOKES_RR: -1, polarization.STOKES_LL: -2,
+    polarization.STOKES_RL: -3, polarization.STOKES_LR: -4, polarization.STOKES_YY: -5,
+    polarization.STOKES_XX: -6, polarization.STOKES_YX: -7, polarization.STOKES_XY: -8,
+}
+
+
+def fits_polarization_axis(polarizations):
+    """(reference value, increment, permutation) describing a list of polarizations as a linear
+    FITS STOKES axis (io.py:38-85).  ValueError if they do not form a linear sequence."""
+    codes = np.array([_FITS_POLARIZATIONS[p] for p in polarizations])
+    order = np.argsort(codes if codes[0] >= 0 else -codes)      # non-IQUV codes count downwards
+    codes = codes[order]
+    delta = int(codes[1] - codes[0]) if len(codes) > 1 else 1
+    if np.any(codes != codes[0] + delta * np.arange(len(codes))):
+        raise ValueError('Polarizations do not form a linear sequence in FITS enumeration')
+    return int(codes[0]), delta, order
+
+
+def _card(key, value, comment=None):
+    if key in ('HISTORY', 'COMMENT'):
+        text = '{:8s}{}'.format(key, value)
+    else:
+        if isinstance(value, (bool, np.bool_)):
+            field = '{:>20s}'.format('T' if value else 'F')
+        elif isinstance(value, (int, np.integer)):
+            field = '{:>20d}'.format(int(value))
+        elif isinstance(value, (float, np.floating)):
+            field = repr(float(value)).upper()
+            if '.' not in field and 'E' not in field and 'N' not in field:
+                field += '.0'
+            field = '{:>20s}'.format(field)
+        else:
+            field = "'{:8s}'".format(str(value).replace("'", "''"))
+        text = '{:8s}= {}'.format(key, field)
+        if comment:
+            text += ' / ' + comment
+    if len(text) > 80:
+        raise ValueError('FITS card too long: ' + text)
+    return text.ljust(80)
+
+
+def write_fits(filename, data, cards):
+    """Primary HDU with ``data`` (any numeric dtype FITS knows; written big-endian) and the header
+    ``cards`` (sequence of (key, value)), preceded by the mandatory keywords."""
+    data = np.asarray(data)
+    bitpix = {'u1': 8, 'i2': 16, 'i4': 32, 'i8': 64, 'f4': -32, 'f8': -64}[data.dtype.str[1:]]
+    head = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', bitpix),
+            _card('NAXIS', data.ndim)]
+    for i, n in enumerate(reversed(data.shape)):
+        head.append(_card('NAXIS%d' % (i + 1), n))
+    head += [_card(k, v) for k, v in cards]
+    head.append('END'.ljust(80))
+    text = ''.join(head).encode('ascii')
+    text += b' ' * (-len(text) % _BLOCK)
+    payload = np.ascontiguousarray(data, data.dtype.newbyteorder('>')).tobytes()
+    with open(filename, 'wb') as f:
+        f.write(text)
+        f.write(payload)
+        f.write(b'\0' * (-len(payload) % _BLOCK))
+
+
+def write_fits_image(image, image_parameters, filename, channel, phase_centre, beam=None,
+                     bunit='Jy/beam', extra_fits_headers=None, date=None):
+    """io.py:88-204.  ``image`` [polarization][m][l] (phase centre at [M, N] of a 2M x 2N image);
+    ``filename`` may contain a printf-style place for ``channel``; ``phase_centre`` = (RA, Dec) in
+    radians (the reference takes them from its dataset); ``beam`` a :class:`~.beam.Beam` in pixels.
+    Returns (the array as written, the header as a list of (key, value))."""
+    image = np.asarray(image)
+    if image.ndim != 3:
+        raise ValueError('image must be [polarization][m][l]')
+    ref, step, order = fits_polarization_axis(image_parameters.fixed.polarizations)
+    if np.any(order != np.arange(len(order))):
+        raise ValueError('polarizations must be in FITS order')
+    if date is None:
+        date = datetime.datetime.utcnow().isoformat(timespec='milliseconds')
+    delt = math.degrees(math.asin(float(image_parameters.pixel_size)))
+    cards = []
+    if bunit is not None:
+        cards.append(('BUNIT', bunit))
+    cards += [
+        ('ORIGIN', 'katsdpimager_amd'), ('HISTORY', 'Created by katsdpimager_amd'),
+        ('TIMESYS', 'UTC'), ('DATE', date),
+        # pixel -> (l, m): the reference point is the image centre; FITS counts from 1 and the
+        # l axis is stored reversed so that RA increases to the left
+        ('CRPIX1', image.shape[2] * 0.5), ('CRPIX2', image.shape[1] * 0.5 + 1.0), ('CRPIX4', 1.0),
+        ('CDELT1', -delt), ('CDELT2', delt), ('CDELT4', 1.0),
+        ('EQUINOX', 2000.0), ('RADESYS', 'FK5'),
+        ('CUNIT1', 'deg'), ('CUNIT2', 'deg'), ('CUNIT4', 'Hz'),
+        ('CTYPE1', 'RA---SIN'), ('CTYPE2', 'DEC--SIN'), ('CTYPE4', 'FREQ'),
+        ('CRVAL1', math.degrees(float(phase_centre[0]))),
+        ('CRVAL2', math.degrees(float(phase_centre[1]))),
+        ('CRVAL4', 299792458.0 / float(image_parameters.wavelength)),
+    ]
+    if beam is not None:
+        pix = math.degrees(float(image_parameters.pixel_size))
+        cards += [('BMAJ', beam.major * pix), ('BMIN', beam.minor * pix),
+                  ('BPA', math.degrees(float(beam.theta)))]
+    cards += [('CTYPE3', 'STOKES'), ('CRPIX3', 1.0), ('CRVAL3', float(ref)),
+              ('CDELT3', float(step))]
+    datamin = float(np.fmin.reduce(image, axis=None))
+    datamax = float(np.fmax.reduce(image, axis=None))
+    if not math.isnan(datamin):
+        cards += [('DATAMIN', datamin), ('DATAMAX', datamax)]
+    if extra_fits_headers:
+        extra = dict(extra_fits_headers)
+        cards = [(k, extra.pop(k) if k in extra else v) for k, v in cards] + list(extra.items())
+    out = image[np.newaxis, :, :, ::-1]
+    try:
+        filename = filename % channel
+    except TypeError:
+        pass
+    write_fits(filename, out, cards)
+    return out, cards

@@ -419,3 +419,90 @@ def test_extract_sky_model_matches_component_path():
     np.testing.assert_allclose(got_lmn, want_lmn, rtol=0, atol=1e-7)
     np.testing.assert_allclose(got_flux, want_flux, rtol=1e-6)
     assert np.all(lmn[:, 2] > 0.9)        # the model's array was not modified
+
+
+def _read_fits(path):
+    """Minimal reader for what io.write_fits writes: (header dict, history list, data)."""
+    raw = open(path, 'rb').read()
+    assert len(raw) % 2880 == 0
+    header, history, pos = {}, [], 0
+    while True:
+        card = raw[pos:pos + 80].decode('ascii')
+        pos += 80
+        assert len(card) == 80
+        if card.startswith('END'):
+            break
+        if card.startswith('HISTORY'):
+            history.append(card[8:].rstrip())
+            continue
+        assert card[8:10] == '= '
+        value = card[10:].split(' / ')[0].strip()
+        if value.startswith("'"):
+            header[card[:8].strip()] = value[1:-1].rstrip()
+        elif value in ('T', 'F'):
+            header[card[:8].strip()] = value == 'T'
+        else:
+            header[card[:8].strip()] = float(value) if ('.' in value or 'E' in value) else int(value)
+    pos += -pos % 2880
+    shape = tuple(header['NAXIS%d' % i] for i in range(header['NAXIS'], 0, -1))
+    dtype = {-32: '>f4', -64: '>f8', 16: '>i2', 32: '>i4'}[header['BITPIX']]
+    n = int(np.prod(shape))
+    data = np.frombuffer(raw, dtype, n, pos).reshape(shape)
+    assert not any(raw[pos + n * np.dtype(dtype).itemsize:])
+    return header, history, data
+
+
+def test_write_fits_image(tmp_path):
+    """io.write_fits_image: header keywords and values of the reference's writer (io.py:126-181),
+    RA axis reversed, degenerate frequency axis, big-endian data, 2880-byte blocks."""
+    import math
+    from katsdpimager_amd import beam, io, parameters, polarization
+    pols = [polarization.STOKES_I, polarization.STOKES_Q, polarization.STOKES_U, polarization.STOKES_V]
+    fixed = parameters.FixedImageParameters(pols, np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.21, None, pixel_size=2e-5, pixels=48)
+    rs = np.random.RandomState(3)
+    image = rs.standard_normal((4, 48, 48)).astype(np.float32)
+    image[2, 5, 7] = np.nan
+    b = beam.Beam(1.0, 3.0, 1.5, 0.4)
+    path = str(tmp_path / 'image-%05d.fits')
+    out, cards = io.write_fits_image(image, ip, path, 12, (1.25, -0.6), beam=b,
+                                     extra_fits_headers={'OBJECT': 'test field', 'BUNIT': 'JY/BEAM'},
+                                     date='2024-10-08T00:00:00.000')
+    header, history, data = _read_fits(str(tmp_path / 'image-00012.fits'))
+    assert data.shape == (1, 4, 48, 48) and data.dtype == np.dtype('>f4')
+    np.testing.assert_array_equal(data[0], image[:, :, ::-1])
+    np.testing.assert_array_equal(out, image[np.newaxis, :, :, ::-1])
+    delt = math.degrees(math.asin(2e-5))
+    expect = {
+        'SIMPLE': True, 'BITPIX': -32, 'NAXIS': 4, 'NAXIS1': 48, 'NAXIS2': 48, 'NAXIS3': 4,
+        'NAXIS4': 1, 'BUNIT': 'JY/BEAM', 'ORIGIN': 'katsdpimager_amd', 'TIMESYS': 'UTC',
+        'DATE': '2024-10-08T00:00:00.000', 'CRPIX1': 24.0, 'CRPIX2': 25.0, 'CRPIX4': 1.0,
+        'CDELT1': -delt, 'CDELT2': delt, 'CDELT4': 1.0, 'EQUINOX': 2000.0, 'RADESYS': 'FK5',
+        'CUNIT1': 'deg', 'CUNIT2': 'deg', 'CUNIT4': 'Hz', 'CTYPE1': 'RA---SIN',
+        'CTYPE2': 'DEC--SIN', 'CTYPE4': 'FREQ', 'CRVAL1': math.degrees(1.25),
+        'CRVAL2': math.degrees(-0.6), 'CRVAL4': 299792458.0 / 0.21,
+        'BMAJ': b.major * math.degrees(2e-5), 'BMIN': b.minor * math.degrees(2e-5),
+        'BPA': math.degrees(b.theta), 'CTYPE3': 'STOKES', 'CRPIX3': 1.0, 'CRVAL3': 1.0,
+        'CDELT3': 1.0, 'DATAMIN': float(np.nanmin(image)), 'DATAMAX': float(np.nanmax(image)),
+        'OBJECT': 'test field',
+    }
+    assert header == expect
+    assert history == ['Created by katsdpimager_amd']
+    # polarization axis: circular products count downwards; unsorted or non-linear lists are refused
+    assert io.fits_polarization_axis([polarization.STOKES_RR, polarization.STOKES_LL])[:2] == (-1, -1)
+    assert io.fits_polarization_axis([polarization.STOKES_I, polarization.STOKES_V])[:2] == (1, 3)
+    with pytest.raises(ValueError):
+        io.fits_polarization_axis([polarization.STOKES_I, polarization.STOKES_Q, polarization.STOKES_V])
+    fixed2 = parameters.FixedImageParameters([polarization.STOKES_Q, polarization.STOKES_I], np.float32)
+    ip2 = parameters.ImageParameters(fixed2, 1.0, None, 0.21, None, pixel_size=2e-5, pixels=48)
+    with pytest.raises(ValueError):
+        io.write_fits_image(image[:2], ip2, str(tmp_path / 'x.fits'), 0, (0.0, 0.0))
+    # an all-NaN image has no DATAMIN / DATAMAX (io.py:176-179); no place for the channel is fine
+    _, cards = io.write_fits_image(np.full((1, 48, 48), np.nan, np.float32),
+                                   parameters.ImageParameters(
+                                       parameters.FixedImageParameters([polarization.STOKES_I], np.float32),
+                                       1.0, None, 0.21, None, pixel_size=2e-5, pixels=48),
+                                   str(tmp_path / 'nan.fits'), 3, (0.0, 0.0), bunit=None)
+    keys = [k for k, _ in cards]
+    assert 'DATAMIN' not in keys and 'BUNIT' not in keys and 'BMAJ' not in keys
+    assert _read_fits(str(tmp_path / 'nan.fits'))[2].shape == (1, 1, 48, 48)
