@@ -58,6 +58,57 @@ __device__ inline best_t block_best(best_t b)
     return b;
 }
 
+// (value, index) as one unsigned key: larger value first, then smaller index.  Values are
+// non-negative floats (never NaN: a NaN metric never replaces a tile's best), whose bit patterns
+// order like the numbers.  Key 0 = nothing.
+typedef unsigned long long key_t;
+
+__device__ inline key_t make_key(float value, int idx)
+{
+    return ((key_t) __float_as_uint(value) << 32) | (unsigned) ~idx;
+}
+
+__device__ inline key_t key_max(key_t a, key_t b) { return a > b ? a : b; }
+
+template <int CTRL>
+__device__ inline key_t key_dpp(key_t k)
+{
+    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned) k, CTRL, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned) (k >> 32), CTRL, 0xf, 0xf, true);
+    return ((key_t) hi << 32) | lo;
+}
+
+// Maximum over each 16-lane row, in every lane of the row (DPP butterflies: ALU latency only)
+__device__ inline key_t row_max_key(key_t k)
+{
+    k = key_max(k, key_dpp<0xB1>(k));       // quad_perm [1,0,3,2]
+    k = key_max(k, key_dpp<0x4E>(k));       // quad_perm [2,3,0,1]
+    k = key_max(k, key_dpp<0x141>(k));      // row_half_mirror
+    k = key_max(k, key_dpp<0x140>(k));      // row_mirror
+    return k;
+}
+
+__device__ inline key_t read_lane_key(key_t k, int lane)
+{
+    return ((key_t) (unsigned) __builtin_amdgcn_readlane((int) (k >> 32), lane) << 32)
+           | (unsigned) __builtin_amdgcn_readlane((int) k, lane);
+}
+
+// Maximum over a block of up to 1024 threads (a multiple of 64), the same (uniform) value in
+// every thread.  `s_keys` [16] is shared scratch; two uses must be separated by a barrier.
+__device__ inline key_t block_max_key(key_t k, key_t *s_keys)
+{
+    k = row_max_key(k);
+    const key_t w = key_max(key_max(read_lane_key(k, 0), read_lane_key(k, 16)),
+                            key_max(read_lane_key(k, 32), read_lane_key(k, 48)));
+    if ((threadIdx.x & 63) == 0)
+        s_keys[threadIdx.x >> 6] = w;
+    __syncthreads();
+    const int nw = blockDim.x >> 6, e = threadIdx.x & 15;
+    k = row_max_key(e < nw ? s_keys[e] : 0);
+    return read_lane_key(k, 0);
+}
+
 template <int MODE>
 __device__ inline float clean_metric(const float *__restrict__ dirty, int64_t addr,
                                      int64_t pol_stride, int P)
@@ -117,30 +168,33 @@ __global__ __launch_bounds__(256) void update_tiles_kernel(
                     tile_x0 + blockIdx.x, tile_y0 + blockIdx.y, tile_max, tile_pos, tiles_x);
 }
 
-// Global argmax over tiles; thread 0 returns the winning tile index (or -1 when no tiles).
+// Global argmax over tiles, by a 1024-thread block; every thread returns the winning tile index
+// (or -1 when there are no tiles).  All of a thread's loads are issued together and clamped
+// instead of predicated (a duplicate of the last tile under a larger index never wins).
 __device__ inline int peak_tile(const float *__restrict__ tile_max, int num_tiles, float &value)
 {
-    best_t b = {-1.0f, INT_MAX};
-    // the loads of a round are issued together (one L2 round trip per 16 tiles per thread
-    // instead of one per tile: this reduction is pure latency)
+    __shared__ key_t s_peak[16];
+    key_t best = 0;
     constexpr int ROUND = 16;
     for (int base = threadIdx.x; base < num_tiles; base += ROUND * blockDim.x) {
         float v[ROUND];
 #pragma unroll
-        for (int k = 0; k < ROUND; k++) {
-            const int i = base + k * blockDim.x;
-            v[k] = i < num_tiles ? tile_max[i] : -1.0f;
-        }
+        for (int k = 0; k < ROUND; k++)
+            v[k] = tile_max[min(base + k * (int) blockDim.x, num_tiles - 1)];
+        key_t c[ROUND];
 #pragma unroll
         for (int k = 0; k < ROUND; k++)
-            if (v[k] > b.value) {
-                b.value = v[k];
-                b.idx = base + k * blockDim.x;
-            }
+            c[k] = make_key(v[k], base + k * (int) blockDim.x);
+#pragma unroll
+        for (int w = ROUND / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; k++)
+                c[k] = key_max(c[k], c[k + w]);
+        best = key_max(best, c[0]);
     }
-    b = block_best(b);
-    value = b.value;
-    return b.idx == INT_MAX ? -1 : b.idx;
+    best = block_max_key(best, s_peak);
+    value = best ? __uint_as_float((unsigned) (best >> 32)) : -1.0f;
+    return best ? ~(int) (unsigned) best : -1;
 }
 
 __global__ __launch_bounds__(1024) void find_peak_kernel(
@@ -209,36 +263,35 @@ __global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
     // The kernel is a chain of dependent memory round trips; keep it short: the state words are
     // fetched together with the tile maxima (not before them), and the pixel and model values of
     // all polarizations are fetched together before anything is stored.
-    const int done = state->done, count = state->count, limit = state->limit;
+    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, -
+    const int count = st.x, done = st.y, limit = st.z;
     float value;
-    int t = peak_tile(tile_max, num_tiles, value);
-    if (threadIdx.x != 0 || done)
+    const int t = peak_tile(tile_max, num_tiles, value);
+    const int p = threadIdx.x;          // one thread per polarization from here on
+    if (p >= P || done)
         return;
     if (t < 0 || value < threshold || count >= limit) {   // clean.py:1065-1066
-        state->done = 1;
+        if (p == 0)
+            state->done = 1;
         return;
     }
-    const int y = tile_pos[2 * t], x = tile_pos[2 * t + 1];
-    float pix[4], mod[4];
-    for (int p = 0; p < P; p++) {
-        const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
-        pix[p] = dirty[a];
-        mod[p] = model[a];
-    }
+    const int2 pos = *reinterpret_cast<const int2 *>(tile_pos + 2 * t);
+    const int y = pos.x, x = pos.y;
+    const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
+    const float pix = dirty[a], mod = model[a];
     float *entry = log + (int64_t) count * (3 + P);
-    entry[0] = value;
-    entry[1] = __int_as_float(y);
-    entry[2] = __int_as_float(x);
-    state->pos_y = y;
-    state->pos_x = x;
-    for (int p = 0; p < P; p++) {
-        const int64_t a = p * pol_stride + (int64_t) y * row_stride + x;
-        const float s = loop_gain * pix[p];     // clean.py:1044
-        state->scale[p] = s;
-        entry[3 + p] = s;
-        model[a] = mod[p] + s;                  // clean.py:1047
+    const float s = loop_gain * pix;            // clean.py:1044
+    state->scale[p] = s;
+    entry[3 + p] = s;
+    model[a] = mod + s;                         // clean.py:1047
+    if (p == 0) {
+        entry[0] = value;
+        entry[1] = __int_as_float(y);
+        entry[2] = __int_as_float(x);
+        state->pos_y = y;
+        state->pos_x = x;
+        state->count = count + 1;
     }
-    state->count = count + 1;
 }
 
 // One workgroup per 32x32 block of the tile lattice that the PSF patch can touch: subtract
@@ -253,8 +306,9 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     const clean_state *__restrict__ state)
 {
     // one round trip for all the state words (they share a cache line)
-    const int done = state->done;
-    const int px = state->pos_x, py = state->pos_y;
+    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, pos_y
+    const int done = st.y, py = st.w;
+    const int px = state->pos_x;
     float scale[4];
     for (int p = 0; p < 4; p++)
         scale[p] = state->scale[p];
@@ -312,16 +366,19 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     }
     if (!is_tile)
         return;
-    b = block_best(b);
+    __shared__ key_t s_keys[16];
+    const key_t kb = block_max_key(b.idx == INT_MAX ? 0 : make_key(b.value, b.idx), s_keys);
     if (threadIdx.x == 0) {
         const int t = ty * tiles_x + tx;
-        tile_max[t] = b.value;
-        if (b.idx == INT_MAX) {
+        if (kb == 0) {                      // clean.py:950 best_pos = (x0, y0), value 0
+            tile_max[t] = 0.0f;
             tile_pos[2 * t] = ox;
             tile_pos[2 * t + 1] = oy;
         } else {
-            tile_pos[2 * t] = oy + (b.idx >> 5);
-            tile_pos[2 * t + 1] = ox + (b.idx & 31);
+            const int idx = ~(int) (unsigned) kb;
+            tile_max[t] = __uint_as_float((unsigned) (kb >> 32));
+            tile_pos[2 * t] = oy + (idx >> 5);
+            tile_pos[2 * t + 1] = ox + (idx & 31);
         }
     }
 }
@@ -342,9 +399,10 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
 //     entry, the model pixel and the next state.
 // Tile records carry the pixel values at the tile's peak (tile_pix), which saves the dependent
 // load of the peak pixel.  Selection and arithmetic are those of the two-launch form, bit for bit.
-// Measured at 4096^2: 6.5 us per cycle up to ~150 lattice blocks, 10.2 at 256 (more workgroups
-// than CUs), 11.6 at 441, against 11.1-12.2 for two launches; 14.7 vs 12.5 at 529.
-constexpr int FUSED_MAX_BLOCKS = 448;     // measured break-even with the two-launch form
+// Measured at 4096^2: 6.5 us per cycle for 25 lattice blocks, 7.1 for 225; with more workgroups
+// than CUs 10.1 (256 blocks) and 11.6 (441), against 9.0-10.0 for two launches: the one-launch
+// form is used while its workgroups fit the 256 CUs.
+constexpr int FUSED_MAX_BLOCKS = 256;     // workgroups of a launch incl. the bookkeeping row: one per CU
 constexpr int FUSED_ROUND = 16;           // tile maxima per thread and round of a rescan
 constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
 
@@ -465,56 +523,6 @@ __device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *t
 #pragma unroll
     for (int p = 0; p < 4; p++)
         tile_pix[4 * d.tile + p] = d.pix[p];
-}
-
-// (value, index) as one unsigned key: larger value first, then smaller index.  Values are
-// non-negative floats (never NaN: a NaN metric never replaces a tile's best), whose bit patterns
-// order like the numbers.  Key 0 = nothing.
-typedef unsigned long long key_t;
-
-__device__ inline key_t make_key(float value, int idx)
-{
-    return ((key_t) __float_as_uint(value) << 32) | (unsigned) ~idx;
-}
-
-__device__ inline key_t key_max(key_t a, key_t b) { return a > b ? a : b; }
-
-template <int CTRL>
-__device__ inline key_t key_dpp(key_t k)
-{
-    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned) k, CTRL, 0xf, 0xf, true);
-    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned) (k >> 32), CTRL, 0xf, 0xf, true);
-    return ((key_t) hi << 32) | lo;
-}
-
-// Maximum over each 16-lane row, in every lane of the row (DPP butterflies: ALU latency only)
-__device__ inline key_t row_max_key(key_t k)
-{
-    k = key_max(k, key_dpp<0xB1>(k));       // quad_perm [1,0,3,2]
-    k = key_max(k, key_dpp<0x4E>(k));       // quad_perm [2,3,0,1]
-    k = key_max(k, key_dpp<0x141>(k));      // row_half_mirror
-    k = key_max(k, key_dpp<0x140>(k));      // row_mirror
-    return k;
-}
-
-__device__ inline key_t read_lane_key(key_t k, int lane)
-{
-    return ((key_t) (unsigned) __builtin_amdgcn_readlane((int) (k >> 32), lane) << 32)
-           | (unsigned) __builtin_amdgcn_readlane((int) k, lane);
-}
-
-// Maximum over a 1024-thread block, the same (uniform) value in every thread.  `s_keys` [16] is
-// shared scratch; two uses must be separated by a barrier.
-__device__ inline key_t block_max_key(key_t k, key_t *s_keys)
-{
-    k = row_max_key(k);
-    const key_t w = key_max(key_max(read_lane_key(k, 0), read_lane_key(k, 16)),
-                            key_max(read_lane_key(k, 32), read_lane_key(k, 48)));
-    if ((threadIdx.x & 63) == 0)
-        s_keys[threadIdx.x >> 6] = w;
-    __syncthreads();
-    k = row_max_key(s_keys[threadIdx.x & 15]);
-    return read_lane_key(k, 0);
 }
 
 #ifdef KIMG_CLEAN_STAMPS
@@ -1116,7 +1124,7 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     const int bx = kimg_divup(patch_width, TILE) + 1, by = kimg_divup(patch_height, TILE) + 1;
     const char *benv = getenv("KIMG_CLEAN_FUSED_BLOCKS");       // timing experiments only
     const int max_blocks = benv ? atoi(benv) : FUSED_MAX_BLOCKS;
-    const bool fused = bx * by <= max_blocks && bx <= 32 && by <= 32
+    const bool fused = bx * (by + 1) <= max_blocks && bx <= 32 && by <= 32
                        && kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) <= FUSED_MAX_SLOTS
                        && !(fenv && fenv[0] == '0');
     KIMG_HIP(hipMemsetAsync(state, 0, sizeof(fused_scratch), s));
