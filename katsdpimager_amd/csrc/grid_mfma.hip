@@ -38,6 +38,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -78,7 +79,7 @@ __device__ inline uint32_t changed_mask(int W, int nW)
 template <int P>
 __device__ __attribute__((always_inline)) inline void flush_window(
     window_acc<P> &acc, float *__restrict__ grid, int64_t row_stride, int64_t pol_stride,
-    int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane)
+    int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane, float scale = 1.0f)
 {
     const uint32_t row_mask = full ? 0xffffffffu : changed_mask(Wv, nWv);
     const uint32_t col_mask = full ? 0xffffffffu : changed_mask(Wu, nWu);
@@ -113,7 +114,7 @@ __device__ __attribute__((always_inline)) inline void flush_window(
                 for (int p = 0; p < P; p++) {
                     const float v = t ? acc.t1[p][k] : acc.t0[p][k];
                     if (x_ok[t] && y_ok && v != 0.0f)
-                        atomicAdd(cell + 2 * p * pol_stride, v);
+                        atomicAdd(cell + 2 * p * pol_stride, v * scale);
                     if (t)
                         acc.t1[p][k] = 0.0f;
                     else
@@ -179,7 +180,54 @@ struct tap_split {
 // hundreds per slice) and are read from a zero-padded copy in HBM instead ([rows][32] taps,
 // built per call by pad_table_kernel; served by L1/L2 -- rows recur along a track).  Everything
 // else is unchanged; only the operand reads are global loads.
-template <int P, int NW, int SUB, int ROW, bool TWO, bool TG = false>
+// ---- fp16 hi/lo formulation (F16 = true) ------------------------------------------------------
+// Each fp32 operand x is carried as two halfs, hi = fp16(x) and lo = fp16(x - hi) (22 bits), and
+// a product as hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22 of it).  A complex multiply-add
+// therefore needs 6 of the 16 k-slots of v_mfma_f32_32x32x16_f16, so ONE instruction (8 passes)
+// carries TWO visibilities -- lanes 0-31 (k 0..7) hold one, lanes 32-63 (k 8..15) the other --
+// against one visibility per 16-pass v_mfma_f32_32x32x2_f32: a quarter of the matrix time.
+// fp16 has little exponent range, so the operands are scaled by powers of two (exact): the table
+// by S (largest tap -> [2^13, 2^14)), the samples of a wave by T (largest sample -> [1, 2)); the
+// accumulators then hold grid * S*S*T and are multiplied by 1/(S*S*T) when they are flushed.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline unsigned cvt_pk_f16_rtz(float lo, float hi)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 r = __builtin_amdgcn_cvt_pkrtz(lo, hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ inline float f16_bits_to_f32(unsigned bits16)
+{
+    return (float) __builtin_bit_cast(_Float16, (unsigned short) bits16);
+}
+
+// x -> (hi | lo << 16)
+__device__ inline unsigned split_f16(float x)
+{
+    const unsigned hi = cvt_pk_f16_rtz(x, 0.0f) & 0xffffu;
+    const float rest = x - f16_bits_to_f32(hi);
+    const unsigned lo = cvt_pk_f16_rtz(rest, 0.0f) & 0xffffu;
+    return hi | (lo << 16);
+}
+
+// (hi | lo << 16) -> fp32
+__device__ inline float join_f16(unsigned packed)
+{
+    return f16_bits_to_f32(packed & 0xffffu) + f16_bits_to_f32(packed >> 16);
+}
+
+// Operands of SUBP staged PAIRS of visibilities (this lane's member of each pair)
+template <int SUBP>
+struct pair_ops {
+    float4 c[SUBP];         // (Re s, Im s, Im s, -Re s) * T
+    uint2 kv[SUBP];         // row tap: (re_hi | re_lo << 16, im_hi | im_lo << 16), times S
+    uint2 t0[SUBP], t1[SUBP];   // column taps of the two tiles, same format
+};
+
+template <int P, int NW, int SUB, int ROW, bool TWO, bool TG = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const float *__restrict__ weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
@@ -189,6 +237,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     int p_total, int dbg, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || ROW == 32 || TG, "two tables only fit LDS with single rows");
+    static_assert(!F16 || (P == 1 && ROW == 64 && !TWO && !TG && SUB == 4), "fp16 form: narrow LDS case only");
     extern __shared__ __align__(16) unsigned char smem[];
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW * (int) sizeof(float2);
@@ -298,6 +347,34 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             stage_table(smem + table_bytes, ts.tu0, ts.Ku);
     }
     __syncthreads();
+    float S_scale = 1.0f;
+    if (F16) {
+        // largest |component| of the table -> S, then every tap is split in place
+        unsigned *s_tabmax = reinterpret_cast<unsigned *>(rec_base);   // (staging area, not yet in use)
+        const unsigned *words = reinterpret_cast<const unsigned *>(smem);
+        const int nwords = table_bytes / 4;
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < nwords; i += NW * 64)
+            m = max(m, words[i] & 0x7fffffffu);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            m = max(m, (unsigned) __shfl_xor((int) m, off, WAVE));
+        if (lane == 0)
+            s_tabmax[wib] = m;
+        __syncthreads();
+        for (int w = 0; w < NW; w++)
+            m = max(m, s_tabmax[w]);
+        // m in [2^e, 2^(e+1)): S = 2^(13 - e)
+        const int e = (int) (m >> 23) - 127;
+        S_scale = m ? __uint_as_float((unsigned) (13 - e + 127) << 23) : 1.0f;
+        uint2 *taps = reinterpret_cast<uint2 *>(smem);
+        for (int i = threadIdx.x; i < nwords / 2; i += NW * 64) {
+            const uint2 t = taps[i];
+            taps[i] = make_uint2(split_f16(__uint_as_float(t.x) * S_scale),
+                                 split_f16(__uint_as_float(t.y) * S_scale));
+        }
+        __syncthreads();
+    }
     if (!active)
         return;
     gather(start, r0);
@@ -313,6 +390,17 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int lane_v = (lane & 31) * 8;                                 // row tap, bytes
     const int lane_u = ((lane & 31) >> 1) * 8 + (b_take_im ? 4 : 0);    // column tap component
     const int lane_s = h ? 8 : 0;                                       // (Re,Im) or (Im,-Re)
+    // fp16 form: which member of a pair this lane serves, the (whole) column tap it reads, and how
+    // its 6 k-slots are cut from (re_hi, re_lo | im_hi, im_lo): even columns (real part) take
+    // (re_hi, re_lo, re_hi, im_hi, im_lo, im_hi), odd ones (-im_hi, -im_lo, -im_hi, re_hi, re_lo, re_hi)
+    const int member = lane >> 5;
+    const int lane_u16 = ((lane & 31) >> 1) * 8;
+    const unsigned sel0 = part ? 0x07060504u : 0x03020100u;
+    const unsigned sel1 = part ? 0x01000504u : 0x05040100u;
+    const unsigned sel2 = part ? 0x01000302u : 0x05040706u;
+    const unsigned flip0 = part ? 0x80008000u : 0u, flip1 = part ? 0x00008000u : 0u;
+    float T_scale = 0.0f;           // sample scale of this wave (0: not chosen yet)
+    float out_scale = 1.0f;         // 1 / (S * S * T)
 
     window_acc<P> acc;
 #pragma unroll
@@ -341,7 +429,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         const int nWv = !bad_v ? Wv : (hi_v > Wv + Sv ? lo_v : hi_v - Sv);
         const bool full = nWu - Wu >= WIN || Wu - nWu >= WIN || nWv - Wv >= WIN || Wv - nWv >= WIN;
         if (!(dbg & 2))
-            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane);
+            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane,
+                            out_scale);
         Wu = nWu;
         Wv = nWv;
     };
@@ -359,11 +448,26 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     // ---- software-pipeline stages over sub-blocks of SUB staged visibilities ---------------
     int2 rec[SUB];
     auto stage_a = [&](int first) __attribute__((always_inline)) {         // record reads
+        if constexpr (F16) {
 #pragma unroll
-        for (int t = 0; t < SUB; t++)
-            rec[t] = recs[first + t];
+            for (int t = 0; t < SUB / 2; t++)
+                rec[t] = recs[first + 2 * t + member];      // this lane's member of pair t
+        } else {
+#pragma unroll
+            for (int t = 0; t < SUB; t++)
+                rec[t] = recs[first + t];
+        }
     };
-    auto stage_b = [&](sub_ops<P, SUB> &o, int first) __attribute__((always_inline)) {     // sample + kernel-table reads
+    auto stage_b = [&](auto &o, int first) __attribute__((always_inline)) {     // sample + kernel-table reads
+        if constexpr (F16) {
+#pragma unroll
+            for (int t = 0; t < SUB / 2; t++) {
+                o.kv[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].y + lane_v));
+                o.t0[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].x + lane_u16));
+                o.t1[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].x + lane_u16) + 128);
+                o.c[t] = samples[first + 2 * t + member];
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
             const unsigned au = addr_u(rec[t].x);
@@ -376,8 +480,51 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 o.c[p][t] = *reinterpret_cast<const float2 *>(
                     reinterpret_cast<const unsigned char *>(samples + p * 64 + first + t) + lane_s);
         }
+        }
     };
-    auto stage_c = [&](const sub_ops<P, SUB> &o) __attribute__((always_inline)) {
+    // fp16 form: the 6 k-slots of this lane's visibility (row operand) and of its column taps
+    auto row_operand = [&](const float4 &c, const uint2 &kvp, bool zero) __attribute__((always_inline)) {
+        const float kre = join_f16(kvp.x), kim = join_f16(kvp.y);
+        float are = fmaf(c.x, kre, c.y * kim);          // Re(s conj kv) * S * T
+        float aim = fmaf(c.z, kre, c.w * kim);          // Im(s conj kv) * S * T
+        if (zero)
+            are = aim = 0.0f;
+        u32x4 A;
+        A[0] = cvt_pk_f16_rtz(are, are);                            // (re_hi, re_hi)
+        const float re_lo = are - f16_bits_to_f32(A[0] & 0xffffu);
+        A[1] = cvt_pk_f16_rtz(re_lo, aim);                          // (re_lo, im_hi)
+        const float im_lo = aim - f16_bits_to_f32(A[1] >> 16);
+        A[2] = cvt_pk_f16_rtz(aim, im_lo);                          // (im_hi, im_lo)
+        A[3] = 0;
+        return A;
+    };
+    auto col_operand = [&](const uint2 &tp) __attribute__((always_inline)) {
+        u32x4 B;
+        B[0] = __builtin_amdgcn_perm(tp.y, tp.x, sel0) ^ flip0;
+        B[1] = __builtin_amdgcn_perm(tp.y, tp.x, sel1) ^ flip1;
+        B[2] = __builtin_amdgcn_perm(tp.y, tp.x, sel2);
+        B[3] = 0;
+        return B;
+    };
+    auto stage_c = [&](const auto &o) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            u32x4 A[SUB / 2], B0[SUB / 2], B1[SUB / 2];
+#pragma unroll
+            for (int t = 0; t < SUB / 2; t++) {
+                A[t] = row_operand(o.c[t], o.kv[t], false);
+                B0[t] = col_operand(o.t0[t]);
+                B1[t] = col_operand(o.t1[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < SUB / 2; t++) {
+                acc.t0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, A[t]), __builtin_bit_cast(f16x8, B0[t]), acc.t0[0], 0, 0, 0);
+                acc.t1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, A[t]), __builtin_bit_cast(f16x8, B1[t]), acc.t1[0], 0, 0, 0);
+            }
+            return;
+        } else {
         // all operands first, then the MFMAs back to back (no VALU -> MFMA wait states)
         float a[P][SUB], b0[SUB], b1[SUB];
 #pragma unroll
@@ -396,6 +543,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b0[t], acc.t0[p], 0, 0, 0);
                 acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b1[t], acc.t1[p], 0, 0, 0);
             }
+        }
     };
     // A group whose visibilities do not share one window position (a jump inside the group):
     // rolled loop, window positioned per visibility, operands re-read from LDS.  Rare.
@@ -416,6 +564,19 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             fit_window(__builtin_amdgcn_readfirstlane(org.x), __builtin_amdgcn_readfirstlane(org.x),
                        __builtin_amdgcn_readfirstlane(org.y), __builtin_amdgcn_readfirstlane(org.y));
             const int2 r = recs[idx];
+            if constexpr (F16) {
+                // one visibility, carried by the first member of a pair; the second contributes 0
+                const uint2 kvp = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.y + lane_v));
+                const uint2 tp0 = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.x + lane_u16));
+                const uint2 tp1 = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.x + lane_u16) + 128);
+                const u32x4 A = row_operand(samples[idx], kvp, member != 0);
+                const u32x4 B0 = col_operand(tp0), B1 = col_operand(tp1);
+                acc.t0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B0), acc.t0[0], 0, 0, 0);
+                acc.t1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc.t1[0], 0, 0, 0);
+                continue;
+            }
             const unsigned au = addr_u(r.x);
             const float2 kv = *reinterpret_cast<const float2 *>(tbytes + addr_v(r.y));
             const float b0 = *reinterpret_cast<const float *>(tbytes + au) * b_sign;
@@ -447,8 +608,30 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             bool live = false;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const float2 sp = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
-                                     : make_float2(0.0f, 0.0f);             // grid.py:1046
+                float2 sp = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
+                               : make_float2(0.0f, 0.0f);                   // grid.py:1046
+                if constexpr (F16) {
+                    // keep the wave's samples in fp16 range: T = 2^-e for the largest one in
+                    // [2^e, 2^(e+1)); a larger sample later on flushes the window (its cells are
+                    // in units of the old T) and picks a new T
+                    unsigned mb = max(__float_as_uint(sp.x) & 0x7fffffffu,
+                                      __float_as_uint(sp.y) & 0x7fffffffu);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1)
+                        mb = max(mb, (unsigned) __shfl_xor((int) mb, off, WAVE));
+                    mb = __builtin_amdgcn_readfirstlane(mb);
+                    if (mb != 0 && (T_scale == 0.0f || __uint_as_float(mb) * T_scale > 2.0f)) {
+                        if (have && T_scale != 0.0f)
+                            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv,
+                                            true, lane, out_scale);
+                        int e = (int) (mb >> 23) - 127;
+                        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+                        T_scale = __uint_as_float((unsigned) (127 - e) << 23);
+                        out_scale = 1.0f / (S_scale * S_scale * T_scale);
+                    }
+                    sp.x *= T_scale;
+                    sp.y *= T_scale;
+                }
                 samples[p * 64 + lane] = make_float4(sp.x, sp.y, sp.y, -sp.x);
                 live |= (sp.x != 0.0f) | (sp.y != 0.0f);
             }
@@ -469,7 +652,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
 
         const int count = end - b < 64 ? (int) (end - b) : 64;
         const int npairs = (count + 2 * SUB - 1) / (2 * SUB);
-        sub_ops<P, SUB> X, Y;
+        typename std::conditional<F16, pair_ops<SUB / 2>, sub_ops<P, SUB>>::type X, Y;
         stage_a(0);
         stage_b(X, 0);
         stage_a(SUB);
@@ -532,7 +715,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     if (have && !(dbg & 1))
-        flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane);
+        flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane, out_scale);
 }
 
 template <int P>
@@ -562,7 +745,7 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int ROW, int NW, bool TWO, bool TG = false>
+template <int P, int ROW, int NW, bool TWO, bool TG = false, bool F16 = false>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
@@ -584,7 +767,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     static bool attr_set = false;
     if (!attr_set) {
         KIMG_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG>),
+            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -604,7 +787,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG><<<blocks, NW * 64, lds, stream>>>(
+    grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
         num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded);
     return kimg_launch_status();
@@ -742,8 +925,17 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                     }
                 } else if (pn == 1) {
                     // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
-                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
-                        LAUNCH(1, 64, 12, false);
+                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8) {
+                        // fp16 hi/lo form (two visibilities per matrix instruction) unless
+                        // KIMG_GRID_F16=0 asks for the exact-fp32 instruction
+                        const char *fenv = getenv("KIMG_GRID_F16");
+                        if (!(fenv && fenv[0] == '0'))
+                            rc = launch<1, 64, 12, false, false, true>(g, grid_row_stride,
+                                grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv,
+                                w_plane, v, num_vis, kern, w_planes, oversample, ts, P, stream);
+                        else
+                            LAUNCH(1, 64, 12, false);
+                    }
                     else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
                         LAUNCH(1, 64, 8, false);
                     else

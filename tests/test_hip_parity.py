@@ -1345,3 +1345,58 @@ def test_noise_est_device_selection(H, W, P, border):
         assert got.dtype == np.float32
         assert got == np.float32(want), (case, got, want)
         assert got == op.host_select()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pattern', ['1e-20', '1e-6', '1', '1e6', '1e20', 'jump_up', 'jump_down',
+                                     'alternate', 'zeros', 'one_in_zeros'])
+def test_gridder_f16_form_ranges(pattern):
+    """The fp16 hi/lo form of the window gridder (two visibilities per matrix instruction) keeps its
+    operands in fp16 range with power-of-two scales chosen on the fly: table scale from the largest
+    tap, sample scale per wave, re-chosen (after a flush) when a larger sample arrives.  Whatever
+    the magnitudes -- tiny, huge, jumping by 10^12 either way, mixed, mostly zero -- the result
+    stays within the 1e-5 gate of the exact-fp32 form and of the oracle."""
+    import os
+    c = gi.make_config(256, 0.0001, 0.01, 1, 28, 32, grid_cover=180, n_vis=1200)
+    t = gi.grid_track(c)
+    n = len(t['uv'])
+    rs = np.random.RandomState(7)
+    scale = np.ones(n, np.float32)
+    if pattern == 'jump_up':
+        scale[:] = 1e-6
+        scale[n // 2 + 13:] = 1e6
+    elif pattern == 'jump_down':
+        scale[:] = 1e6
+        scale[n // 3 + 5:] = 1e-6
+    elif pattern == 'alternate':
+        scale = (10.0 ** rs.randint(-8, 9, n)).astype(np.float32)
+    elif pattern == 'zeros':
+        scale[:] = 0.0
+    elif pattern == 'one_in_zeros':
+        scale[:] = 0.0
+        scale[777] = 3.0e4
+    else:
+        scale[:] = float(pattern)
+    t = dict(t)
+    t['vis'] = (t['vis'] * scale[:, None]).astype(np.complex64)
+
+    def run(flag):
+        os.environ['KIMG_GRID_F16'] = flag
+        try:
+            fn, q = _gridder(c, 'mfma')
+            return _run_gridder(fn, q, t), fn.convolve_kernel.data
+        finally:
+            os.environ.pop('KIMG_GRID_F16', None)
+    exact, kernel = run('0')
+    split, _ = run('1')
+    assert np.all(np.isfinite(split))
+    peak = np.abs(exact).max()
+    if peak == 0:
+        assert np.abs(split).max() == 0
+        return
+    assert np.abs(split - exact).max() <= 2e-6 * peak
+    want = np.zeros(exact.shape, np.complex64)
+    wg = np.zeros(exact.shape, np.float32)
+    gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
+    orc.grid(kernel, want, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
+    assert relerr(split, want) < GRID_TOL

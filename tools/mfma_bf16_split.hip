@@ -2,11 +2,38 @@
 // and contracted by v_mfma_f32_32x32x16_bf16 (6 cross terms x (re, im) = 12 of 16 k-slots),
 // against the exact-fp32 v_mfma_f32_32x32x2_f32 formulation.  Per "visibility": operand LDS
 // reads, a = c.kv, split/pack of a and of two b values, 2 MFMAs.
+// MODE 2: fp16 hi/lo split (hi*hi + hi*lo + lo*hi for re and im = 6 k-slots per visibility) with
+// TWO visibilities per v_mfma_f32_32x32x16_f16: lanes 0-31 (k 0..7) carry one visibility, lanes
+// 32-63 (k 8..15) the other; the column operand comes pre-split from the table (re_hi, re_lo,
+// im_hi, im_lo per tap, the same 8 bytes) and is arranged with three v_perm and two sign flips.
+// Throughput only: operand values are not meaningful.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned cvt_pk_f16(float lo, float hi)
+{
+    unsigned r;
+    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+__device__ inline float f16_lo_to_f32(unsigned packed)
+{
+    float r;
+    asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(packed));
+    return r;
+}
+
+__device__ inline float f16_hi_to_f32(unsigned packed)
+{
+    float r;
+    asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(packed));
+    return r;
+}
 
 __device__ inline unsigned cvt_pk_bf16(float lo, float hi)
 {
@@ -53,6 +80,13 @@ __global__ __launch_bounds__(768) void k(float *out, int iters)
     const unsigned char *tb = reinterpret_cast<const unsigned char *>(table);
     const int lane_v = (lane & 31) * 8, lane_u = ((lane & 31) >> 1) * 8 + ((lane & 1) ? 4 : 0);
     const float sign = (lane & 33) == 1 ? -1.0f : 1.0f;
+    // MODE 2: per-parity byte selectors and sign masks of the column operand
+    const int lane_u2 = ((lane & 31) >> 1) * 8;
+    const bool odd = lane & 1;
+    const unsigned sel0 = odd ? 0x07060504u : 0x03020100u;
+    const unsigned sel1 = odd ? 0x01000504u : 0x05040100u;
+    const unsigned sel2 = odd ? 0x01000302u : 0x05040706u;
+    const unsigned sgn1 = odd ? 0u : 0x80000000u, sgn2 = odd ? 0u : 0x80008000u;
     int rv = (threadIdx.x >> 6) * 512, ru = rv + 256;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -64,7 +98,33 @@ __global__ __launch_bounds__(768) void k(float *out, int iters)
             const float2 c = *reinterpret_cast<const float2 *>(
                 reinterpret_cast<const unsigned char *>(samples + ((it * 4 + t) & 63)) + (lane >= 32 ? 8 : 0));
             const float a = fmaf(c.x, kv.x, c.y * kv.y);
-            if (MODE == 0) {
+            if (MODE == 2) {
+                // this lane's visibility: both components of a, split and packed into 6 k-slots
+                const float a_im = fmaf(c.y, kv.x, -c.x * kv.y);
+                u32x4 A;
+                A[0] = cvt_pk_f16(a, a);                                    // (re_hi, re_hi)
+                const float re_lo = a - f16_lo_to_f32(A[0]);
+                A[1] = cvt_pk_f16(re_lo, a_im);                             // (re_lo, im_hi)
+                const float im_lo = a_im - f16_hi_to_f32(A[1]);
+                A[2] = cvt_pk_f16(a_im, im_lo);                             // (im_hi, im_lo)
+                A[3] = 0;
+                // column operands of the two 16-column tiles from pre-split table entries
+                const uint2 t0 = *reinterpret_cast<const uint2 *>(tb + ru + lane_u2);
+                const uint2 t1 = *reinterpret_cast<const uint2 *>(tb + ru + lane_u2 + 128);
+                u32x4 B0, B1;
+                B0[0] = __builtin_amdgcn_perm(t0.y, t0.x, sel0);
+                B0[1] = __builtin_amdgcn_perm(t0.y, t0.x, sel1) ^ sgn1;
+                B0[2] = __builtin_amdgcn_perm(t0.y, t0.x, sel2) ^ sgn2;
+                B0[3] = 0;
+                B1[0] = __builtin_amdgcn_perm(t1.y, t1.x, sel0);
+                B1[1] = __builtin_amdgcn_perm(t1.y, t1.x, sel1) ^ sgn1;
+                B1[2] = __builtin_amdgcn_perm(t1.y, t1.x, sel2) ^ sgn2;
+                B1[3] = 0;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A),
+                                                              __builtin_bit_cast(f16x8, B0), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A),
+                                                              __builtin_bit_cast(f16x8, B1), acc1, 0, 0, 0);
+            } else if (MODE == 0) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             } else {
@@ -94,8 +154,8 @@ void run(float *out, const char *name)
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
-        // "visibilities" per SIMD: iters * 4 * (waves / 4)
-        double ns = ms * 1e6 / ((double) iters * 4 * (waves / 4.0));
+        // "visibilities" per SIMD: iters * 4 * (waves / 4), twice that when an MFMA pair covers two
+        double ns = ms * 1e6 / ((double) iters * 4 * (MODE == 2 ? 2 : 1) * (waves / 4.0));
         printf("%s waves/SIMD %d: %.1f ns per visibility per SIMD -> %.2f Gvis/s chip\n", name, waves / 4, ns,
                1024.0 / ns);
     }
@@ -106,5 +166,6 @@ int main()
     float *out; hipMalloc(&out, 256 * 768 * 4);
     run<0>(out, "fp32 mfma 32x32x2 ");
     run<1>(out, "bf16x3 split 32x32x16");
+    run<2>(out, "fp16x2 split, 2 vis/MFMA");
     return 0;
 }
