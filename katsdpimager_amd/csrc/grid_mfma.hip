@@ -220,9 +220,9 @@ __device__ inline float join_f16(unsigned packed)
 }
 
 // Operands of SUBP staged PAIRS of visibilities (this lane's member of each pair)
-template <int SUBP>
+template <int P, int SUBP>
 struct pair_ops {
-    float4 c[SUBP];         // (Re s, Im s, Im s, -Re s) * T
+    float4 c[P][SUBP];      // (Re s, Im s, Im s, -Re s) * T
     uint2 kv[SUBP];         // row tap: (re_hi | re_lo << 16, im_hi | im_lo << 16), times S
     uint2 t0[SUBP], t1[SUBP];   // column taps of the two tiles, same format
 };
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     int p_total, int dbg, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || ROW == 32 || TG, "two tables only fit LDS with single rows");
-    static_assert(!F16 || (P == 1 && ROW == 64 && !TWO && !TG && SUB == 4), "fp16 form: narrow LDS case only");
+    static_assert(!F16 || (!TWO && !TG && SUB % 2 == 0), "fp16 form: one table, in LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW * (int) sizeof(float2);
@@ -461,6 +461,9 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     auto addr_u = [&](int rx) __attribute__((always_inline)) {
         return (unsigned) (ROW == 64 ? rx + lane_u : (rx & ~0xff) | ((rx + lane_u) & 0xfc));
     };
+    auto addr_u16 = [&](int rx) __attribute__((always_inline)) {         // whole column tap
+        return (unsigned) (ROW == 64 ? rx + lane_u16 : (rx & ~0xff) | ((rx + lane_u16) & 0xf8));
+    };
 
     // ---- software-pipeline stages over sub-blocks of SUB staged visibilities ---------------
     int2 rec[SUB];
@@ -479,10 +482,14 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         if constexpr (F16) {
 #pragma unroll
             for (int t = 0; t < SUB / 2; t++) {
-                o.kv[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].y + lane_v));
-                o.t0[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].x + lane_u16));
-                o.t1[t] = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (rec[t].x + lane_u16) + 128);
-                o.c[t] = samples[first + 2 * t + member];
+                const unsigned au = addr_u16(rec[t].x);
+                o.kv[t] = *reinterpret_cast<const uint2 *>(tbytes + addr_v(rec[t].y));
+                o.t0[t] = *reinterpret_cast<const uint2 *>(tbytes + au);
+                o.t1[t] = *reinterpret_cast<const uint2 *>(ROW == 64 ? tbytes + au + 128
+                                                                     : tbytes + (au ^ 128u));
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    o.c[p][t] = samples[p * 64 + first + 2 * t + member];
             }
         } else {
 #pragma unroll
@@ -500,8 +507,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         }
     };
     // fp16 form: the 6 k-slots of this lane's visibility (row operand) and of its column taps
-    auto row_operand = [&](const float4 &c, const uint2 &kvp, bool zero) __attribute__((always_inline)) {
-        const float kre = join_f16(kvp.x), kim = join_f16(kvp.y);
+    auto row_operand = [&](const float4 &c, float kre, float kim, bool zero) __attribute__((always_inline)) {
         float are = fmaf(c.x, kre, c.y * kim);          // Re(s conj kv) * S * T
         float aim = fmaf(c.z, kre, c.w * kim);          // Im(s conj kv) * S * T
         if (zero)
@@ -525,21 +531,26 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     };
     auto stage_c = [&](const auto &o) __attribute__((always_inline)) {
         if constexpr (F16) {
-            u32x4 A[SUB / 2], B0[SUB / 2], B1[SUB / 2];
+            u32x4 A[P][SUB / 2], B0[SUB / 2], B1[SUB / 2];
 #pragma unroll
             for (int t = 0; t < SUB / 2; t++) {
-                A[t] = row_operand(o.c[t], o.kv[t], false);
+                const float kre = join_f16(o.kv[t].x), kim = join_f16(o.kv[t].y);
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    A[p][t] = row_operand(o.c[p][t], kre, kim, false);
                 B0[t] = col_operand(o.t0[t]);
                 B1[t] = col_operand(o.t1[t]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < SUB / 2; t++) {
-                acc.t0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    __builtin_bit_cast(f16x8, A[t]), __builtin_bit_cast(f16x8, B0[t]), acc.t0[0], 0, 0, 0);
-                acc.t1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    __builtin_bit_cast(f16x8, A[t]), __builtin_bit_cast(f16x8, B1[t]), acc.t1[0], 0, 0, 0);
-            }
+            for (int t = 0; t < SUB / 2; t++)
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, A[p][t]), __builtin_bit_cast(f16x8, B0[t]), acc.t0[p], 0, 0, 0);
+                    acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, A[p][t]), __builtin_bit_cast(f16x8, B1[t]), acc.t1[p], 0, 0, 0);
+                }
             return;
         } else {
         // all operands first, then the MFMAs back to back (no VALU -> MFMA wait states)
@@ -583,15 +594,21 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             const int2 r = recs[idx];
             if constexpr (F16) {
                 // one visibility, carried by the first member of a pair; the second contributes 0
-                const uint2 kvp = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.y + lane_v));
-                const uint2 tp0 = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.x + lane_u16));
-                const uint2 tp1 = *reinterpret_cast<const uint2 *>(tbytes + (unsigned) (r.x + lane_u16) + 128);
-                const u32x4 A = row_operand(samples[idx], kvp, member != 0);
+                const unsigned au16 = addr_u16(r.x);
+                const uint2 kvp = *reinterpret_cast<const uint2 *>(tbytes + addr_v(r.y));
+                const uint2 tp0 = *reinterpret_cast<const uint2 *>(tbytes + au16);
+                const uint2 tp1 = *reinterpret_cast<const uint2 *>(ROW == 64 ? tbytes + au16 + 128
+                                                                           : tbytes + (au16 ^ 128u));
+                const float kre = join_f16(kvp.x), kim = join_f16(kvp.y);
                 const u32x4 B0 = col_operand(tp0), B1 = col_operand(tp1);
-                acc.t0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B0), acc.t0[0], 0, 0, 0);
-                acc.t1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc.t1[0], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const u32x4 A = row_operand(samples[p * 64 + idx], kre, kim, member != 0);
+                    acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B0), acc.t0[p], 0, 0, 0);
+                    acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc.t1[p], 0, 0, 0);
+                }
                 continue;
             }
             const unsigned au = addr_u(r.x);
@@ -623,34 +640,43 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             recs[lane] = r;
             origins[lane] = make_int2(mu, mv);
             bool live = false;
+            float2 sp[P];
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                sp[p] = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
+                           : make_float2(0.0f, 0.0f);                       // grid.py:1046
+            if constexpr (F16) {
+                // keep the wave's samples in fp16 range: T = 2^-e for the largest one in
+                // [2^e, 2^(e+1)); a larger sample later on flushes the window (its cells are
+                // in units of the old T) and picks a new T
+                unsigned mb = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    mb = max(mb, max(__float_as_uint(sp[p].x) & 0x7fffffffu,
+                                     __float_as_uint(sp[p].y) & 0x7fffffffu));
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    mb = max(mb, (unsigned) __shfl_xor((int) mb, off, WAVE));
+                mb = __builtin_amdgcn_readfirstlane(mb);
+                if (mb != 0 && (T_scale == 0.0f || __uint_as_float(mb) * T_scale > 2.0f)) {
+                    if (have && T_scale != 0.0f)
+                        flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv,
+                                        true, lane, out_scale);
+                    int e = (int) (mb >> 23) - 127;
+                    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+                    T_scale = __uint_as_float((unsigned) (127 - e) << 23);
+                    out_scale = 1.0f / (S_scale * S_scale * T_scale);
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    sp[p].x *= T_scale;
+                    sp[p].y *= T_scale;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                float2 sp = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
-                               : make_float2(0.0f, 0.0f);                   // grid.py:1046
-                if constexpr (F16) {
-                    // keep the wave's samples in fp16 range: T = 2^-e for the largest one in
-                    // [2^e, 2^(e+1)); a larger sample later on flushes the window (its cells are
-                    // in units of the old T) and picks a new T
-                    unsigned mb = max(__float_as_uint(sp.x) & 0x7fffffffu,
-                                      __float_as_uint(sp.y) & 0x7fffffffu);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1)
-                        mb = max(mb, (unsigned) __shfl_xor((int) mb, off, WAVE));
-                    mb = __builtin_amdgcn_readfirstlane(mb);
-                    if (mb != 0 && (T_scale == 0.0f || __uint_as_float(mb) * T_scale > 2.0f)) {
-                        if (have && T_scale != 0.0f)
-                            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv,
-                                            true, lane, out_scale);
-                        int e = (int) (mb >> 23) - 127;
-                        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-                        T_scale = __uint_as_float((unsigned) (127 - e) << 23);
-                        out_scale = 1.0f / (S_scale * S_scale * T_scale);
-                    }
-                    sp.x *= T_scale;
-                    sp.y *= T_scale;
-                }
-                samples[p * 64 + lane] = make_float4(sp.x, sp.y, sp.y, -sp.x);
-                live |= (sp.x != 0.0f) | (sp.y != 0.0f);
+                samples[p * 64 + lane] = make_float4(sp[p].x, sp[p].y, sp[p].y, -sp[p].x);
+                live |= (sp[p].x != 0.0f) | (sp[p].y != 0.0f);
             }
             // bounds over each aligned group of 8 lanes; dead visibilities do not constrain
             gmin_u = group8_min(live ? mu : INT_MAX);
@@ -669,7 +695,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
 
         const int count = end - b < 64 ? (int) (end - b) : 64;
         const int npairs = (count + 2 * SUB - 1) / (2 * SUB);
-        typename std::conditional<F16, pair_ops<SUB / 2>, sub_ops<P, SUB>>::type X, Y;
+        typename std::conditional<F16, pair_ops<P, SUB / 2>, sub_ops<P, SUB>>::type X, Y;
         stage_a(0);
         stage_b(X, 0);
         stage_a(SUB);
@@ -942,28 +968,29 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
                             kern, w_planes, oversample, ts, P, stream, padded);
                     }
-                } else if (pn == 1) {
-                    // 156 VGPRs -> 3 waves per SIMD: 12-wave blocks, one per CU (LDS-bound)
-                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8) {
-                        // fp16 hi/lo form (two visibilities per matrix instruction) unless
-                        // KIMG_GRID_F16=0 asks for the exact-fp32 instruction
-                        const char *fenv = getenv("KIMG_GRID_F16");
-                        if (!(fenv && fenv[0] == '0'))
-                            rc = launch<1, 64, 12, false, false, true>(g, grid_row_stride,
-                                grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv,
-                                w_plane, v, num_vis, kern, w_planes, oversample, ts, P, stream);
-                        else
-                            LAUNCH(1, 64, 12, false);
-                    }
-                    else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                        LAUNCH(1, 64, 8, false);
-                    else
-                        LAUNCH(1, 32, 8, false);
                 } else {
-                    if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                        LAUNCH(2, 64, 8, false);
-                    else
-                        LAUNCH(2, 32, 8, false);
+                    // one table in LDS: the fp16 hi/lo form (two visibilities per matrix
+                    // instruction) unless KIMG_GRID_F16=0 asks for the exact-fp32 instruction
+                    const char *fenv = getenv("KIMG_GRID_F16");
+                    const bool f16 = !(fenv && fenv[0] == '0');
+#define LAUNCH1(PP, ROWV, NWV) do { if (f16) rc = launch<PP, ROWV, NWV, false, false, true>(g, \
+        grid_row_stride, grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, \
+        num_vis, kern, w_planes, oversample, ts, P, stream); else LAUNCH(PP, ROWV, NWV, false); } while (0)
+                    if (pn == 1) {
+                        // 12-wave blocks, one per CU (LDS-bound), when the doubled table leaves room
+                        if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
+                            LAUNCH1(1, 64, 12);
+                        else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                            LAUNCH1(1, 64, 8);
+                        else
+                            LAUNCH1(1, 32, 8);
+                    } else {
+                        if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                            LAUNCH1(2, 64, 8);
+                        else
+                            LAUNCH1(2, 32, 8);
+                    }
+#undef LAUNCH1
                 }
 #undef LAUNCH
                 if (rc)
