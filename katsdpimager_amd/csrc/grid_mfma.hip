@@ -234,10 +234,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float2 *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
-    int p_total, int dbg, const unsigned char *__restrict__ padded)
+    int p_total, int dbg, const unsigned char *__restrict__ padded,
+    const unsigned *__restrict__ tab_max)
 {
     static_assert(!TWO || ROW == 32 || TG, "two tables only fit LDS with single rows");
-    static_assert(!F16 || (!TWO && !TG && SUB % 2 == 0), "fp16 form: one table, in LDS");
+    static_assert(!F16 || SUB % 2 == 0, "fp16 form: visibilities go in pairs");
     extern __shared__ __align__(16) unsigned char smem[];
     const int table_rows = W * OV;
     const int table_bytes = table_rows * ROW * (int) sizeof(float2);
@@ -365,11 +366,16 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     }
     __syncthreads();
     float S_scale = 1.0f;
-    if (F16) {
+    if (F16 && TG) {
+        // table in HBM: already split by pad_table_kernel, with S from the same maximum
+        const unsigned m = *tab_max;
+        const int e = (int) (m >> 23) - 127;
+        S_scale = m ? __uint_as_float((unsigned) (13 - e + 127) << 23) : 1.0f;
+    } else if (F16) {
         // largest |component| of the table -> S, then every tap is split in place
         unsigned *s_tabmax = reinterpret_cast<unsigned *>(rec_base);   // (staging area, not yet in use)
         const unsigned *words = reinterpret_cast<const unsigned *>(smem);
-        const int nwords = table_bytes / 4;
+        const int nwords = table_bytes * (TWO ? 2 : 1) / 4;
         unsigned m = 0;
         for (int i = threadIdx.x; i < nwords; i += NW * 64)
             m = max(m, words[i] & 0x7fffffffu);
@@ -769,15 +775,39 @@ constexpr int waves_per_block()
 
 // Zero-padded copy of taps [tap0, tap0 + Kp) of every table row: [rows][ROW] float2 (ROW = 64:
 // the 32 taps twice).
-template <int ROW>
+// F16: taps scaled by S (from the largest |component| of the whole table, *tab_max) and split
+// into fp16 hi/lo pairs, as the kernel does in LDS for tables that live there.
+template <int ROW, bool F16 = false>
 __global__ __launch_bounds__(256) void pad_table_kernel(
-    const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out)
+    const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out,
+    const unsigned *__restrict__ tab_max = nullptr)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * ROW)
         return;
     const int row = idx / ROW, t = idx & 31;
-    out[idx] = t < Kp ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
+    float2 v = t < Kp ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
+    if (F16) {
+        const unsigned m = *tab_max;
+        const int e = (int) (m >> 23) - 127;
+        const float S = m ? __uint_as_float((unsigned) (13 - e + 127) << 23) : 1.0f;
+        v = make_float2(__uint_as_float(split_f16(v.x * S)), __uint_as_float(split_f16(v.y * S)));
+    }
+    out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void table_max_kernel(const float *__restrict__ kern, int64_t n,
+                                                         unsigned *__restrict__ out)
+{
+    unsigned m = 0;
+    for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n;
+         i += (int64_t) gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(kern[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        m = max(m, (unsigned) __shfl_xor((int) m, off, WAVE));
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(out, m);
 }
 
 size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
@@ -793,19 +823,28 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
            int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
-           unsigned char *padded = nullptr)
+           unsigned char *padded = nullptr, size_t tab_max_offset = 0)
 {
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
     const size_t lds = TG ? lds_bytes(P, NW, 0, 0, ROW) : lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
+    unsigned *tab_max = nullptr;
     if (TG) {
         // the padded table(s) of this launch: row taps first, column taps behind them
         const int rows = W * OV;
         float2 *out = reinterpret_cast<float2 *>(padded);
-        pad_table_kernel<ROW><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
-            kern, rows, ts.K, ts.tv0, ts.Kv, out);
+        if (F16) {
+            // (the last 256 bytes of the workspace hold the table maximum)
+            tab_max = reinterpret_cast<unsigned *>(padded + tab_max_offset);
+            KIMG_HIP(hipMemsetAsync(tab_max, 0, sizeof(unsigned), stream));
+            const int64_t n = (int64_t) rows * ts.K * 2;
+            table_max_kernel<<<kimg_divup(n, 256 * 8), 256, 0, stream>>>(
+                reinterpret_cast<const float *>(kern), n, tab_max);
+        }
+        pad_table_kernel<ROW, F16><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
+            kern, rows, ts.K, ts.tv0, ts.Kv, out, tab_max);
         if (TWO)
-            pad_table_kernel<ROW><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
-                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * ROW);
+            pad_table_kernel<ROW, F16><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
+                kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * ROW, tab_max);
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -834,7 +873,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
     grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded);
+        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded, tab_max);
     return kimg_launch_status();
 }
 
@@ -878,7 +917,7 @@ size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int k
     const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
     if (fits && kernel_width <= WIN && !getenv("KIMG_GRID_TABLE"))
         return 0;
-    return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
+    return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
 
 int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
@@ -924,9 +963,18 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                 ts.tu0 = kb * Kh;
                 ts.Ku = kb ? K - Kh : Kh;
                 int rc;
-#define LAUNCH(PP, ROWV, NWV, TWOV) rc = launch<PP, ROWV, NWV, TWOV>(g, grid_row_stride, \
-        grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, \
-        w_planes, oversample, ts, P, stream)
+                // GO(P, ROW, NW, TWO, TG): the fp16 hi/lo form (two visibilities per matrix
+                // instruction) unless KIMG_GRID_F16=0 asks for the exact-fp32 instruction
+#define GO(PP, ROWV, NWV, TWOV, TGV) do { \
+        if (f16) rc = launch<PP, ROWV, NWV, TWOV, TGV, true>(g, grid_row_stride, grid_pol_stride, \
+            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
+            oversample, ts, P, stream, padded, tab_max_offset); \
+        else rc = launch<PP, ROWV, NWV, TWOV, TGV, false>(g, grid_row_stride, grid_pol_stride, \
+            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
+            oversample, ts, P, stream, padded, tab_max_offset); } while (0)
+                const char *fenv = getenv("KIMG_GRID_F16");
+                const bool f16 = !(fenv && fenv[0] == '0');
+                const size_t tab_max_offset = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
                 // Diagonal blocks of a wide kernel take row and column taps from the same half of
                 // the table: one table, which fits LDS whenever a narrow kernel's would.
                 const bool two = wide && jb != kb;
@@ -938,61 +986,39 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                     // two tables: doubled rows in HBM, 12-wave blocks (P = 1) as for the LDS form
                     if (!in_lds) {
                         if (pn == 1)
-                            rc = launch<1, 64, 12, true, true>(g, grid_row_stride, grid_pol_stride,
-                                grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
-                                kern, w_planes, oversample, ts, P, stream, padded);
+                            GO(1, 64, 12, true, true);
                         else
-                            rc = launch<2, 64, 8, true, true>(g, grid_row_stride, grid_pol_stride,
-                                grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
-                                kern, w_planes, oversample, ts, P, stream, padded);
+                            GO(2, 64, 8, true, true);
                     } else if (pn == 1) {
                         if (lds_bytes(1, 12, w_planes, oversample, 32, 2) <= LDS_LIMIT && nw_env != 8)
-                            LAUNCH(1, 32, 12, true);
+                            GO(1, 32, 12, true, false);
                         else
-                            LAUNCH(1, 32, 8, true);
+                            GO(1, 32, 8, true, false);
                     } else {
-                        LAUNCH(2, 32, 8, true);
+                        GO(2, 32, 8, true, false);
                     }
                 } else if (!single_in_lds) {
-                    if (pn == 1 && table_env != 32) {
-                        // doubled rows (no wrap arithmetic): 5 % faster than single rows
-                        rc = launch<1, 64, 12, false, true>(g, grid_row_stride, grid_pol_stride,
-                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
-                            kern, w_planes, oversample, ts, P, stream, padded);
-                    } else if (pn == 1) {
-                        rc = launch<1, 32, 12, false, true>(g, grid_row_stride, grid_pol_stride,
-                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
-                            kern, w_planes, oversample, ts, P, stream, padded);
-                    } else {
-                        rc = launch<2, 64, 8, false, true>(g, grid_row_stride, grid_pol_stride,
-                            grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis,
-                            kern, w_planes, oversample, ts, P, stream, padded);
-                    }
+                    if (pn == 1 && table_env != 32)
+                        GO(1, 64, 12, false, true);     // doubled rows: 5 % faster than single rows
+                    else if (pn == 1)
+                        GO(1, 32, 12, false, true);
+                    else
+                        GO(2, 64, 8, false, true);
+                } else if (pn == 1) {
+                    // 12-wave blocks, one per CU (LDS-bound), when the doubled table leaves room
+                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
+                        GO(1, 64, 12, false, false);
+                    else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                        GO(1, 64, 8, false, false);
+                    else
+                        GO(1, 32, 8, false, false);
                 } else {
-                    // one table in LDS: the fp16 hi/lo form (two visibilities per matrix
-                    // instruction) unless KIMG_GRID_F16=0 asks for the exact-fp32 instruction
-                    const char *fenv = getenv("KIMG_GRID_F16");
-                    const bool f16 = !(fenv && fenv[0] == '0');
-#define LAUNCH1(PP, ROWV, NWV) do { if (f16) rc = launch<PP, ROWV, NWV, false, false, true>(g, \
-        grid_row_stride, grid_pol_stride, grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, \
-        num_vis, kern, w_planes, oversample, ts, P, stream); else LAUNCH(PP, ROWV, NWV, false); } while (0)
-                    if (pn == 1) {
-                        // 12-wave blocks, one per CU (LDS-bound), when the doubled table leaves room
-                        if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
-                            LAUNCH1(1, 64, 12);
-                        else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                            LAUNCH1(1, 64, 8);
-                        else
-                            LAUNCH1(1, 32, 8);
-                    } else {
-                        if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
-                            LAUNCH1(2, 64, 8);
-                        else
-                            LAUNCH1(2, 32, 8);
-                    }
-#undef LAUNCH1
+                    if (lds_bytes(2, 8, w_planes, oversample, 64) <= LDS_LIMIT)
+                        GO(2, 64, 8, false, false);
+                    else
+                        GO(2, 32, 8, false, false);
                 }
-#undef LAUNCH
+#undef GO
                 if (rc)
                     return rc;
             }
