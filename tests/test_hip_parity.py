@@ -1348,16 +1348,18 @@ def test_noise_est_device_selection(H, W, P, border):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('P,K,W', [(1, 28, 32), (2, 28, 32), (1, 28, 160), (1, 45, 16), (4, 60, 96)])
 @pytest.mark.parametrize('pattern', ['1e-20', '1e-6', '1', '1e6', '1e20', 'jump_up', 'jump_down',
                                      'alternate', 'zeros', 'one_in_zeros'])
-def test_gridder_f16_form_ranges(pattern):
+def test_gridder_f16_form_ranges(pattern, P, K, W):
     """The fp16 hi/lo form of the window gridder (two visibilities per matrix instruction) keeps its
     operands in fp16 range with power-of-two scales chosen on the fly: table scale from the largest
     tap, sample scale per wave, re-chosen (after a flush) when a larger sample arrives.  Whatever
     the magnitudes -- tiny, huge, jumping by 10^12 either way, mixed, mostly zero -- the result
-    stays within the 1e-5 gate of the exact-fp32 form and of the oracle."""
+    stays within the 1e-5 gate of the exact-fp32 form and of the oracle.  (P, K, W) pick the forms:
+    table in LDS, two polarizations per launch, table in HBM, 2 x 2 tap blocks of a wide kernel.)"""
     import os
-    c = gi.make_config(256, 0.0001, 0.01, 1, 28, 32, grid_cover=180, n_vis=1200)
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1200)
     t = gi.grid_track(c)
     n = len(t['uv'])
     rs = np.random.RandomState(7)
@@ -1383,7 +1385,7 @@ def test_gridder_f16_form_ranges(pattern):
     def run(flag):
         os.environ['KIMG_GRID_F16'] = flag
         try:
-            fn, q = _gridder(c, 'mfma')
+            fn, q = _gridder(c, 'mfma', max_vis=2048)
             return _run_gridder(fn, q, t), fn.convolve_kernel.data
         finally:
             os.environ.pop('KIMG_GRID_F16', None)
@@ -1395,6 +1397,8 @@ def test_gridder_f16_form_ranges(pattern):
         assert np.abs(split).max() == 0
         return
     assert np.abs(split - exact).max() <= 2e-6 * peak
+    if pattern not in ('1', 'jump_up', 'alternate'):
+        return              # (the oracle comparison of one pattern per kind is enough)
     want = np.zeros(exact.shape, np.complex64)
     wg = np.zeros(exact.shape, np.float32)
     gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
