@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2516.6     # same table: BF16/F16 dense, v_mfma_f32_32x32x16_f16
 HBM_PEAK_GBS = 8000.0
 
 
@@ -191,6 +192,23 @@ def main():
         # (tests/imager_bench.py:204-208), N K^2 P / t
         'GGAPS': round(n_vis * K * K * P / (kern_ms * 1e-3) / 1e9, 1),
     }
+    # Which matrix instruction carried the work.  The gridder's default form splits every fp32
+    # operand into an fp16 hi/lo pair and puts two visibilities into one v_mfma_f32_32x32x16_f16
+    # (fp32 accumulation, results within 2e-6 of the exact form); KIMG_GRID_F16=0 selects the exact
+    # v_mfma_f32_32x32x2_f32.  `achieved` / `peak` / `frac` stay what they were -- algorithmic fp32
+    # work against the fp32 matrix peak, i.e. against what the exact instruction could ever reach --
+    # and `pipe_*` give the executed flops against the peak of the pipe actually used.
+    f16_form = args.variant != 'generic' and K <= 64 and os.environ.get('KIMG_GRID_F16', '1') != '0'
+    blocks = 1 if K <= 32 else 4                 # 2 x 2 tap blocks for wide kernels
+    executed_per_vis = blocks * P * (2 * 32 * 32 * 16 * 2 / 2 if f16_form else 2 * 32 * 32 * 2 * 2)
+    pipe_peak = F16_MFMA_PEAK_TFLOPS if f16_form else FP32_MFMA_PEAK_TFLOPS
+    executed_tflops = executed_per_vis * n_vis / (kern_ms * 1e-3) / 1e12
+    roofline.update({
+        'form': ('fp16 hi/lo pairs, 2 visibilities per v_mfma_f32_32x32x16_f16' if f16_form
+                 else 'v_mfma_f32_32x32x2_f32' if args.variant != 'generic' else 'per-tap atomics'),
+        'pipe_peak': pipe_peak, 'pipe_executed': round(executed_tflops, 1),
+        'pipe_frac': round(executed_tflops / pipe_peak, 4),
+    })
     traffic_file = os.path.join(ROOT, 'profiles', 'gridder_traffic.json')
     if os.path.exists(traffic_file):
         try:
@@ -202,7 +220,9 @@ def main():
         'metric': 'Mvis/s gridded (4096^2 grid, 32 W-planes)', 'value': round(mvis, 2),
         'unit': 'Mvis/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None,
+        'dtype': 'f32 (operands as fp16 hi/lo pairs, fp32 accumulation)' if f16_form else 'f32',
+        'data': 'synthetic',
         'config': {'workload': 'C2: 1 channel per GPU, {0}^2 image, {1} W-planes, {2} vis, '
                                'K={3}, P={4}, vis_block={5}'.format(G, W, n_vis, K, P, vb),
                    'grid_size': Gg, 'channels': world, 'parallelism': 'channel-sharded',
