@@ -249,3 +249,22 @@ def test_full_size_noise_estimate_and_clean_rate_invariants(G, P):
                                 - resid.sum(axis=(1, 2), dtype=np.float64)),
                                total * psf[0, G // 2 - 32:G // 2 + 33, G // 2 - 32:G // 2 + 33].sum(dtype=np.float64),
                                rtol=1e-3)
+
+
+def test_c2_f16_form_vs_exact_and_repeatable():
+    """Config 2 geometry, 2.2 M visibilities: the default fp16 hi/lo form of the gridder against the
+    exact-fp32 form (KIMG_GRID_F16=0) and against itself (the only run-to-run difference allowed is the
+    order of the float atomics)."""
+    ctx, q, obs, fn, wg = _setup(4096, 2_200_000, 32, 1)
+
+    def run(flag):
+        os.environ['KIMG_GRID_F16'] = flag
+        try:
+            return _grid_all(ctx, q, obs, fn).clone()
+        finally:
+            os.environ.pop('KIMG_GRID_F16', None)
+    exact, split, again = run('0'), run('1'), run('1')
+    peak = float(exact.abs().max())
+    assert float((split - exact).abs().max()) <= 2e-6 * peak
+    assert float((split - again).abs().max()) <= 5e-7 * peak
+    assert int((split != 0).sum()) == int((exact != 0).sum())
