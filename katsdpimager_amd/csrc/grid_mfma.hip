@@ -660,10 +660,15 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 for (int p = 0; p < P; p++)
                     mb = max(mb, max(__float_as_uint(sp[p].x) & 0x7fffffffu,
                                      __float_as_uint(sp[p].y) & 0x7fffffffu));
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
-                    mb = max(mb, (unsigned) __shfl_xor((int) mb, off, WAVE));
-                mb = __builtin_amdgcn_readfirstlane(mb);
+                // wave maximum: DPP butterflies inside the 16-lane rows, then the four rows
+                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0xB1, 0xf, 0xf, true));
+                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x4E, 0xf, 0xf, true));
+                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x141, 0xf, 0xf, true));
+                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x140, 0xf, 0xf, true));
+                mb = max(max((unsigned) __builtin_amdgcn_readlane((int) mb, 0),
+                             (unsigned) __builtin_amdgcn_readlane((int) mb, 16)),
+                         max((unsigned) __builtin_amdgcn_readlane((int) mb, 32),
+                             (unsigned) __builtin_amdgcn_readlane((int) mb, 48)));
                 if (mb != 0 && (T_scale == 0.0f || __uint_as_float(mb) * T_scale > 2.0f)) {
                     if (have && T_scale != 0.0f)
                         flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv,
