@@ -219,11 +219,21 @@ __device__ inline float join_f16(unsigned packed)
     return f16_bits_to_f32(packed & 0xffffu) + f16_bits_to_f32(packed >> 16);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// A complex tap as it is kept in the tables of the fp16 form: (re_hi | im_hi << 16, re_lo | im_lo << 16)
+__device__ inline uint2 split_tap(float re, float im)
+{
+    const unsigned hi = cvt_pk_f16_rtz(re, im);
+    const unsigned lo = cvt_pk_f16_rtz(re - f16_bits_to_f32(hi & 0xffffu), im - f16_bits_to_f32(hi >> 16));
+    return make_uint2(hi, lo);
+}
+
 // Operands of SUBP staged PAIRS of visibilities (this lane's member of each pair)
 template <int P, int SUBP>
 struct pair_ops {
     float4 c[P][SUBP];      // (Re s, Im s, Im s, -Re s) * T
-    uint2 kv[SUBP];         // row tap: (re_hi | re_lo << 16, im_hi | im_lo << 16), times S
+    uint2 kv[SUBP];         // row tap: (re_hi | im_hi << 16, re_lo | im_lo << 16), times S
     uint2 t0[SUBP], t1[SUBP];   // column taps of the two tiles, same format
 };
 
@@ -393,8 +403,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         uint2 *taps = reinterpret_cast<uint2 *>(smem);
         for (int i = threadIdx.x; i < nwords / 2; i += NW * 64) {
             const uint2 t = taps[i];
-            taps[i] = make_uint2(split_f16(__uint_as_float(t.x) * S_scale),
-                                 split_f16(__uint_as_float(t.y) * S_scale));
+            taps[i] = split_tap(__uint_as_float(t.x) * S_scale, __uint_as_float(t.y) * S_scale);
         }
         __syncthreads();
     }
@@ -414,14 +423,13 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int lane_u = ((lane & 31) >> 1) * 8 + (b_take_im ? 4 : 0);    // column tap component
     const int lane_s = h ? 8 : 0;                                       // (Re,Im) or (Im,-Re)
     // fp16 form: which member of a pair this lane serves, the (whole) column tap it reads, and how
-    // its 6 k-slots are cut from (re_hi, re_lo | im_hi, im_lo): even columns (real part) take
-    // (re_hi, re_lo, re_hi, im_hi, im_lo, im_hi), odd ones (-im_hi, -im_lo, -im_hi, re_hi, re_lo, re_hi)
+    // its 6 k-slots come from the tap (re_hi, im_hi | re_lo, im_lo): even columns (real part of the
+    // result) take (re_hi, im_hi, re_lo, im_lo, re_hi, im_hi) as stored, odd ones (-im_hi, re_hi,
+    // -im_lo, re_lo, -im_hi, re_hi); the row operand is (re_hi, im_hi, re_hi, im_hi, re_lo, im_lo)
     const int member = lane >> 5;
     const int lane_u16 = ((lane & 31) >> 1) * 8;
-    const unsigned sel0 = part ? 0x07060504u : 0x03020100u;
-    const unsigned sel1 = part ? 0x01000504u : 0x05040100u;
-    const unsigned sel2 = part ? 0x01000302u : 0x05040706u;
-    const unsigned flip0 = part ? 0x80008000u : 0u, flip1 = part ? 0x00008000u : 0u;
+    const unsigned sel = part ? 0x01000302u : 0x03020100u;      // odd columns swap (re, im)
+    const unsigned flip = part ? 0x00008000u : 0u;              // ... and negate im
     float T_scale = 0.0f;           // sample scale of this wave (0: not chosen yet)
     float out_scale = 1.0f;         // 1 / (S * S * T)
 
@@ -513,25 +521,33 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         }
     };
     // fp16 form: the 6 k-slots of this lane's visibility (row operand) and of its column taps
-    auto row_operand = [&](const float4 &c, float kre, float kim, bool zero) __attribute__((always_inline)) {
-        float are = fmaf(c.x, kre, c.y * kim);          // Re(s conj kv) * S * T
-        float aim = fmaf(c.z, kre, c.w * kim);          // Im(s conj kv) * S * T
+    auto join_tap = [&](const uint2 &tp) __attribute__((always_inline)) {        // -> (re, im) in fp32
+        // (scalar on purpose: with v_pk_fma_f32 / v_pk_add_f32 here the results were not repeatable)
+        v2f r;
+        r.x = f16_bits_to_f32(tp.x & 0xffffu) + f16_bits_to_f32(tp.y & 0xffffu);
+        r.y = f16_bits_to_f32(tp.x >> 16) + f16_bits_to_f32(tp.y >> 16);
+        return r;
+    };
+    auto row_operand = [&](const float4 &c, v2f kv, bool zero) __attribute__((always_inline)) {
+        // (Re, Im)(s conj kv) * S * T = (sx, sy) kv.re + (sy, -sx) kv.im, two lanes of packed math
+        float are = fmaf(c.x, kv.x, c.y * kv.y);
+        float aim = fmaf(c.z, kv.x, c.w * kv.y);
         if (zero)
             are = aim = 0.0f;
         u32x4 A;
-        A[0] = cvt_pk_f16_rtz(are, are);                            // (re_hi, re_hi)
+        A[0] = cvt_pk_f16_rtz(are, aim);                            // (re_hi, im_hi)
         const float re_lo = are - f16_bits_to_f32(A[0] & 0xffffu);
-        A[1] = cvt_pk_f16_rtz(re_lo, aim);                          // (re_lo, im_hi)
-        const float im_lo = aim - f16_bits_to_f32(A[1] >> 16);
-        A[2] = cvt_pk_f16_rtz(aim, im_lo);                          // (im_hi, im_lo)
+        const float im_lo = aim - f16_bits_to_f32(A[0] >> 16);
+        A[1] = A[0];
+        A[2] = cvt_pk_f16_rtz(re_lo, im_lo);                        // (re_lo, im_lo)
         A[3] = 0;
         return A;
     };
     auto col_operand = [&](const uint2 &tp) __attribute__((always_inline)) {
         u32x4 B;
-        B[0] = __builtin_amdgcn_perm(tp.y, tp.x, sel0) ^ flip0;
-        B[1] = __builtin_amdgcn_perm(tp.y, tp.x, sel1) ^ flip1;
-        B[2] = __builtin_amdgcn_perm(tp.y, tp.x, sel2);
+        B[0] = __builtin_amdgcn_perm(tp.x, tp.x, sel) ^ flip;
+        B[1] = __builtin_amdgcn_perm(tp.y, tp.y, sel) ^ flip;
+        B[2] = B[0];
         B[3] = 0;
         return B;
     };
@@ -540,10 +556,10 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             u32x4 A[P][SUB / 2], B0[SUB / 2], B1[SUB / 2];
 #pragma unroll
             for (int t = 0; t < SUB / 2; t++) {
-                const float kre = join_f16(o.kv[t].x), kim = join_f16(o.kv[t].y);
+                const v2f kv = join_tap(o.kv[t]);
 #pragma unroll
                 for (int p = 0; p < P; p++)
-                    A[p][t] = row_operand(o.c[p][t], kre, kim, false);
+                    A[p][t] = row_operand(o.c[p][t], kv, false);
                 B0[t] = col_operand(o.t0[t]);
                 B1[t] = col_operand(o.t1[t]);
             }
@@ -605,11 +621,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 const uint2 tp0 = *reinterpret_cast<const uint2 *>(tbytes + au16);
                 const uint2 tp1 = *reinterpret_cast<const uint2 *>(ROW == 64 ? tbytes + au16 + 128
                                                                            : tbytes + (au16 ^ 128u));
-                const float kre = join_f16(kvp.x), kim = join_f16(kvp.y);
+                const v2f kvj = join_tap(kvp);
                 const u32x4 B0 = col_operand(tp0), B1 = col_operand(tp1);
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    const u32x4 A = row_operand(samples[p * 64 + idx], kre, kim, member != 0);
+                    const u32x4 A = row_operand(samples[p * 64 + idx], kvj, member != 0);
                     acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                         __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B0), acc.t0[p], 0, 0, 0);
                     acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -796,7 +812,8 @@ __global__ __launch_bounds__(256) void pad_table_kernel(
         const unsigned m = *tab_max;
         const int e = (int) (m >> 23) - 127;
         const float S = m ? __uint_as_float((unsigned) (13 - e + 127) << 23) : 1.0f;
-        v = make_float2(__uint_as_float(split_f16(v.x * S)), __uint_as_float(split_f16(v.y * S)));
+        const uint2 t = split_tap(v.x * S, v.y * S);
+        v = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
     }
     out[idx] = v;
 }
