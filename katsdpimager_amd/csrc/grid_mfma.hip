@@ -676,6 +676,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 for (int p = 0; p < P; p++)
                     mb = max(mb, max(__float_as_uint(sp[p].x) & 0x7fffffffu,
                                      __float_as_uint(sp[p].y) & 0x7fffffffu));
+                if (mb >= 0x7f800000u)
+                    mb = 0;         // NaN / Inf samples poison their own footprint, not the scale
                 // wave maximum: DPP butterflies inside the 16-lane rows, then the four rows
                 mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0xB1, 0xf, 0xf, true));
                 mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x4E, 0xf, 0xf, true));

@@ -1350,7 +1350,7 @@ def test_noise_est_device_selection(H, W, P, border):
 @pytest.mark.gpu
 @pytest.mark.parametrize('P,K,W', [(1, 28, 32), (2, 28, 32), (1, 28, 160), (1, 45, 16), (4, 60, 96)])
 @pytest.mark.parametrize('pattern', ['1e-20', '1e-6', '1', '1e6', '1e20', 'jump_up', 'jump_down',
-                                     'alternate', 'zeros', 'one_in_zeros'])
+                                     'alternate', 'zeros', 'one_in_zeros', 'nan'])
 def test_gridder_f16_form_ranges(pattern, P, K, W):
     """The fp16 hi/lo form of the window gridder (two visibilities per matrix instruction) keeps its
     operands in fp16 range with power-of-two scales chosen on the fly: table scale from the largest
@@ -1377,10 +1377,14 @@ def test_gridder_f16_form_ranges(pattern, P, K, W):
     elif pattern == 'one_in_zeros':
         scale[:] = 0.0
         scale[777] = 3.0e4
-    else:
+    elif pattern != 'nan':
         scale[:] = float(pattern)
     t = dict(t)
     t['vis'] = (t['vis'] * scale[:, None]).astype(np.complex64)
+    if pattern == 'nan':
+        # non-finite samples spoil their own footprint only, in both forms
+        t['vis'][100, 0] = np.nan
+        t['vis'][700, -1] = complex(np.inf, 1.0)
 
     def run(flag):
         os.environ['KIMG_GRID_F16'] = flag
@@ -1391,6 +1395,13 @@ def test_gridder_f16_form_ranges(pattern, P, K, W):
             os.environ.pop('KIMG_GRID_F16', None)
     exact, kernel = run('0')
     split, _ = run('1')
+    if pattern == 'nan':
+        bad = ~np.isfinite(exact)
+        assert 0 < bad.sum() < 0.2 * exact.size
+        np.testing.assert_array_equal(~np.isfinite(split), bad)
+        peak = np.abs(exact[~bad]).max()
+        assert np.abs(split[~bad] - exact[~bad]).max() <= 2e-6 * peak
+        return
     assert np.all(np.isfinite(split))
     peak = np.abs(exact).max()
     if peak == 0:
