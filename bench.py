@@ -273,6 +273,24 @@ def main():
         for _ in range(3):
             grid_two_streams()
         sec['grid_two_streams_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+        # the same per-chunk launches as `value`, with the exact v_mfma_f32_32x32x2_f32 instruction
+        # instead of the default fp16 hi/lo form (the library reads the variable per call)
+        if f16_form:
+            def grid_chunks_once():
+                for uv_c, wp_c, vis_c, n in chunks:
+                    fn.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+                    fn.num_vis = n
+                    fn._run()
+                q.finish()
+            os.environ['KIMG_GRID_F16'] = '0'
+            try:
+                grid_chunks_once()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    grid_chunks_once()
+                sec['grid_exact_fp32_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
+            finally:
+                os.environ.pop('KIMG_GRID_F16', None)
         del fn_b
         # PCIe-inclusive: the reference-style host path, every chunk copied from host memory
         # (uv, w_plane, vis: 18 B per visibility at P=1) before it is gridded
