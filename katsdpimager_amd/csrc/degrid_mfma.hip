@@ -85,7 +85,40 @@ struct tap_split {
 // taps (pad_rows_kernel, rebuilt per call in the caller's workspace).  Each wave copies the 2 x 16
 // rows its current 16 visibilities need into a private LDS cache (coalesced 16-byte loads: a row
 // is 256 bytes) and then works exactly like the single-row LDS form (TAPS must be 32).
-template <int P, int NW, int TAPS, bool TWO, bool TG = false>
+// ---- fp16 hi/lo form (F16 = true; one polarization, table in LDS) ---------------------------
+// As in the gridder (grid_mfma.hip): fp32 operands travel as fp16 hi/lo pairs, a complex product
+// needs 6 of the 16 k-slots of v_mfma_f32_32x32x16_f16, so one 8-pass instruction contracts TWO
+// window rows (lanes 0-31: row 2i, lanes 32-63: row 2i + 1) where the exact 16-pass instruction
+// takes one.  The window is split when it is (re)loaded, scaled by a power of two S_g chosen from
+// its largest value; the row taps are split on the fly (the table stays fp32: step 2 needs it so),
+// scaled by S from the largest tap; the sums are multiplied by 1 / (S_g S) at the end.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (round to nearest: v_cvt_pk_f16_f32; with truncation the errors of the 10^7 products of an
+// inner product all point the same way and the adjointness check sees them)
+__device__ inline unsigned dg_cvt_pk_f16(float lo, float hi)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const v2f x = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, h2));
+}
+
+__device__ inline float dg_f16_to_f32(unsigned bits16)
+{
+    return (float) __builtin_bit_cast(_Float16, (unsigned short) bits16);
+}
+
+// 2^(13 - e) for a largest magnitude with bit pattern m in [2^e, 2^(e+1)); 1 for m == 0
+__device__ inline float dg_scale_for(unsigned m)
+{
+    int e = (int) (m >> 23) - 127;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return (m && m < 0x7f800000u) ? __uint_as_float((unsigned) (13 - e + 127) << 23) : 1.0f;
+}
+
+template <int P, int NW, int TAPS, bool TWO, bool TG = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
@@ -94,6 +127,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     int p_total, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || TAPS == 32 || TG, "two tables only fit LDS with single rows");
+    static_assert(!F16 || (P == 1 && !TG), "fp16 form: one polarization, table in LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = TG ? padded : smem;
@@ -146,6 +180,27 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             stage_table(smem + table_bytes, ts.tu0, ts.Ku);
     }
     __syncthreads();
+    float S_kv = 1.0f;
+    if (F16) {
+        // largest |component| of the row-tap table (block reduction; the staging area is still free)
+        unsigned *s_max = reinterpret_cast<unsigned *>(rec_base);
+        // (taps 0..31 of every row: the padding tap of the 65-tap rows is never written)
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < table_rows * 32; i += NW * 64) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(smem + (size_t) (i >> 5) * ROW_BYTES + (i & 31) * 8);
+            m = max(m, max(t.x & 0x7fffffffu, t.y & 0x7fffffffu));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            m = max(m, (unsigned) __shfl_xor((int) m, off, WAVE));
+        if (lane == 0)
+            s_max[wib] = m;
+        __syncthreads();
+        for (int w = 0; w < NW; w++)
+            m = max(m, s_max[w]);
+        S_kv = dg_scale_for(m);
+        __syncthreads();
+    }
 
     const int64_t block_start = (int64_t) blockIdx.x * vis_per_block;
     int64_t block_end = block_start + vis_per_block;
@@ -179,6 +234,13 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
 #pragma unroll
         for (int y = 0; y < WIN; y++)
             win.g[p][y] = 0.0f;
+    // fp16 form: this lane's 16 rows (2 i + (lane >> 5)) of its column as complex values, the
+    // same split into the row-pair operands of the matrix instruction, and the scales
+    unsigned a_hi[F16 ? WIN / 2 : 1], a_lo[F16 ? WIN / 2 : 1];     // (re_hi, im_hi), (re_lo, im_lo)
+    float S_g = 1.0f, inv_scale = 1.0f;
+    const int hrow = lane >> 5;
+    const unsigned sel = part ? 0x01000302u : 0x03020100u;      // odd outputs swap (re, im)
+    const unsigned flip = part ? 0u : 0x80000000u;              // even outputs negate im
     bool have = false;
     int Wu = 0, Wv = 0;
 
@@ -189,6 +251,44 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
         const int gx = nWu + ((x_lane - nWu) & 31);
         const bool col_changed = (col_mask >> x_lane) & 1u;
         const bool x_ok = (unsigned) gx < (unsigned) Gg;
+        if constexpr (F16) {
+            // The whole window is (re)read at every move: the split needs one scale for all of it,
+            // and keeping the fp32 values as well would not fit the register budget.  Moves are rare.
+            float2 g2[WIN / 2];
+#pragma unroll
+            for (int i = 0; i < WIN / 2; i++) {
+                const int y = 2 * i + hrow;
+                const int gy = nWv + ((y - nWv) & 31);
+                const bool y_ok = (unsigned) gy < (unsigned) Gg;
+                const float2 *cell = reinterpret_cast<const float2 *>(grid)
+                                     + ((int64_t) gy * row_stride + gx);
+                g2[i] = (x_ok && y_ok) ? *cell : make_float2(0.0f, 0.0f);
+            }
+            // scale from the largest magnitude in the window, then split every row pair
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < WIN / 2; i++)
+                m = max(m, max(__float_as_uint(g2[i].x) & 0x7fffffffu,
+                               __float_as_uint(g2[i].y) & 0x7fffffffu));
+            m = (unsigned) row16_max((int) (m >= 0x7f800000u ? 0u : m));
+            m = max(max((unsigned) __builtin_amdgcn_readlane((int) m, 0),
+                        (unsigned) __builtin_amdgcn_readlane((int) m, 16)),
+                    max((unsigned) __builtin_amdgcn_readlane((int) m, 32),
+                        (unsigned) __builtin_amdgcn_readlane((int) m, 48)));
+            S_g = dg_scale_for(m);
+            inv_scale = 1.0f / (S_g * S_kv);
+#pragma unroll
+            for (int i = 0; i < WIN / 2; i++) {
+                const float re = g2[i].x * S_g, im = g2[i].y * S_g;
+                a_hi[i] = dg_cvt_pk_f16(re, im);
+                a_lo[i] = dg_cvt_pk_f16(re - dg_f16_to_f32(a_hi[i] & 0xffffu),
+                                        im - dg_f16_to_f32(a_hi[i] >> 16));
+            }
+            Wu = nWu;
+            Wv = nWv;
+            have = true;
+            return;
+        }
 #pragma unroll
         for (int y = 0; y < WIN; y++) {
             const bool row_changed = (row_mask >> y) & 1u;          // uniform
@@ -329,6 +429,35 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                                              : tbytes + (TAPS == 64 ? rec.x : (rec.x >> 16) * ROW_BYTES)
                                                    + b_comp;
                 const int off_v = rec.x & 0xff;
+                if constexpr (F16) {
+                    // two window rows per instruction; this lane's row is 2 i + hrow, its tap is
+                    // split here: (kre_hi, -kim_hi, ...) for real outputs, (kim_hi, kre_hi, ...) else
+                    const unsigned char *pv16 = pv - b_comp;
+#pragma unroll
+                    for (int i = 0; i < WIN / 2; i++) {
+                        const int y = 2 * i + hrow;
+                        const float2 kv = *reinterpret_cast<const float2 *>(
+                            TAPS == 64 ? pv16 + 8 * y : pv16 + ((off_v + 8 * y) & 0xf8));
+                        const float kre = kv.x * S_kv, kim = kv.y * S_kv;
+                        const unsigned hi = dg_cvt_pk_f16(kre, kim);
+                        const unsigned lo = dg_cvt_pk_f16(kre - dg_f16_to_f32(hi & 0xffffu),
+                                                          kim - dg_f16_to_f32(hi >> 16));
+                        u32x4 B;
+                        B[0] = __builtin_amdgcn_perm(hi, hi, sel) ^ flip;
+                        B[1] = __builtin_amdgcn_perm(lo, lo, sel) ^ flip;
+                        B[2] = B[0];
+                        B[3] = 0;
+                        u32x4 A;
+                        A[0] = a_hi[i];
+                        A[1] = a_hi[i];
+                        A[2] = a_lo[i];
+                        A[3] = 0;
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[0], 0, 0, 0);
+                        if (i % 4 == 3)
+                            __builtin_amdgcn_sched_barrier(0);      // bounds the operands in flight
+                    }
+                } else {
 #pragma unroll
                 for (int y = 0; y < WIN; y++) {
                     const float bv = *reinterpret_cast<const float *>(
@@ -336,6 +465,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
 #pragma unroll
                     for (int p = 0; p < P; p++)
                         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
+                }
                 }
                 // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
                 const unsigned char *pu = TG ? cache_u + b_lane * CACHE_ROW
@@ -369,7 +499,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                     const int64_t r = b0 + first + b_lane;
 #pragma unroll
                     for (int p = 0; p < P; p++)
-                        vis[(r * p_total + p) * 2 + part] = old_vis[p] - old_wgt[p] * sum[p];   // grid.py:1154
+                        vis[(r * p_total + p) * 2 + part] =
+                            old_vis[p] - old_wgt[p] * (F16 ? sum[p] * inv_scale : sum[p]);         // grid.py:1154
                 }
             }
         }
@@ -408,7 +539,7 @@ size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int P, int NW, int TAPS, bool TWO, bool TG = false>
+template <int P, int NW, int TAPS, bool TWO, bool TG = false, bool F16 = false>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
            const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
@@ -427,7 +558,7 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     }
     static bool attr_set = false;
     if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO, TG>),
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
@@ -437,7 +568,7 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
-    degrid_mfma_kernel<P, NW, TAPS, TWO, TG><<<blocks, NW * 64, lds, stream>>>(
+    degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, ts,
         vis_per_block, p_total, padded);
     return kimg_launch_status();
@@ -516,7 +647,19 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                 } else if (!single_in_lds) {
                     if (pn == 1) LAUNCH_TG(1, 12, 32, false); else LAUNCH_TG(2, 8, 32, false);
                 } else if (pn == 1) {
-                    if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
+                    // fp16 hi/lo form (two window rows per matrix instruction) unless
+                    // KIMG_DEGRID_F16=0 asks for the exact-fp32 instruction
+                    const char *fenv = getenv("KIMG_DEGRID_F16");
+                    if (!(fenv && fenv[0] == '0')) {
+                        if (doubled)
+                            rc = launch<1, 12, 64, false, false, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,
+                                (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
+                        else
+                            rc = launch<1, 12, 32, false, false, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,
+                                (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
+                    } else if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
                 } else {
                     if (doubled) LAUNCH(2, 8, 64, false); else LAUNCH(2, 8, 32, false);
                 }
