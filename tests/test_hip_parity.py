@@ -1415,3 +1415,61 @@ def test_gridder_f16_form_ranges(pattern, P, K, W):
     gi.middle(wg, t['weights_grid'].shape)[:] = t['weights_grid']
     orc.grid(kernel, want, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
     assert relerr(split, want) < GRID_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('W', [32, 64])
+@pytest.mark.parametrize('pattern', ['1e-20', '1', '1e20', 'spike', 'smooth_ramp', 'zeros', 'nan'])
+def test_degridder_f16_form_ranges(pattern, W):
+    """The fp16 hi/lo form of the window degridder (two window rows per matrix instruction) scales
+    every window it loads by a power of two chosen from the window's largest value, and the taps
+    by one chosen from the table.  Model grids of any magnitude, with a 10^9 spike next to ordinary
+    values, with a steep ramp, all zero, or with NaN cells stay within 2e-6 (of the largest
+    prediction) of the exact-fp32 form; NaN reaches the same visibilities in both."""
+    import os
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(512, 0.0001, 0.01, 1, 28, W, grid_cover=300, n_vis=1500)
+    t = gi.grid_track(c)
+    ip, gp, ap = make_params(c)
+    n = c['n_vis']
+    rs = np.random.RandomState(11)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn.ensure_all_bound()
+    shape = fn.buffer('grid').shape
+    model = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    if pattern == 'spike':
+        # (on the track, so that windows really hold the spike next to ordinary values)
+        model[0, int(t['uv'][n // 2, 1]) + shape[1] // 2 + 3, int(t['uv'][n // 2, 0]) + shape[2] // 2 - 5] = 1e9
+    elif pattern == 'smooth_ramp':
+        model *= (10.0 ** np.linspace(-12, 12, shape[2])).astype(np.float32)[None, None, :]
+    elif pattern == 'zeros':
+        model[:] = 0
+    elif pattern == 'nan':
+        model[0, shape[1] // 2, shape[2] // 2] = np.nan
+    else:
+        model *= np.float32(float(pattern))
+    vis0 = (rs.standard_normal((n, 1)) + 1j * rs.standard_normal((n, 1))).astype(np.complex64)
+    weights = rs.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+
+    def run(flag):
+        os.environ['KIMG_DEGRID_F16'] = flag
+        try:
+            fn.buffer('grid').set(q, model)
+            fn.num_vis = n
+            fn.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+            fn.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+            fn.buffer('vis').set_region(q, vis0, np.s_[:n], np.s_[:])
+            fn.buffer('weights').set_region(q, weights, np.s_[:n], np.s_[:])
+            fn()
+            return fn.buffer('vis').get(q)[:n]
+        finally:
+            os.environ.pop('KIMG_DEGRID_F16', None)
+    exact, split = run('0'), run('1')
+    bad = ~np.isfinite(exact)
+    np.testing.assert_array_equal(~np.isfinite(split), bad)
+    assert (pattern == 'nan') == bool(bad.any())
+    pred = np.abs(exact[~bad] - vis0[~bad])
+    scale = max(float(pred.max()), 1e-30) if pred.size else 1.0
+    # (plus one rounding of the stored residual, which is of the size of the visibility)
+    assert np.abs(split[~bad] - exact[~bad]).max() <= 2e-6 * scale + 2.4e-7 * np.abs(exact[~bad]).max()
