@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     int p_total, const unsigned char *__restrict__ padded)
 {
     static_assert(!TWO || TAPS == 32 || TG, "two tables only fit LDS with single rows");
-    static_assert(!F16 || (P == 1 && !TG), "fp16 form: one polarization, table in LDS");
+    static_assert(!F16 || !TG, "fp16 form: table in LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = TG ? padded : smem;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             win.g[p][y] = 0.0f;
     // fp16 form: this lane's 16 rows (2 i + (lane >> 5)) of its column as complex values, the
     // same split into the row-pair operands of the matrix instruction, and the scales
-    unsigned a_hi[F16 ? WIN / 2 : 1], a_lo[F16 ? WIN / 2 : 1];     // (re_hi, im_hi), (re_lo, im_lo)
+    unsigned a_hi[P][F16 ? WIN / 2 : 1], a_lo[P][F16 ? WIN / 2 : 1];   // (re_hi, im_hi), (re_lo, im_lo)
     float S_g = 1.0f, inv_scale = 1.0f;
     const int hrow = lane >> 5;
     const unsigned sel = part ? 0x01000302u : 0x03020100u;      // odd outputs swap (re, im)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
         if constexpr (F16) {
             // The whole window is (re)read at every move: the split needs one scale for all of it,
             // and keeping the fp32 values as well would not fit the register budget.  Moves are rare.
-            float2 g2[WIN / 2];
+            float2 g2[P][WIN / 2];
 #pragma unroll
             for (int i = 0; i < WIN / 2; i++) {
                 const int y = 2 * i + hrow;
@@ -262,14 +262,18 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                 const bool y_ok = (unsigned) gy < (unsigned) Gg;
                 const float2 *cell = reinterpret_cast<const float2 *>(grid)
                                      + ((int64_t) gy * row_stride + gx);
-                g2[i] = (x_ok && y_ok) ? *cell : make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    g2[p][i] = (x_ok && y_ok) ? cell[p * pol_stride] : make_float2(0.0f, 0.0f);
             }
             // scale from the largest magnitude in the window, then split every row pair
             unsigned m = 0;
 #pragma unroll
-            for (int i = 0; i < WIN / 2; i++)
-                m = max(m, max(__float_as_uint(g2[i].x) & 0x7fffffffu,
-                               __float_as_uint(g2[i].y) & 0x7fffffffu));
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int i = 0; i < WIN / 2; i++)
+                    m = max(m, max(__float_as_uint(g2[p][i].x) & 0x7fffffffu,
+                                   __float_as_uint(g2[p][i].y) & 0x7fffffffu));
             m = (unsigned) row16_max((int) (m >= 0x7f800000u ? 0u : m));
             m = max(max((unsigned) __builtin_amdgcn_readlane((int) m, 0),
                         (unsigned) __builtin_amdgcn_readlane((int) m, 16)),
@@ -278,12 +282,14 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             S_g = dg_scale_for(m);
             inv_scale = 1.0f / (S_g * S_kv);
 #pragma unroll
-            for (int i = 0; i < WIN / 2; i++) {
-                const float re = g2[i].x * S_g, im = g2[i].y * S_g;
-                a_hi[i] = dg_cvt_pk_f16(re, im);
-                a_lo[i] = dg_cvt_pk_f16(re - dg_f16_to_f32(a_hi[i] & 0xffffu),
-                                        im - dg_f16_to_f32(a_hi[i] >> 16));
-            }
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int i = 0; i < WIN / 2; i++) {
+                    const float re = g2[p][i].x * S_g, im = g2[p][i].y * S_g;
+                    a_hi[p][i] = dg_cvt_pk_f16(re, im);
+                    a_lo[p][i] = dg_cvt_pk_f16(re - dg_f16_to_f32(a_hi[p][i] & 0xffffu),
+                                               im - dg_f16_to_f32(a_hi[p][i] >> 16));
+                }
             Wu = nWu;
             Wv = nWv;
             have = true;
@@ -447,13 +453,16 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                         B[1] = __builtin_amdgcn_perm(lo, lo, sel) ^ flip;
                         B[2] = B[0];
                         B[3] = 0;
-                        u32x4 A;
-                        A[0] = a_hi[i];
-                        A[1] = a_hi[i];
-                        A[2] = a_lo[i];
-                        A[3] = 0;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[0], 0, 0, 0);
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            u32x4 A;
+                            A[0] = a_hi[p][i];
+                            A[1] = a_hi[p][i];
+                            A[2] = a_lo[p][i];
+                            A[3] = 0;
+                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[p], 0, 0, 0);
+                        }
                         if (i % 4 == 3)
                             __builtin_amdgcn_sched_barrier(0);      // bounds the operands in flight
                     }
@@ -661,7 +670,17 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                                 (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
                     } else if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
                 } else {
-                    if (doubled) LAUNCH(2, 8, 64, false); else LAUNCH(2, 8, 32, false);
+                    const char *fenv = getenv("KIMG_DEGRID_F16");
+                    if (!(fenv && fenv[0] == '0')) {
+                        if (doubled)
+                            rc = launch<2, 8, 64, false, false, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,
+                                (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
+                        else
+                            rc = launch<2, 8, 32, false, false, true>(g, grid_row_stride, grid_pol_stride,
+                                grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,
+                                (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
+                    } else if (doubled) LAUNCH(2, 8, 64, false); else LAUNCH(2, 8, 32, false);
                 }
 #undef LAUNCH
 #undef LAUNCH_TG
