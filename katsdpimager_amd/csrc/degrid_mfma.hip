@@ -124,10 +124,9 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
-    int p_total, const unsigned char *__restrict__ padded)
+    int p_total, const unsigned char *__restrict__ padded, const unsigned *__restrict__ tab_max)
 {
     static_assert(!TWO || TAPS == 32 || TG, "two tables only fit LDS with single rows");
-    static_assert(!F16 || !TG, "fp16 form: table in LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROW_BYTES = row_bytes<TAPS>();
     const unsigned char *tbytes = TG ? padded : smem;
@@ -181,7 +180,9 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     }
     __syncthreads();
     float S_kv = 1.0f;
-    if (F16) {
+    if (F16 && TG) {
+        S_kv = dg_scale_for(*tab_max);          // table in HBM: maximum found by dg_table_max_kernel
+    } else if (F16) {
         // largest |component| of the row-tap table (block reduction; the staging area is still free)
         unsigned *s_max = reinterpret_cast<unsigned *>(rec_base);
         // (taps 0..31 of every row: the padding tap of the 65-tap rows is never written)
@@ -530,6 +531,21 @@ __global__ __launch_bounds__(256) void pad_table_kernel(
     out[idx] = (c < TAPS && t < Kp) ? kern[(int64_t) row * K + tap0 + t] : make_float2(0.0f, 0.0f);
 }
 
+// Largest |component| of the raw table (bit pattern), for the fp16 form with the table in HBM.
+__global__ __launch_bounds__(256) void dg_table_max_kernel(const float *__restrict__ kern, int64_t n,
+                                                            unsigned *__restrict__ out)
+{
+    unsigned m = 0;
+    for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n;
+         i += (int64_t) gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(kern[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        m = max(m, (unsigned) __shfl_xor((int) m, off, WAVE));
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(out, m);
+}
+
 // TG: [rows][32] zero-padded taps (256-byte rows).
 __global__ __launch_bounds__(256) void pad_rows_kernel(
     const float2 *__restrict__ kern, int rows, int K, int tap0, int Kp, float2 *__restrict__ out)
@@ -552,13 +568,22 @@ template <int P, int NW, int TAPS, bool TWO, bool TG = false, bool F16 = false>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
            const float2 *kern, int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
-           unsigned char *padded = nullptr)
+           unsigned char *padded = nullptr, size_t tab_max_offset = 0)
 {
     const size_t lds = TG ? lds_bytes(NW, 0, 0, TAPS) + (size_t) NW * 2 * BATCH * 272
                           : lds_bytes(NW, W, OV, TAPS, TWO ? 2 : 1);
+    unsigned *tab_max = nullptr;
     if (TG) {
         const int rows = W * OV;
         float2 *out = reinterpret_cast<float2 *>(padded);
+        if (F16) {
+            // (the last 256 bytes of the workspace hold the table maximum)
+            tab_max = reinterpret_cast<unsigned *>(padded + tab_max_offset);
+            KIMG_HIP(hipMemsetAsync(tab_max, 0, sizeof(unsigned), stream));
+            const int64_t n = (int64_t) rows * ts.K * 2;
+            dg_table_max_kernel<<<kimg_divup(n, 256 * 8), 256, 0, stream>>>(
+                reinterpret_cast<const float *>(kern), n, tab_max);
+        }
         pad_rows_kernel<<<kimg_divup(rows * 32, 256), 256, 0, stream>>>(kern, rows, ts.K, ts.tv0,
                                                                        ts.Kv, out);
         if (TWO)
@@ -579,7 +604,7 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
     degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, ts,
-        vis_per_block, p_total, padded);
+        vis_per_block, p_total, padded, tab_max);
     return kimg_launch_status();
 }
 
@@ -602,7 +627,7 @@ size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int
     if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width)
         || (tables_fit_lds(w_planes, oversample, kernel_width) && !getenv("KIMG_DEGRID_TABLE")))
         return 0;       // (with the experiment variable set, scratch is reserved either way)
-    return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1);
+    return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
 
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
@@ -639,9 +664,15 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
         grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream)
                 const bool doubled = lds_bytes(12, w_planes, oversample, 64) <= LDS_LIMIT;
-#define LAUNCH_TG(PP, NWV, TAPSV, TWOV) rc = launch<PP, NWV, TAPSV, TWOV, true>(g, grid_row_stride, \
+#define LAUNCH_TG(PP, NWV, TAPSV, TWOV) do { if (f16_tg) rc = launch<PP, NWV, TAPSV, TWOV, true, true>(g, \
+        grid_row_stride, grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, \
+        num_vis, (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded, \
+        tab_max_offset); else rc = launch<PP, NWV, TAPSV, TWOV, true, false>(g, grid_row_stride, \
         grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
-        (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded)
+        (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded, 0); } while (0)
+                const char *fenv_tg = getenv("KIMG_DEGRID_F16");
+                const bool f16_tg = !(fenv_tg && fenv_tg[0] == '0');
+                const size_t tab_max_offset = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
                 // Diagonal blocks of a wide kernel use the same taps for rows and columns: one
                 // table, handled exactly like a narrow kernel's.
                 const bool two = wide && jb != kb;

@@ -1418,7 +1418,7 @@ def test_gridder_f16_form_ranges(pattern, P, K, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('W', [32, 64])
+@pytest.mark.parametrize('W', [32, 64, 160])          # doubled rows, single rows, table in HBM
 @pytest.mark.parametrize('pattern', ['1e-20', '1', '1e20', 'spike', 'smooth_ramp', 'zeros', 'nan'])
 def test_degridder_f16_form_ranges(pattern, W):
     """The fp16 hi/lo form of the window degridder (two window rows per matrix instruction) scales
