@@ -192,11 +192,14 @@ struct tap_split {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// (lo | hi << 16), rounded to nearest (v_cvt_pk_f16_f32): truncation would bias every product
+// the same way.  (The name dates from a first version that truncated.)
 __device__ inline unsigned cvt_pk_f16_rtz(float lo, float hi)
 {
-    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-    const h2 r = __builtin_amdgcn_cvt_pkrtz(lo, hi);
-    return __builtin_bit_cast(unsigned, r);
+    typedef float pk2f __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const pk2f x = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, h2));
 }
 
 __device__ inline float f16_bits_to_f32(unsigned bits16)
