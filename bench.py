@@ -3,18 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): one spectral channel, 4096^2 image, 32 W-planes,
-~50 M synthetic visibilities (tools/synth.py), float32, Stokes I, kernel width 28,
-oversample 8, streamed through Gridder in --vis-block chunks (reference default 1 048 576,
-frontend.py:357) with every input resident in HBM.  One "step" = clear the grid + grid all
-chunks of the channel (the hot loop #1 of frontend.make_dirty, frontend.py:126-139).
-With N > 1 (one process per GPU, torchrun) every rank images its own channel (frequency
-spread +-3 %): the path shards by channel with no data-path collective (weak scaling);
-rank 0 broadcasts the channel-independent tables over RCCL once at start-up.
+Workload (BASELINE.json configs[1], "C2"): one spectral channel per GPU, 4096^2 image, 32
+W-planes, ~50 M synthetic visibilities (tools/synth.py: 64-antenna array, earth-rotation tracks,
+baseline-major order, uncompressed), float32, Stokes I, kernel width 28, oversample 8, every input
+resident in HBM.  One "step" = clear the grid + grid the channel's W-slice the way the product's
+resident-store driver does it (frontend.make_dirty over VisibilityReaderDevice.iter_slice_device
+with one block per slice, i.e. ONE gridder launch per slice; the hot loop #1 of the reference's
+frontend.make_dirty, frontend.py:126-139).  The same visibilities streamed in the reference's
+--vis-block chunks of 1 048 576 (frontend.py:357), one launch per chunk, are measured too
+(`chunked`).
 
-Prints ONE JSON line on rank 0: metric "Mvis/s gridded", plus `roofline` for the dominant
-kernel (grid_mfma_kernel), `cpu_baseline` (the oracle's single-thread C restatement timed on
-this host) and secondary numbers (CLEAN minor-cycles/s, degrid, FFT).
+`value` / `roofline` are for the gridder's float32 arithmetic (KIMG_ARITH_FP32,
+v_mfma_f32_32x32x2_f32: every product and sum in float32 like the reference's kernel).  The
+opt-in fp16 hi/lo form (KIMG_ARITH_SPLIT_FP16) is a second block, `split_fp16`, scored against
+the F16 matrix pipe it runs on.  Both blocks carry their max-norm error against a float64
+evaluation of one 1 M-visibility chunk.
+
+With N > 1 (one process per GPU, torchrun) every rank images its own channel of an 8-channel band
+(rank 0 always the top channel, the one the N = 1 run images; same geometry for every N): the
+path shards by channel with no data-path collective (weak scaling); rank 0 broadcasts the
+channel-independent baseline table over RCCL once at start-up.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -32,6 +42,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2516.6     # same table: BF16/F16 dense, v_mfma_f32_32x32x16_f16
 HBM_PEAK_GBS = 8000.0
+BAND_CHANNELS = 8                 # BASELINE config 3: 8 spectral-line channels
+BAND_SPREAD = 0.03
 
 
 def parse_args():
@@ -44,49 +56,139 @@ def parse_args():
     p.add_argument('--w-planes', type=int, default=32)
     p.add_argument('--kernel-width', type=int, default=28)
     p.add_argument('--polarizations', type=int, default=1)
-    p.add_argument('--vis-block', type=int, default=1048576)
+    p.add_argument('--vis-block', type=int, default=1048576,
+                   help='chunk size of the `chunked` measurements (the reference\'s --vis-block)')
     p.add_argument('--variant', default='auto', choices=['auto', 'generic', 'mfma'])
     p.add_argument('--clean-cycles', type=int, default=1000)
-    p.add_argument('--cpu-sample', type=int, default=16_000_000,
-                   help='visibilities gridded by the CPU baseline (0 disables it)')
-    p.add_argument('--streams', type=int, default=2, choices=[1, 2],
-                   help='HIP streams per channel in the major-loop measurements')
-    p.add_argument('--major-loop', action='store_true',
-                   help='also time the full major-cycle loop (BASELINE config 5)')
+    p.add_argument('--cpu-sample', type=int, default=3_200_000,
+                   help='visibilities per timed pass of the CPU baseline (0 disables it)')
+    p.add_argument('--cpu-passes', type=int, default=5)
     p.add_argument('--no-secondary', action='store_true',
-                   help='skip the CLEAN / degrid / FFT secondary measurements')
+                   help='only the headline gridder measurement (and the CPU baseline)')
+    p.add_argument('--no-major-loop', action='store_true',
+                   help='skip the major-cycle loop (BASELINE config 5)')
+    p.add_argument('--extras', action='store_true',
+                   help='also: preprocessing + store-driven driver, several channels in flight, '
+                        'host-chunk (PCIe-inclusive) gridding')
+    p.add_argument('--traffic-json', default=None,
+                   help='HBM bytes per launch from a rocprofv3 --pmc pass of this same command '
+                        '(tools/profile_round.sh); included as roofline.traffic only if its '
+                        'recorded configuration matches this run')
+    p.add_argument('--rehearse', action='store_true',
+                   help='CPU rehearsal of the multi-process plumbing (rendezvous, broadcast, channel '
+                        'assignment, barriers, reductions, the JSON line) with no device work; for '
+                        'the gloo tests')
     return p.parse_args()
+
+
+def rank_channel(rank, world):
+    """Channel of the 8-channel band imaged by `rank`: rank 0 always takes the top channel (so the
+    N = 1 run is one of the channels of every N > 1 run); the others spread over the band."""
+    stride = max(BAND_CHANNELS // max(world, 1), 1)
+    return (BAND_CHANNELS - 1 - rank * stride) % BAND_CHANNELS
+
+
+def channel_scale(channel):
+    """Relative frequency of a band channel, normalised to the top one: uvw in wavelengths scale
+    with it, so every channel's footprint stays inside the grid sized for the top channel."""
+    from katsdpimager_amd import parallel
+    return parallel.channel_frequency_scale(channel, BAND_CHANNELS, BAND_SPREAD) / (1 + BAND_SPREAD)
+
+
+class Timer:
+    """K steps bracketed by barrier + synchronize; per-step HIP events on the operator's stream."""
+
+    def __init__(self, q, barrier, dev):
+        self.q, self.barrier, self.dev = q, barrier, dev
+
+    def run(self, step, steps, warmup, reduce=True):
+        import torch
+        from katsdpimager_amd import parallel
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        for _ in range(warmup):
+            step(None, None)
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(ev0[k], ev1[k])
+        torch.cuda.synchronize()
+        self.barrier()
+        t1 = time.perf_counter()
+        elapsed = parallel.max_over_ranks(t1 - t0, self.dev) if reduce else t1 - t0
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        return elapsed / steps, kern_ms
+
+
+def grid_roofline(arith, K, P, n_vis, launches, kern_ms, variant):
+    """Roofline block of the gridder kernel: algorithmic flops of one launch / its average
+    duration (HIP events on the launch stream), against the peak of the matrix pipe it uses."""
+    flop_per_vis = 8.0 * K * K * P               # one complex MAC per tap and polarization
+    bytes_per_vis = 8 + 2 + 8 * P + 4 * P        # uv + w_plane + vis + weight gather
+    launch_us = kern_ms * 1e3 / launches
+    secs = kern_ms * 1e-3
+    achieved = flop_per_vis * n_vis / secs / 1e12
+    blocks = 1 if K <= 32 else 4                 # 2 x 2 tap blocks for wide kernels
+    split = arith == 'split_fp16' and variant != 'generic' and K <= 64
+    mfma = variant != 'generic' and K <= 64
+    # executed: a 32x32 window per visibility (and tap block); the split form spends a whole
+    # 32x32x16 instruction (6 of 16 k-slots used) on two visibilities
+    executed_per_vis = blocks * P * (2 * 32 * 32 * 16 * 2 / 2 if split else 2 * 32 * 32 * 2 * 2)
+    peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    executed = executed_per_vis * n_vis / secs / 1e12
+    out = {
+        'kernel': 'grid_mfma_kernel' if mfma else 'grid_generic_kernel',
+        'instruction': ('v_mfma_f32_32x32x16_f16 (fp16 hi/lo operand pairs, 2 visibilities each)'
+                        if split else 'v_mfma_f32_32x32x2_f32' if mfma else 'per-tap float atomics'),
+        'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4), 'traffic': None,
+        'flop_per_vis': flop_per_vis, 'vis_per_launch': int(round(n_vis / launches)),
+        'launches_per_step': launches, 'avg_launch_us': round(launch_us, 2),
+        'executed_tflops': round(executed, 2), 'executed_frac': round(executed / peak, 4),
+        'hbm_algorithmic_GBps': round(bytes_per_vis * n_vis / secs / 1e9, 1),
+        'hbm_frac_of_8TBps': round(bytes_per_vis * n_vis / secs / 1e9 / HBM_PEAK_GBS, 4),
+        # the reference bench's own figure of merit: grid-point additions per second
+        # (tests/imager_bench.py:204-208), N K^2 P / t
+        'GGAPS': round(n_vis * K * K * P / secs / 1e9, 1),
+    }
+    if split:
+        # the split form's loop is bound by VALU issue (operand re-join / split / permute), not by
+        # the F16 pipe: also state the algorithmic fp32 work against the fp32 matrix peak, i.e.
+        # against the best the exact instruction could do
+        out['frac_of_fp32_mfma_peak'] = round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)
+    return out
 
 
 def main():
     args = parse_args()
+    if args.rehearse:
+        return rehearse(args)
     import torch
     import torch.distributed as dist
     import synth
-    from katsdpimager_amd import accel, grid, image, clean, parameters, parallel, _lib
+    from katsdpimager_amd import accel, grid, parallel, _lib
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # KIMG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    # (ranks share devices); the driver's runs use the default, RCCL with one GPU per rank.
-    backend = os.environ.get('KIMG_DIST_BACKEND', 'nccl')
-    device_index = local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(device_index)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
-        else:
-            dist.init_process_group(backend)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
         raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch with torchrun'.format(
             args.gpus, world))
     _lib.lib()      # fail loudly if the HIP extension is missing
-    ctx = accel.Context(device_index)
+    ctx = accel.Context(local_rank)
     q = ctx.create_command_queue()
     dev = ctx.device
     P, K, W, G = args.polarizations, args.kernel_width, args.w_planes, args.pixels
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
 
     # ---- shared tables: computed on rank 0, broadcast over RCCL/xGMI (SURVEY 8e) -------
     t_bcast = 0.0
@@ -100,13 +202,10 @@ def main():
         t_bcast = time.perf_counter() - t0
         assert torch.equal(shared['baselines'].cpu(), torch.from_numpy(synth.baselines_equatorial()))
 
-    # ---- this rank's channel (channel c -> rank c mod world; one channel per GPU here) ----
-    channel = parallel.assign_channels(world, world, rank)[0]
-    chan_scale = parallel.channel_frequency_scale(channel, world)
-    # uv coordinates scale with frequency: keep the footprint inside the grid for every channel
-    cover = 0.30 / (1.03 if world > 1 else 1.0)
-    obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=cover,
-                                 channel_scale=chan_scale, seed=2 + rank)
+    # ---- this rank's channel -------------------------------------------------------------
+    channel = rank_channel(rank, world)
+    obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=0.30,
+                                 channel_scale=channel_scale(channel), seed=2 + rank)
     ip, gp, ap = synth.make_parameters(obs, P, K)
     n_vis = obs.n_vis
     vb = args.vis_block
@@ -119,16 +218,30 @@ def main():
         z = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         return torch.cat([t, z])
     uv_all, wp_all, vis_all = padded(obs.uv), padded(obs.w_plane), padded(obs.vis)
+    n_pad = n_chunks * vb
 
-    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': args.variant})
-    fn = template.instantiate(q, ap, ip, gp, vb)
+    templates = {a: grid.GridderTemplate(ctx, ip.fixed, gp.fixed,
+                                         {'variant': args.variant, 'arith': a})
+                 for a in ('fp32', 'split_fp16')}
+    slice_ops = {a: t.instantiate(q, ap, ip, gp, n_pad) for a, t in templates.items()}
+    fn = slice_ops['fp32']
     Gg = fn.slots['grid'].shape[1]
     gen = torch.Generator(device=dev)
     gen.manual_seed(2)
     wg = accel.DeviceArray(ctx, (P, Gg, Gg), np.float32,
                            tensor=torch.rand((P, Gg, Gg), generator=gen, device=dev))
-    fn.bind(weights_grid=wg)
-    fn.ensure_all_bound()
+    grid_buf = accel.DeviceArray(ctx, (P, Gg, Gg), np.complex64)
+    whole = dict(uv=accel.DeviceArray(ctx, (n_pad, 4), np.int16, tensor=uv_all),
+                 w_plane=accel.DeviceArray(ctx, (n_pad,), np.int16, tensor=wp_all),
+                 vis=accel.DeviceArray(ctx, (n_pad, P), np.complex64, tensor=vis_all))
+    for op in slice_ops.values():
+        op.bind(grid=grid_buf, weights_grid=wg, **whole)
+        op.ensure_all_bound()
+        op.num_vis = n_vis
+    chunk_ops = {a: t.instantiate(q, ap, ip, gp, vb) for a, t in templates.items()}
+    for op in chunk_ops.values():
+        op.bind(grid=grid_buf, weights_grid=wg)
+        op.ensure_all_bound()
     chunks = []
     for i in range(n_chunks):
         s = slice(i * vb, (i + 1) * vb)
@@ -136,245 +249,116 @@ def main():
                        accel.DeviceArray(ctx, (vb,), np.int16, tensor=wp_all[s]),
                        accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=vis_all[s]),
                        min(vb, n_vis - i * vb)))
-    grid_buf = fn.buffer('grid')
-    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()        # torch produced the inputs on its own stream
 
-    def step(k=None):
-        grid_buf.zero(q)                               # imager.clear_grid()
-        if k is not None:
-            ev_start[k].record(q.stream)
-        for uv_c, wp_c, vis_c, n in chunks:
-            fn.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
-            fn.num_vis = n
-            fn._run()                                  # imager.grid()
-        if k is not None:
-            ev_stop[k].record(q.stream)
+    def slice_step(arith):
+        op = slice_ops[arith]
 
-    def barrier():
-        if world > 1:
-            if backend == 'nccl':
-                dist.barrier(device_ids=[device_index])
-            else:
-                dist.barrier()
+        def step(e0, e1):
+            grid_buf.zero(q)                            # imager.clear_grid()
+            if e0 is not None:
+                e0.record(q.stream)
+            op._run()                                   # imager.grid(): the whole slice, one launch
+            if e1 is not None:
+                e1.record(q.stream)
+        return step
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = parallel.max_over_ranks(t1 - t0, dev)
-    ms_per_step = elapsed / args.steps * 1e3
-    mvis = world * n_vis / (elapsed / args.steps) / 1e6
+    def chunk_step(arith):
+        op = chunk_ops[arith]
 
-    # ---- roofline of the dominant kernel (gridder), HIP events on the kernel's stream ----
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_start, ev_stop)]))
-    launch_us = kern_ms * 1e3 / n_chunks
-    flop_per_vis = 8.0 * K * K * P               # one complex MAC per tap and polarization
-    achieved_tflops = flop_per_vis * n_vis / (kern_ms * 1e-3) / 1e12
-    bytes_per_vis = 8 + 2 + 8 * P + 4 * P        # uv + w_plane + vis + weight gather
-    roofline = {
-        'kernel': 'grid_mfma_kernel' if args.variant != 'generic' else 'grid_generic_kernel',
-        'bound': 'mfma', 'achieved': round(achieved_tflops, 3), 'peak': FP32_MFMA_PEAK_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-        'traffic': None,
-        'flop_per_vis': flop_per_vis, 'avg_launch_us': round(launch_us, 2),
-        'vis_per_launch': vb,
-        'hbm_algorithmic_GBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9, 1),
-        'hbm_frac_of_8TBps': round(bytes_per_vis * n_vis / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        # the reference bench's own figure of merit: grid-point additions per second
-        # (tests/imager_bench.py:204-208), N K^2 P / t
-        'GGAPS': round(n_vis * K * K * P / (kern_ms * 1e-3) / 1e9, 1),
-    }
-    # Which matrix instruction carried the work.  The gridder's default form splits every fp32
-    # operand into an fp16 hi/lo pair and puts two visibilities into one v_mfma_f32_32x32x16_f16
-    # (fp32 accumulation, results within 2e-6 of the exact form); KIMG_GRID_F16=0 selects the exact
-    # v_mfma_f32_32x32x2_f32.  `achieved` / `peak` / `frac` stay what they were -- algorithmic fp32
-    # work against the fp32 matrix peak, i.e. against what the exact instruction could ever reach --
-    # and `pipe_*` give the executed flops against the peak of the pipe actually used.
-    f16_form = args.variant != 'generic' and K <= 64 and os.environ.get('KIMG_GRID_F16', '1') != '0'
-    blocks = 1 if K <= 32 else 4                 # 2 x 2 tap blocks for wide kernels
-    executed_per_vis = blocks * P * (2 * 32 * 32 * 16 * 2 / 2 if f16_form else 2 * 32 * 32 * 2 * 2)
-    pipe_peak = F16_MFMA_PEAK_TFLOPS if f16_form else FP32_MFMA_PEAK_TFLOPS
-    executed_tflops = executed_per_vis * n_vis / (kern_ms * 1e-3) / 1e12
-    roofline.update({
-        'form': ('fp16 hi/lo pairs, 2 visibilities per v_mfma_f32_32x32x16_f16' if f16_form
-                 else 'v_mfma_f32_32x32x2_f32' if args.variant != 'generic' else 'per-tap atomics'),
-        'pipe_peak': pipe_peak, 'pipe_executed': round(executed_tflops, 1),
-        'pipe_frac': round(executed_tflops / pipe_peak, 4),
-    })
-    traffic_file = os.path.join(ROOT, 'profiles', 'gridder_traffic.json')
-    if os.path.exists(traffic_file):
-        try:
-            roofline['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
-        except Exception:
-            pass
+        def step(e0, e1):
+            grid_buf.zero(q)
+            if e0 is not None:
+                e0.record(q.stream)
+            for uv_c, wp_c, vis_c, n in chunks:
+                op.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+                op.num_vis = n
+                op._run()
+            if e1 is not None:
+                e1.record(q.stream)
+        return step
 
+    timer = Timer(q, barrier, dev)
+    # ---- the headline: float32 arithmetic, one launch per slice ---------------------------
+    sec_per_step, kern_ms = timer.run(slice_step('fp32'), args.steps, args.warmup)
+    mvis = world * n_vis / sec_per_step / 1e6
+    roofline = grid_roofline('fp32', K, P, n_vis, 1, kern_ms, args.variant)
+    traffic = load_traffic(args, roofline)
+    if traffic is not None:
+        roofline['traffic'] = traffic
+
+    workload = ('{0}: 1 channel per GPU, {1}^2 image, {2} W-planes, {3} vis, K={4}, P={5}, '
+                'one gridder launch per W-slice (resident store)').format(
+        'C2' if (G, W, P) == (4096, 32, 1) else 'C4' if (G, W, P) == (8192, 64, 4) else 'custom',
+        G, W, n_vis, K, P)
     result = {
         'metric': 'Mvis/s gridded (4096^2 grid, 32 W-planes)', 'value': round(mvis, 2),
         'unit': 'Mvis/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': 'f32 (operands as fp16 hi/lo pairs, fp32 accumulation)' if f16_form else 'f32',
-        'data': 'synthetic',
-        'config': {'workload': 'C2: 1 channel per GPU, {0}^2 image, {1} W-planes, {2} vis, '
-                               'K={3}, P={4}, vis_block={5}'.format(G, W, n_vis, K, P, vb),
-                   'grid_size': Gg, 'channels': world, 'parallelism': 'channel-sharded',
+        'ms_per_step': round(sec_per_step * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': workload, 'grid_size': Gg, 'channels': world,
+                   'band_channel_of_rank0': channel, 'parallelism': 'channel-sharded',
                    'broadcast_ms': round(t_bcast * 1e3, 3)},
         'roofline': roofline,
     }
 
+    # ---- the opt-in fp16 hi/lo form, same step, scored against the pipe it uses -----------
+    if args.variant != 'generic' and K <= 64:
+        s_split, k_split = timer.run(slice_step('split_fp16'), args.steps, args.warmup)
+        result['split_fp16'] = {
+            'value': round(world * n_vis / s_split / 1e6, 2), 'unit': 'Mvis/s',
+            'ms_per_step': round(s_split * 1e3, 3),
+            'dtype': 'f32 accumulation, operands as fp16 hi/lo pairs (22 bits, lo*lo dropped)',
+            'roofline': grid_roofline('split_fp16', K, P, n_vis, 1, k_split, args.variant),
+        }
+
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         result['cpu_baseline'] = cpu_baseline(args, obs, fn, wg, Gg)
+
     if rank == 0 and not args.no_secondary:
-        sec = secondary(args, ctx, q, obs, ip, gp, ap, fn, chunks)
-        # all chunks of the channel resident and gridded by ONE launch (what a resident
-        # visibility store, SURVEY 8f-2, buys over vis_block-sized launches)
-        big = template.instantiate(q, ap, ip, gp, n_chunks * vb)
-        big.bind(grid=grid_buf, weights_grid=wg,
-                 uv=accel.DeviceArray(ctx, (n_chunks * vb, 4), np.int16, tensor=uv_all),
-                 w_plane=accel.DeviceArray(ctx, (n_chunks * vb,), np.int16, tensor=wp_all),
-                 vis=accel.DeviceArray(ctx, (n_chunks * vb, P), np.complex64, tensor=vis_all))
-        big.num_vis = n_vis
-        big._run()
-        q.finish()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            big._run()
-        q.finish()
-        sec['grid_single_launch_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
-        # Chunk launches alternated over two HIP streams (both accumulate into the same grid with
-        # atomics): the tail of one launch overlaps the head of the next, which recovers the
-        # single-launch rate while keeping vis_block-sized launches.  Not used for `value`: the
-        # per-launch durations of overlapping kernels no longer add up to the wall time, so the
-        # roofline accounting above would not apply.
-        q2 = ctx.create_command_queue()
-        fn_b = template.instantiate(q2, ap, ip, gp, vb)
-        fn_b.bind(grid=grid_buf, weights_grid=wg)
-        fn_b.ensure_all_bound()
-        pair = (fn, fn_b)
-
-        def grid_two_streams():
-            for i, (uv_c, wp_c, vis_c, n) in enumerate(chunks):
-                g_ = pair[i & 1]
-                g_.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
-                g_.num_vis = n
-                g_._run()
+        sec = {}
+        # accuracy of both forms against float64 on one vis_block chunk of this workload
+        mid = (n_chunks // 2) * vb
+        mid = min(mid, max(n_vis - vb, 0))
+        cn = min(vb, n_vis - mid)
+        truth = synth.grid_truth_fp64(fn.convolve_kernel.data, obs.uv[mid:mid + cn],
+                                      obs.w_plane[mid:mid + cn], obs.vis[mid:mid + cn],
+                                      wg.tensor, K)
+        tmax = float(truth.abs().max())
+        for arith in ('fp32', 'split_fp16'):
+            if arith == 'split_fp16' and 'split_fp16' not in result:
+                continue
+            op = chunk_ops[arith]
+            grid_buf.zero(q)
+            s = slice(mid, mid + vb)
+            op.bind(uv=accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=uv_all[s]),
+                    w_plane=accel.DeviceArray(ctx, (vb,), np.int16, tensor=wp_all[s]),
+                    vis=accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=vis_all[s]))
+            op.num_vis = cn
+            op._run()
             q.finish()
-            q2.finish()
-        grid_two_streams()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            grid_two_streams()
-        sec['grid_two_streams_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
-        # the same per-chunk launches as `value`, with the exact v_mfma_f32_32x32x2_f32 instruction
-        # instead of the default fp16 hi/lo form (the library reads the variable per call)
-        if f16_form:
-            def grid_chunks_once():
-                for uv_c, wp_c, vis_c, n in chunks:
-                    fn.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
-                    fn.num_vis = n
-                    fn._run()
-                q.finish()
-            os.environ['KIMG_GRID_F16'] = '0'
-            try:
-                grid_chunks_once()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    grid_chunks_once()
-                sec['grid_exact_fp32_Mvis_per_s'] = round(3 * n_vis / (time.perf_counter() - t0) / 1e6, 1)
-            finally:
-                os.environ.pop('KIMG_GRID_F16', None)
-        del fn_b
-        # PCIe-inclusive: the reference-style host path, every chunk copied from host memory
-        # (uv, w_plane, vis: 18 B per visibility at P=1) before it is gridded
-        host_fn = template.instantiate(q, ap, ip, gp, vb)
-        host_fn.bind(grid=grid_buf, weights_grid=wg)
-        host_fn.ensure_all_bound()
-        h_uv = uv_all[:vb].cpu().numpy()
-        h_wp = wp_all[:vb].cpu().numpy()
-        h_vis = vis_all[:vb].cpu().numpy()
-        host_fn.num_vis = vb
-
-        def host_chunk():
-            host_fn.buffer('uv').set(q, h_uv)
-            host_fn.buffer('w_plane').set(q, h_wp)
-            host_fn.buffer('vis').set(q, h_vis)
-            host_fn._run()
-        host_chunk()
-        q.finish()
-        t0 = time.perf_counter()
-        for _ in range(8):
-            host_chunk()
-        q.finish()
-        sec['grid_host_chunks_Mvis_per_s'] = round(8 * vb / (time.perf_counter() - t0) / 1e6, 1)
-        # many W planes (the reference's default w-step gives hundreds per slice): the kernel
-        # table no longer fits LDS and is read from a padded copy in HBM
-        del host_fn, big
-        n2 = min(n_vis, 16 * vb)
-        obs2 = synth.make_observation(G, n2, 256, P, device=dev, seed=5)
-        ip2, gp2, ap2 = synth.make_parameters(obs2, P, K)
-        fn2 = template.instantiate(q, ap2, ip2, gp2, vb)
-        grid2 = accel.DeviceArray(ctx, fn2.slots['grid'].shape, np.complex64)
-        wg2 = accel.DeviceArray(ctx, fn2.slots['grid'].shape, np.float32,
-                                tensor=torch.ones(fn2.slots['grid'].shape, device=dev))
-        fn2.bind(grid=grid2, weights_grid=wg2)
-        fn2.ensure_all_bound()
-        torch.cuda.synchronize()
-
-        def grid_obs2():
-            for start in range(0, n2 - vb + 1, vb):
-                sl = slice(start, start + vb)
-                fn2.bind(uv=accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=obs2.uv[sl]),
-                         w_plane=accel.DeviceArray(ctx, (vb,), np.int16, tensor=obs2.w_plane[sl]),
-                         vis=accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=obs2.vis[sl]))
-                fn2.num_vis = vb
-                fn2._run()
-        grid_obs2()
-        q.finish()
-        t0 = time.perf_counter()
-        grid_obs2()
-        q.finish()
-        sec['grid_256_planes_Mvis_per_s'] = round((n2 // vb) * vb / (time.perf_counter() - t0) / 1e6, 1)
-        # the reference's default geometry: kernel width 60 (frontend.py:325) on the same 256 planes
-        if K != 60:
-            del fn2
-            ip3, gp3, ap3 = synth.make_parameters(obs2, P, 60)
-            fn2 = grid.GridderTemplate(ctx, ip3.fixed, gp3.fixed, {'variant': args.variant}) \
-                .instantiate(q, ap3, ip3, gp3, vb)
-            del grid2, wg2
-            shape3 = fn2.slots['grid'].shape
-            fn2.bind(grid=accel.DeviceArray(ctx, shape3, np.complex64),
-                     weights_grid=accel.DeviceArray(ctx, shape3, np.float32,
-                                                    tensor=torch.ones(shape3, device=dev)))
-            fn2.ensure_all_bound()
-            torch.cuda.synchronize()
-            grid_obs2()
-            q.finish()
-            t0 = time.perf_counter()
-            grid_obs2()
-            q.finish()
-            sec['grid_k60_256_planes_Mvis_per_s'] = round(
-                (n2 // vb) * vb / (time.perf_counter() - t0) / 1e6, 1)
-        if args.major_loop:
-            # PSF pass grids the weights as visibilities (frontend.py:511)
-            wt_all = padded(obs.weights)
-            psf_all = torch.complex(wt_all, torch.zeros_like(wt_all))
-            obs.vis.copy_(torch.where(torch.isfinite(obs.vis.real), obs.vis, torch.zeros_like(obs.vis)))
-            chunks_dev = []
-            for i in range(n_chunks):
-                sl = slice(i * vb, (i + 1) * vb)
-                wt_c = accel.DeviceArray(ctx, (vb, P), np.float32, tensor=wt_all[sl])
-                wt_c.psf_vis = accel.DeviceArray(ctx, (vb, P), np.complex64, tensor=psf_all[sl])
-                chunks_dev.append((chunks[i][0], chunks[i][1], chunks[i][2], wt_c, chunks[i][3]))
-            sec['major_cycle_loop'] = major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev)
+            err = float((grid_buf.tensor.to(torch.complex128) - truth).abs().max()) / tmax
+            block = result if arith == 'fp32' else result['split_fp16']
+            block['max_norm_error_vs_fp64'] = float('%.3g' % err)
+        del truth
+        # the reference's chunking: vis_block-sized launches on one stream
+        for arith in ('fp32', 'split_fp16'):
+            if arith == 'split_fp16' and 'split_fp16' not in result:
+                continue
+            s_c, k_c = timer.run(chunk_step(arith), 3, 1, reduce=False)
+            r = grid_roofline(arith, K, P, n_vis, n_chunks, k_c, args.variant)
+            sec['chunked_' + arith] = {
+                'Mvis_per_s': round(n_vis / s_c / 1e6, 1), 'vis_block': vb,
+                'avg_launch_us': r['avg_launch_us'], 'frac': r['frac']}
+        sec.update(secondary(args, ctx, q, obs, ip, gp, ap, fn, grid_buf, chunks))
+        sec.update(geometry_sweep(args, ctx, q, dev))
         result['secondary'] = sec
+        if args.extras:
+            result['extras'] = extras(args, ctx, q, obs, ip, gp, ap, templates['fp32'], grid_buf,
+                                      wg, uv_all, wp_all, vis_all)
+    if rank == 0 and not args.no_major_loop and not args.no_secondary:
+        del slice_ops, chunk_ops, chunks
+        result['major_cycle_loop'] = major_cycle_loop(args, ctx, q, obs, extras=args.extras)
     barrier()
     if rank == 0:
         print(json.dumps(result))
@@ -382,8 +366,25 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
-    """CLEAN minor-cycles/s (second half of BASELINE's metric), FFT + layer_to_image, degrid."""
+def load_traffic(args, roofline):
+    """roofline.traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes) from a rocprofv3 --pmc pass of THIS command, handed over by
+    tools/profile_round.sh.  Never a stale number: the file must describe the same launch."""
+    if not args.traffic_json or not os.path.exists(args.traffic_json):
+        return None
+    try:
+        t = json.load(open(args.traffic_json))
+    except Exception:
+        return None
+    same = (t.get('kernel') == roofline['kernel'] and t.get('vis_per_launch') == roofline['vis_per_launch']
+            and t.get('arith') == 'fp32' and t.get('kernel_width') == args.kernel_width
+            and t.get('polarizations') == args.polarizations)
+    return t.get('bytes_per_launch') if same else None
+
+
+def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
+    """CLEAN minor-cycles/s (second half of BASELINE's metric), FFT + layer_to_image, degrid,
+    DFT predict."""
     import torch
     from katsdpimager_amd import accel, grid, image, clean, parameters
     out = {}
@@ -392,9 +393,9 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     # grid -> image (pad/shift + rocFFT + layer_to_image)
     template = image.GridImageTemplate(ctx, np.float32)
     g2i = template.instantiate_grid_to_image(
-        q, gridder.buffer('grid').shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
+        q, grid_buf.shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
         template.make_fft_plan((G, G)))
-    g2i.bind(grid=gridder.buffer('grid'))
+    g2i.bind(grid=grid_buf)
     g2i.ensure_all_bound()
     g2i.buffer('kernel1d').set(q, gridder.convolve_kernel.taper(G).astype(np.float32))
     g2i.buffer('image').zero(q)
@@ -404,7 +405,14 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     for _ in range(5):
         g2i()
     q.finish()
-    out['grid_to_image_ms'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    dt = (time.perf_counter() - t0) / 5
+    out['grid_to_image_ms'] = round(dt * 1e3, 3)
+    # compulsory HBM traffic per polarization: read the grid, write + FFT the layer (2 passes,
+    # read + write each), read it again, read-modify-write the image
+    Gg = grid_buf.shape[1]
+    g2i_bytes = P * (8 * Gg * Gg + 8 * G * G + 32 * G * G + 8 * G * G + 8 * G * G)
+    out['grid_to_image_GBps'] = round(g2i_bytes / dt / 1e9, 1)
+    out['grid_to_image_frac_of_8TBps'] = round(g2i_bytes / dt / 1e9 / HBM_PEAK_GBS, 4)
 
     # restoring-beam convolution of one polarization plane (R2C + Gaussian + C2R, beam.py:351-398)
     from katsdpimager_amd import beam
@@ -422,9 +430,6 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     del conv
 
     # CLEAN: dirty = 200 point sources (x) PSF + noise, patch from psf_patch
-    dirty = g2i.buffer('image')
-    img = dirty.get(q)
-    peak = img[:, G // 2, G // 2].copy()
     rs = np.random.RandomState(4)
     g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
     psf = np.outer(g1, g1)[None].repeat(P, axis=0).astype(np.float32)
@@ -443,65 +448,77 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     pp = clean.PsfPatchTemplate(ctx, np.float32, P).instantiate(q, (P, G, G))
     pp.bind(psf=cl.buffer('psf'))
     patch = pp(cp.psf_cutoff, cp.psf_limit)
-    for label in ('batched_first_call', 'batched', 'per_cycle'):
-        # 'batched_first_call' includes the one-off capture + instantiation of the hipGraph
+
+    def clean_rate(patch_, per_cycle=False):
         cl.buffer('dirty').set(q, sky)
         cl.buffer('model').zero(q)
         cl.reset()
-        n = min(args.clean_cycles, 200) if label == 'per_cycle' else args.clean_cycles
+        n = min(args.clean_cycles, 200) if per_cycle else args.clean_cycles
         q.finish()
         t0 = time.perf_counter()
-        if label != 'per_cycle':
-            done = len(cl.run_cycles(patch, 0.0, n))
+        if not per_cycle:
+            done = len(cl.run_cycles(patch_, 0.0, n))
         else:
             done = 0
             for _ in range(n):
-                v, p_, m = cl(patch, 0.0)
+                v, p_, m = cl(patch_, 0.0)
                 done += v is not None
         q.finish()
-        out['clean_%s_cycles_per_s' % label] = round(done / (time.perf_counter() - t0), 1)
-    out['clean_psf_patch'] = list(patch)
-    # the same with the patch of a measured PSF (111 x 133, the --major-loop case): few lattice
-    # blocks, so the cycle is ONE launch (every workgroup repeats the peak search)
+        return done / (time.perf_counter() - t0)
+    clean_rate(patch)           # first call: hipGraph capture + instantiation
     small = (P, min(111, patch[1]), min(133, patch[2]))
-    for label in ('warm', 'timed'):
-        cl.buffer('dirty').set(q, sky)
-        cl.buffer('model').zero(q)
-        cl.reset()
-        q.finish()
-        t0 = time.perf_counter()
-        done = len(cl.run_cycles(small, 0.0, args.clean_cycles))
-        q.finish()
-        out['clean_small_patch_cycles_per_s'] = round(done / (time.perf_counter() - t0), 1)
-    out['clean_small_patch'] = list(small)
+    clean_rate(small)
+    large = clean_rate(patch)
+    out['clean'] = {
+        # metric half 2: minor cycles per second, device-resident loop, incl. the final read-back
+        'large_patch': list(patch), 'large_patch_cycles_per_s': round(large, 1),
+        'large_patch_us_per_cycle': round(1e6 / large, 2),
+        'small_patch': list(small),
+        'small_patch_cycles_per_s': round(clean_rate(small), 1),
+        'per_cycle_host_sync_cycles_per_s': round(clean_rate(patch, per_cycle=True), 1),
+        # latency budget of a cycle (dependent chain; DESIGN.md "CLEAN cycle latency"): graph
+        # node-to-node 2.1 us, cold first load 1.0, peak search 0.9, winner record 0.3, block
+        # pixels 0.45, subtract + rescan + stores 1.1
+        'bound': 'latency', 'budget_us_one_launch_cycle': 5.85,
+    }
+    out['clean']['small_patch_us_per_cycle'] = round(1e6 / out['clean']['small_patch_cycles_per_s'], 2)
+    # bytes a cycle moves: 12 P patch^2 + tile refresh; only meaningful for big patches
+    cyc_bytes = 12 * P * patch[1] * patch[2] + 4 * P * 1024 * ((patch[1] + 31) // 32 + 1) * ((patch[2] + 31) // 32 + 1)
+    out['clean']['large_patch_GBps'] = round(cyc_bytes * large / 1e9, 1)
+    del cl, pp
 
     # degridder over every chunk of the channel (hot loop of the 2nd+ major cycles with --degrid,
     # frontend.py:128-139): vis -= weights * degrid(model grid)
-    template_d = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed)
-    dg = template_d.instantiate(q, ap, ip, gp, args.vis_block)
-    dg.bind(grid=gridder.buffer('grid'))
     wts = accel.DeviceArray(ctx, (args.vis_block, P), np.float32,
                             tensor=torch.ones((args.vis_block, P), device=ctx.device))
-    dg.bind(weights=wts)
-    dg.ensure_all_bound()
     torch.cuda.synchronize()        # torch filled `wts` on its own stream
-
-    def degrid_all():
-        for uv_c, wp_c, vis_c, n in chunks:
-            dg.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
-            dg.num_vis = n
-            dg._run()
-    degrid_all()
-    q.finish()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        degrid_all()
-    q.finish()
     total = sum(c[3] for c in chunks)
-    out['degrid_Mvis_per_s'] = round(2 * total / (time.perf_counter() - t0) / 1e6, 2)
+    flop_per_vis = 8.0 * args.kernel_width ** 2 * P
+    for arith in ('fp32', 'split_fp16'):
+        dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(
+            q, ap, ip, gp, args.vis_block)
+        dg.bind(grid=grid_buf, weights=wts)
+        dg.ensure_all_bound()
 
-    # direct (DFT) prediction of a 1000-component model over every chunk: the reference's default
-    # predictor when --degrid is not given (frontend.py:113-138, predict.py:419-438)
+        def degrid_all():
+            for uv_c, wp_c, vis_c, n in chunks:
+                dg.bind(uv=uv_c, w_plane=wp_c, vis=vis_c)
+                dg.num_vis = n
+                dg._run()
+        degrid_all()
+        q.finish()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            degrid_all()
+        q.finish()
+        rate = 2 * total / (time.perf_counter() - t0)
+        peak = FP32_MFMA_PEAK_TFLOPS if arith == 'fp32' else F16_MFMA_PEAK_TFLOPS
+        out['degrid_' + arith] = {'Mvis_per_s': round(rate / 1e6, 1),
+                                  'frac': round(flop_per_vis * rate / 1e12 / peak, 4), 'peak': peak}
+        del dg
+
+    # direct (DFT) prediction of a 1000-component model: the reference's default predictor when
+    # --degrid is not given (frontend.py:113-138, predict.py:419-438)
     from katsdpimager_amd import predict
     S = 1000
     pr = predict.PredictTemplate(ctx, np.float32, P).instantiate(q, ip, gp, args.vis_block, S)
@@ -531,21 +548,89 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, chunks):
     return out
 
 
-def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
+def geometry_sweep(args, ctx, q, dev):
+    """Other geometries and input orders, float32 arithmetic, one launch per slice: the
+    reference's default geometry (kernel width 60, frontend.py:325; hundreds of W planes from the
+    default w-step, frontend.py:318) and the orders SURVEY 8d lists."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel, grid
+    out = {}
+    P, G, K = args.polarizations, args.pixels, args.kernel_width
+    n2 = min(args.vis, 16 * args.vis_block)
+
+    def rate(obs2, Kx, arith='fp32', order=None):
+        ip2, gp2, ap2 = synth.make_parameters(obs2, P, Kx)
+        n = obs2.n_vis
+        op = grid.GridderTemplate(ctx, ip2.fixed, gp2.fixed, {'variant': args.variant, 'arith': arith}) \
+            .instantiate(q, ap2, ip2, gp2, n)
+        shape = op.slots['grid'].shape
+        uv, wp, vis = obs2.uv, obs2.w_plane, obs2.vis
+        if order is not None:
+            uv, wp, vis = uv[order].contiguous(), wp[order].contiguous(), vis[order].contiguous()
+        op.bind(grid=accel.DeviceArray(ctx, shape, np.complex64),
+                weights_grid=accel.DeviceArray(ctx, shape, np.float32,
+                                               tensor=torch.ones(shape, device=dev)),
+                uv=accel.DeviceArray(ctx, (n, 4), np.int16, tensor=uv),
+                w_plane=accel.DeviceArray(ctx, (n,), np.int16, tensor=wp),
+                vis=accel.DeviceArray(ctx, (n, P), np.complex64, tensor=vis))
+        op.ensure_all_bound()
+        op.num_vis = n
+        torch.cuda.synchronize()
+        op._run()
+        q.finish()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            op._run()
+        q.finish()
+        return round(reps * n / (time.perf_counter() - t0) / 1e6, 1)
+
+    obs2 = synth.make_observation(G, n2, 256, P, device=dev, seed=5)
+    out['grid_256_planes_Mvis_per_s'] = rate(obs2, K)
+    if K != 60:
+        out['grid_k60_256_planes_Mvis_per_s'] = rate(obs2, 60)
+        out['grid_k60_256_planes_split_fp16_Mvis_per_s'] = rate(obs2, 60, 'split_fp16')
+    del obs2
+    # input orders (same visibilities, W=32): as generated (baseline-major, every baseline's whole
+    # track), loader-shaped (baseline-sorted runs per load block of `dumps` time samples, adjacent
+    # equal cells merged as preprocess.cpp:334-397 does), time-major, shuffled
+    obs3 = synth.make_observation(G, n2, args.w_planes, P, device=dev, seed=6)
+    out['order_baseline_major_Mvis_per_s'] = rate(obs3, K)
+    for name, fn_order in (('loader_blocks', synth.order_loader_blocks),
+                           ('time_major', synth.order_time_major),
+                           ('shuffled', synth.order_shuffled)):
+        o = fn_order(obs3)
+        out['order_%s_Mvis_per_s' % name] = rate(o['obs'], K)
+        if 'note' in o:
+            out['order_%s_note' % name] = o['note']
+    return out
+
+
+def major_cycle_loop(args, ctx, q, obs, extras=False):
     """BASELINE config 5: the per-channel loop of frontend.process_channel (frontend.py:465-585)
-    on the Imaging facade with every chunk resident in HBM: robust weights -> PSF -> 2 major
-    cycles of { grid -> FFT -> noise estimate -> CLEAN minor cycles -> degrid + regrid }.
-    Returns wall-clock seconds per stage (queue drained after each stage)."""
+    on the Imaging facade with the channel resident in HBM and one launch per W-slice: robust
+    weights -> PSF -> 2 major cycles of { grid -> FFT -> noise estimate -> CLEAN minor cycles ->
+    degrid + regrid }.  Wall-clock milliseconds per stage (queue drained after each stage)."""
     import torch
     from katsdpimager_amd import accel, imaging, parameters, weight
+    from katsdpimager_amd import preprocess as _pp
     P, G = args.polarizations, args.pixels
     import synth
     ipd, gpd, apd = synth.make_parameters(obs, P, args.kernel_width, degrid=True)
     cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
     wparm = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
     template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
-    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
+    n = obs.n_vis
+    im = template.instantiate(q, ipd, gpd, n, 0, 2)
     im.ensure_all_bound()
+    vis = torch.where(torch.isfinite(obs.vis.real), obs.vis, torch.zeros_like(obs.vis))
+    chunk = _pp.DeviceChunk(
+        n, accel.DeviceArray(ctx, (n, 4), np.int16, tensor=obs.uv),
+        accel.DeviceArray(ctx, (n,), np.int16, tensor=obs.w_plane),
+        accel.DeviceArray(ctx, (n, P), np.float32, tensor=obs.weights),
+        accel.DeviceArray(ctx, (n, P), np.complex64, tensor=vis))
+    torch.cuda.synchronize()
     times = {}
 
     def timed(name, fn):
@@ -558,26 +643,20 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
 
     def make_weights():
         im.clear_weights()
-        for uv_c, wp_c, vis_c, wt_c, n in chunks_dev:
-            im.bind(uv=uv_c, weights=wt_c)
-            im._weights.grid(n)
+        im.grid_weights_device(chunk)
         return im.finalize_weights()
-
-    from katsdpimager_amd import preprocess as _pp
 
     def grid_pass(field, predict):
         im.clear_grid()
-        for uv_c, wp_c, vis_c, wt_c, n in chunks_dev:
-            # zero-copy coordinates / weights, device-to-device copy of the visibilities; with
-            # streams=2 consecutive chunks alternate between two HIP streams
-            im.set_chunk_device(_pp.DeviceChunk(n, uv_c, wp_c, wt_c, vis_c), field)
-            if predict:
-                im.predict(0.0)
-            im.grid()
+        # zero-copy coordinates / weights, device-to-device copy of the visibilities
+        im.set_chunk_device(chunk, field)
+        if predict:
+            im.predict(0.0)
+        im.grid()
 
     # first use of a kernel loads its code object (milliseconds): not part of a channel's cost
-    uv_c, wp_c, vis_c, wt_c, n = chunks_dev[0]
-    im.set_chunk_device(_pp.DeviceChunk(n, uv_c, wp_c, wt_c, vis_c), 'weights')
+    make_weights()
+    grid_pass('weights', False)
     q.finish()
     timed('weights', make_weights)
     im.clear_dirty()
@@ -604,15 +683,27 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
         vals = timed('clean', lambda: im.clean_cycles(patch, thr, args.clean_cycles - 1))
         minor += 1 + len(vals)
     total = sum(times.values())
-    out = {k + '_s': round(v, 4) for k, v in times.items()}
-    out['total_s'] = round(total, 4)
+    out = {k + '_ms': round(v * 1e3, 3) for k, v in times.items()}
+    out['total_ms'] = round(total * 1e3, 3)
     out['minor_cycles'] = minor
+    out['clean_cycles_per_s'] = round((minor - 2) / times['clean'], 1)
     out['psf_patch'] = list(patch)
+    out['visibilities'] = n
+    out['arith'] = 'fp32'
     del im
+    if extras:
+        out['extras'] = major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm)
+    return out
 
-    # The same channel from raw inputs: device preprocessing into the HBM-resident
-    # store (8f-2), then the store-driven driver katsdpimager_amd.frontend.process_channel.
-    from katsdpimager_amd import frontend, preprocess
+
+def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm):
+    """The same channel from raw inputs: device preprocessing into the HBM-resident
+    store (8f-2), then the store-driven driver katsdpimager_amd.frontend.process_channel; and four
+    channels with 1-4 of them in flight."""
+    import torch
+    from katsdpimager_amd import accel, frontend, imaging, parameters, preprocess
+    P = args.polarizations
+    out = {}
     n = obs.n_vis
     raw_vis = torch.where((obs.uvw[:, 2] < 0)[:, None], torch.conj(obs.vis), obs.vis)
     raw_vis = torch.where(torch.isfinite(raw_vis.real), raw_vis, torch.zeros_like(raw_vis))
@@ -621,57 +712,45 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
     d_vis = accel.DeviceArray(ctx, (1, n, P), np.complex64, tensor=raw_vis[None].contiguous())
     ident = np.identity(P, np.complex64)
     torch.cuda.synchronize()
-    # the collector's buffer size is the user's choice (the reference passes --vis-block); each
-    # buffer is a chain of ~13 small dependent launches, so larger buffers amortise it
-    for rep in range(2):
-        big = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], 16 * args.vis_block)
-        q.finish()
-        t0 = time.perf_counter()
-        big.add(d_uvw, d_wts, d_vis, None, None, ident, None)
-        q.finish()
-        dt_big = time.perf_counter() - t0
-        del big
-    out['preprocess_16x_buffer_Mvis_per_s'] = round(n / dt_big / 1e6, 1)
-    for rep in range(2):            # the first pass warms up the kernels and the allocator
-        coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], args.vis_block)
-        q.finish()
-        t0 = time.perf_counter()
-        coll.add(d_uvw, d_wts, d_vis, None, None, ident, None)
-        q.finish()
-        dt = time.perf_counter() - t0
-        if rep == 0:
-            del coll
+    for label, bs in (('preprocess_16x_buffer_Mvis_per_s', 16 * args.vis_block),
+                      ('preprocess_Mvis_per_s', args.vis_block)):
+        for rep in range(2):            # the first pass warms up the kernels and the allocator
+            coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], bs)
+            q.finish()
+            t0 = time.perf_counter()
+            coll.add(d_uvw, d_wts, d_vis, None, None, ident, None)
+            q.finish()
+            dt = time.perf_counter() - t0
+        out[label] = round(n / dt / 1e6, 1)
     coll.close()
     reader = coll.reader()
-    out['preprocess_Mvis_per_s'] = round(n / dt / 1e6, 1)
     out['preprocess_kept_fraction'] = round(coll.num_output / coll.num_input, 4)
     out['store_MB'] = round(coll.nbytes() / 1e6, 1)
-    im = template.instantiate(q, ipd, gpd, args.vis_block, 0, 2, streams=args.streams)
+    block = max(reader.len(0, s) for s in range(reader.num_w_slices(0)))
+    im = template.instantiate(q, ipd, gpd, block, 0, 2)
     im.ensure_all_bound()
     for rep in range(2):
         q.finish()
         t0 = time.perf_counter()
         stats = frontend.process_channel(reader, 0, im, ipd, gpd, cp, wparm.weight_type,
-                                         args.vis_block, 2, True)
+                                         block, 2, True)
         q.finish()
         dt = time.perf_counter() - t0
-    out['store_driver_total_s'] = round(dt, 4)
+    out['store_driver_total_ms'] = round(dt * 1e3, 3)
     out['store_driver_minor_cycles'] = int(stats['minor']) if stats else None
-
+    del im
     # Four channels (here: the same stored channel imaged four times) with 1, 2, 3 and 4 of them in
-    # flight on their own streams; CLEAN thresholds forced low so that every major
-    # cycle runs its full 1000 minor cycles, as in the staged loop above.
+    # flight on their own streams; CLEAN thresholds forced low so that every major cycle runs its
+    # full 1000 minor cycles, as in the staged loop above.
     cp2 = parameters.CleanParameters(args.clean_cycles, 0.1, 1.0, 0.0, 0, 0.01, 0.5, 0.02)
-    template2 = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp2)
+    template2 = imaging.ImagingTemplate(ctx, template.array_parameters, ipd.fixed, wparm, gpd.fixed, cp2)
     jobs = []
     for _ in range(4):
         qi = ctx.create_command_queue()
-        # one stream per channel: the device maps streams onto four hardware queues, and a
-        # channel whose chain of CLEAN launches shares a queue with another one waits for it
-        imi = template2.instantiate(qi, ipd, gpd, args.vis_block, 0, 2, streams=1)
+        imi = template2.instantiate(qi, ipd, gpd, block, 0, 2)
         imi.ensure_all_bound()
         jobs.append(dict(reader=reader, rel_channel=0, imager=imi, image_p=ipd, grid_p=gpd,
-                         clean_p=cp2, weight_type=wparm.weight_type, vis_block=args.vis_block,
+                         clean_p=cp2, weight_type=wparm.weight_type, vis_block=block,
                          major=2, degrid=True))
     frontend.process_channels(jobs, workers=4)          # warm-up (graph capture per imager)
     for workers in (1, 2, 3, 4):
@@ -679,19 +758,48 @@ def major_cycle_loop(args, ctx, q, obs, ip, gp, ap, chunks_dev):
         t0 = time.perf_counter()
         res = frontend.process_channels(jobs, workers=workers)
         torch.cuda.synchronize()
-        out['four_channels_%d_in_flight_s' % workers] = round(time.perf_counter() - t0, 4)
+        out['four_channels_%d_in_flight_ms' % workers] = round((time.perf_counter() - t0) * 1e3, 2)
     out['four_channels_minor_cycles'] = [int(r['minor']) for r in res]
+    return out
+
+
+def extras(args, ctx, q, obs, ip, gp, ap, template, grid_buf, wg, uv_all, wp_all, vis_all):
+    """PCIe-inclusive gridding (never `value`): the reference-style host path, every chunk copied
+    from host memory (uv, w_plane, vis: 18 B per visibility at P=1) before it is gridded."""
+    vb = args.vis_block
+    out = {}
+    host_fn = template.instantiate(q, ap, ip, gp, vb)
+    host_fn.bind(grid=grid_buf, weights_grid=wg)
+    host_fn.ensure_all_bound()
+    h_uv = uv_all[:vb].cpu().numpy()
+    h_wp = wp_all[:vb].cpu().numpy()
+    h_vis = vis_all[:vb].cpu().numpy()
+    host_fn.num_vis = vb
+
+    def host_chunk():
+        host_fn.buffer('uv').set(q, h_uv)
+        host_fn.buffer('w_plane').set(q, h_wp)
+        host_fn.buffer('vis').set(q, h_vis)
+        host_fn._run()
+    host_chunk()
+    q.finish()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        host_chunk()
+    q.finish()
+    out['grid_host_chunks_Mvis_per_s'] = round(8 * vb / (time.perf_counter() - t0) / 1e6, 1)
     return out
 
 
 def cpu_baseline(args, obs, gridder, wg, Gg):
     """The oracle's C restatement of the reference's numba `_grid` loop (grid.py:1032-1052),
-    single thread (the reference CPU path is single-threaded), on a bounded sample."""
+    single thread (the reference CPU path is single-threaded), on a bounded sample: the median of
+    `--cpu-passes` timed passes over the same `--cpu-sample` visibilities after one warm-up."""
     from oracle import kimg_oracle as orc
     S = min(args.cpu_sample, obs.n_vis)
-    # a sample spread over the whole track set: every (n_vis // S)-block contributes a run
+    # a sample spread over the whole track set: 64 runs of consecutive visibilities
     runs = 64
-    run_len = S // runs
+    run_len = max(S // runs, 1)
     starts = np.linspace(0, obs.n_vis - run_len, runs).astype(np.int64)
     idx = (starts[:, None] + np.arange(run_len)[None, :]).reshape(-1)
     import torch
@@ -703,22 +811,24 @@ def cpu_baseline(args, obs, gridder, wg, Gg):
     P = vis.shape[1]
     g = np.zeros((P, Gg, Gg), np.complex64)
     wgrid = wg.tensor.cpu().numpy()
-    orc.grid(kernel, g, wgrid, uv[:1000, :2].copy(), uv[:1000, 2:].copy(), wp[:1000], vis[:1000])
-    t0 = time.perf_counter()
-    orc.grid(kernel, g, wgrid, np.ascontiguousarray(uv[:, :2]), np.ascontiguousarray(uv[:, 2:]),
-             wp, vis)
-    dt = time.perf_counter() - t0
+    uv01 = np.ascontiguousarray(uv[:, :2])
+    uv23 = np.ascontiguousarray(uv[:, 2:])
+    orc.grid(kernel, g, wgrid, uv01[:20000], uv23[:20000], wp[:20000], vis[:20000])     # warm-up
+    times = []
+    for _ in range(max(args.cpu_passes, 1)):
+        t0 = time.perf_counter()
+        orc.grid(kernel, g, wgrid, uv01, uv23, wp, vis)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     out = {'value': round(len(idx) / dt / 1e6, 4), 'unit': 'Mvis/s', 'cores': 1, 'kind': 'port',
-           'sample': '{} visibilities ({} runs of {} consecutive samples spread over the '
-                     'channel), same grid / kernel table, {:.1f} s'.format(len(idx), runs,
-                                                                           run_len, dt)}
+           'sample': 'median of {} passes over {} visibilities ({} runs of {} consecutive samples '
+                     'spread over the channel), same grid / kernel table, {:.1f} s per pass'.format(
+                         len(times), len(idx), runs, run_len, dt)}
     # A stricter comparator than the reference itself (which is single-threaded): the same loop
     # on every host core, one private grid per thread (ctypes releases the GIL), same sample.
     import concurrent.futures
     threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     threads = max(1, min(threads, runs, 16))        # the host share that goes with one GPU
-    uv01 = np.ascontiguousarray(uv[:, :2])
-    uv23 = np.ascontiguousarray(uv[:, 2:])
     bounds = np.linspace(0, runs, threads + 1).astype(np.int64) * run_len
     grids = [np.zeros((P, Gg, Gg), np.complex64) for _ in range(threads)]
 
@@ -732,6 +842,55 @@ def cpu_baseline(args, obs, gridder, wg, Gg):
     out['all_cores'] = {'value': round(len(idx) / dt_all / 1e6, 3), 'cores': threads,
                         'note': 'not the reference: its CPU path is single-threaded numba'}
     return out
+
+
+def rehearse(args):
+    """The multi-process skeleton of main() on CPU tensors (gloo): same rendezvous, broadcast,
+    channel assignment, barrier-bracketed timing, max-over-ranks and one JSON line from rank 0 --
+    with a sleep where the device work would be.  `value` is meaningless; `rehearsal` says so."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    from katsdpimager_amd import parallel
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group('gloo')
+    if args.gpus != world:
+        raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch with torchrun'.format(
+            args.gpus, world))
+    shared = {'baselines': torch.from_numpy(synth.baselines_equatorial()) if rank == 0
+              else torch.empty((2016, 3), dtype=torch.float64)}
+    parallel.broadcast_shared(shared, src=0)
+    assert torch.equal(shared['baselines'], torch.from_numpy(synth.baselines_equatorial()))
+    channel = rank_channel(rank, world)
+    n_vis = min(args.vis, 20000)
+    obs = synth.make_observation(256, n_vis, 8, 1, device='cpu', cover=0.30,
+                                 channel_scale=channel_scale(channel), seed=2 + rank)
+    checksum = float(obs.uv.to(torch.float64).abs().sum())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    stats = parallel.gather_stats([float(channel), checksum])
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'Mvis/s gridded (4096^2 grid, 32 W-planes)',
+            'value': round(world * n_vis / (elapsed / args.steps) / 1e6, 3), 'unit': 'Mvis/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'rehearsal': 'no device work: plumbing only',
+            'config': {'workload': 'rehearsal', 'channels': world,
+                       'band_channels': [int(c) for c in stats[:, 0].tolist()]}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

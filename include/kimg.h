@@ -29,11 +29,31 @@
 extern "C" {
 #endif
 
-#define KIMG_VERSION 1
+#define KIMG_VERSION 2
 
 #define KIMG_EINVAL (-10001)      /* bad argument (null pointer, negative size ...) */
 #define KIMG_EUNSUPPORTED (-10002) /* parameter combination not supported by this build */
 #define KIMG_EWORKSPACE (-10003)   /* workspace too small */
+
+/* Arithmetic of the gridder / degridder matrix instructions (argument `arith`):
+ *   KIMG_ARITH_FP32        v_mfma_f32_32x32x2_f32 -- every product and sum in float32, bit-identical
+ *                          to the fmaf chain of the reference's kernels (grid.py:1049-1052).  Default.
+ *   KIMG_ARITH_SPLIT_FP16  operands carried as fp16 (hi, lo) pairs (22 significant bits, lo*lo
+ *                          dropped), two visibilities per v_mfma_f32_32x32x16_f16, float32
+ *                          accumulation.  Faster, narrower than the reference's arithmetic: opt-in.
+ * The generic (non-MFMA) kernels always compute in float32 and ignore it. */
+#define KIMG_ARITH_FP32 0
+#define KIMG_ARITH_SPLIT_FP16 1
+
+/* Kernel choice of kimg_grid / kimg_degrid (argument `variant`) */
+#define KIMG_VARIANT_AUTO 0     /* MFMA window kernel when the parameters allow it */
+#define KIMG_VARIANT_GENERIC 1  /* one wave per visibility, any kernel width */
+#define KIMG_VARIANT_MFMA 2     /* MFMA window kernel or KIMG_EUNSUPPORTED */
+
+/* Form of the device-resident CLEAN loop (argument `form` of kimg_clean_cycles) */
+#define KIMG_CLEAN_FORM_AUTO 0      /* one launch per cycle when the patch's lattice blocks fit the CUs */
+#define KIMG_CLEAN_FORM_TWO_LAUNCH 1
+#define KIMG_CLEAN_FORM_ONE_LAUNCH 2    /* falls back to two launches when the patch is too large */
 
 #define KIMG_CLEAN_I 0      /* clean.py:29 */
 #define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */
@@ -71,9 +91,9 @@ int kimg_kernel_table(void *table, const double *ws, int w_planes, int kernel_wi
  *                   oversample, kernel_width) bytes (0 unless the kernel table is too large for
  *                   LDS -- more than 512 rows w_planes*oversample for widths <= 32, 256 for 33..64
  *                   -- in which case a zero-padded copy of it is built there on every call)
- *   variant         0 = automatic; 1 = generic scatter kernel (any kernel width); 2 = MFMA window
- *                   kernel (kernel_width <= 64), KIMG_EUNSUPPORTED otherwise.
- *                   Automatic = MFMA when supported.
+ *   variant         KIMG_VARIANT_*: automatic = MFMA window kernel when supported (kernel_width
+ *                   <= 64), else the generic scatter kernel
+ *   arith           KIMG_ARITH_* (above); anything else is KIMG_EINVAL
  *   Out-of-range coordinates (footprint outside the grid, sub_uv >= oversample, w_plane >=
  *   w_planes) contribute nothing instead of faulting.
  */
@@ -84,18 +104,19 @@ int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int 
               const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
               const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
               const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
-              void *workspace, size_t workspace_bytes, int variant, void *stream);
+              void *workspace, size_t workspace_bytes, int variant, int arith, void *stream);
 
 /* ---- degridding: grid.py:985-1029 Degridder.static_run/_run + degrid.mako:77-199
  * vis[r][p] -= weights[r][p] * sum_{j,k} kern[w][sub_v][j]*kern[w][sub_u][k]*grid[p][v0+j][u0+k]
  *   weights  float32 [N][P] statistical weights
+ *   variant, arith as for kimg_grid
  */
 int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
                 int num_polarizations,
                 const int16_t *uv, const int16_t *w_plane, const float *weights, void *vis,
                 int64_t num_vis,
                 const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
-                void *workspace, size_t workspace_bytes, void *stream);
+                void *workspace, size_t workspace_bytes, int variant, int arith, void *stream);
 /* Device scratch kimg_degrid needs (0 unless the kernel table is too large for LDS; then a padded
  * copy of it is built there on every call, as for kimg_grid). */
 size_t kimg_degrid_workspace_bytes(int num_polarizations, int w_planes, int oversample,
@@ -287,6 +308,7 @@ int kimg_noise_est(const float *image, int64_t row_stride, int64_t pol_stride,
  *          call (loop state, and for the one-launch-per-cycle form used with small PSF patches
  *          the per-tile peak pixel values and the tile records in flight between cycles)
  *   log    device float32 [max_cycles][3 + P]: (metric, y, x as float bits, loop_gain*pixel[p])
+ *   form   KIMG_CLEAN_FORM_*
  *   After the stream is synchronised, ((int32*)state)[0] holds the number of cycles done
  *   (stops early when the peak metric < threshold, clean.py:879-880).
  */
@@ -297,7 +319,7 @@ int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t po
                       int psf_width, int psf_height, int patch_width, int patch_height,
                       int border, int mode, float loop_gain, float threshold,
                       float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
-                      int max_cycles, void *state, float *log, void *stream);
+                      int max_cycles, int form, void *state, float *log, void *stream);
 
 #ifdef __cplusplus
 }

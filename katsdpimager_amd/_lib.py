@@ -18,13 +18,15 @@ I = c_int
 L = c_int64
 F = c_float
 
+VERSION = 2     # KIMG_VERSION of include/kimg.h
+
 PROTOTYPES = {
     'kimg_version': (c_int, []),
     'kimg_error_string': (c_char_p, [I]),
     'kimg_kernel_table': (c_int, [P, P, I, I, I, I, c_double, c_double, c_double, P]),
     'kimg_grid_workspace_bytes': (c_size_t, [L, I, I, I, I]),
-    'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, P]),
-    'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, P]),
+    'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
+    'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
     'kimg_degrid_workspace_bytes': (c_size_t, [I, I, I, I]),
     'kimg_predict': (c_int, [P, P, P, P, P, P, L, I, I, I, F, F, F, P]),
     'kimg_grid_weights': (c_int, [P, L, L, I, I, I, P, P, L, P]),
@@ -61,7 +63,7 @@ PROTOTYPES = {
     'kimg_noise_est': (c_int, [P, L, L, I, I, I, I, F, P, P, P]),
     'kimg_clean_state_bytes': (c_size_t, [I, I, I]),
     'kimg_clean_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, F,
-                                  P, P, I, I, I, P, P, P]),
+                                  P, P, I, I, I, I, P, P, P]),
 }
 
 
@@ -102,7 +104,7 @@ def lib():
             raise KimgLibraryError('libkimg.so lacks symbol ' + name) from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if handle.kimg_version() != 1:
+    if handle.kimg_version() != VERSION:
         raise KimgLibraryError('libkimg.so version mismatch')
     _lib = handle
     return _lib

@@ -123,7 +123,7 @@ class DeviceArray:
     """Dense device array.  ``padded_shape`` always equals ``shape`` here (the HIP
     kernels take explicit strides, so no padding is ever required)."""
 
-    def __init__(self, context, shape, dtype, padded_shape=None, tensor=None):
+    def __init__(self, context, shape, dtype, padded_shape=None, tensor=None, queue=None):
         torch = _torch()
         self.context = context
         self.shape = tuple(int(s) for s in shape)
@@ -132,10 +132,24 @@ class DeviceArray:
         if tensor is None:
             tensor = torch.empty(self.shape, dtype=torch_dtype(dtype), device=context.device)
         self.tensor = tensor
+        self._streams = set()
+        if queue is not None:
+            self.used_on(queue)
 
     @property
     def ptr(self):
         return self.tensor.data_ptr()
+
+    def used_on(self, command_queue):
+        """Tell torch's caching allocator that `command_queue`'s stream uses this memory (the
+        kernels of libkimg see raw pointers, so torch cannot know): when the array is freed, its
+        block is then not handed out again before the work enqueued on that stream so far has
+        finished.  Cheap after the first call per stream."""
+        key = command_queue.handle
+        if key not in self._streams:
+            self._streams.add(key)
+            if self.tensor.is_cuda:
+                self.tensor.record_stream(command_queue.stream)
 
     @property
     def buffer(self):
@@ -155,6 +169,7 @@ class DeviceArray:
         ary = np.asarray(ary)
         if ary.shape != self.shape:
             raise ValueError('shape mismatch: {} vs {}'.format(ary.shape, self.shape))
+        self.used_on(command_queue)
         with _torch().cuda.stream(command_queue.stream):
             self.tensor.copy_(self._as_host_tensor(ary), non_blocking=False)
 
@@ -162,6 +177,7 @@ class DeviceArray:
         self.set(command_queue, ary)
 
     def get(self, command_queue, ary=None):
+        self.used_on(command_queue)
         with _torch().cuda.stream(command_queue.stream):
             host = self.tensor.cpu().numpy()
         if self.dtype == np.uint32:
@@ -175,6 +191,7 @@ class DeviceArray:
         return self.get(command_queue, ary)
 
     def zero(self, command_queue):
+        self.used_on(command_queue)
         with _torch().cuda.stream(command_queue.stream):
             self.tensor.zero_()
 
@@ -183,6 +200,7 @@ class DeviceArray:
         src = np.asarray(ary)[ary_region]
         if self.dtype == np.uint32:
             src = src.view(np.int32)
+        self.used_on(command_queue)
         with torch.cuda.stream(command_queue.stream):
             dst = self.tensor[device_region]
             src_t = torch.from_numpy(np.ascontiguousarray(src)) if not src.flags.c_contiguous \
@@ -190,11 +208,14 @@ class DeviceArray:
             dst.copy_(src_t.reshape(dst.shape), non_blocking=not blocking)
 
     def get_region(self, command_queue, ary, device_region, ary_region, blocking=True):
+        self.used_on(command_queue)
         with _torch().cuda.stream(command_queue.stream):
             host = self.tensor[device_region].cpu().numpy()
         np.asarray(ary)[ary_region] = host.reshape(np.asarray(ary)[ary_region].shape)
 
     def copy_region(self, command_queue, dest, src_region, dest_region):
+        self.used_on(command_queue)
+        dest.used_on(command_queue)
         with _torch().cuda.stream(command_queue.stream):
             d = dest.tensor[dest_region]
             d.copy_(self.tensor[src_region].reshape(d.shape))
@@ -306,6 +327,8 @@ class Operation:
     def bind(self, **kwargs):
         for name, buffer in kwargs.items():
             self.slots[name].bind(buffer)
+            if buffer is not None:
+                buffer.used_on(self.command_queue)
 
     def buffer(self, name):
         return self.slots[name].buffer
@@ -313,7 +336,7 @@ class Operation:
     def ensure_bound(self, name):
         slot = self.slots[name]
         if not slot.is_bound():
-            slot.allocate(self.allocator)
+            slot.allocate(self.allocator).used_on(self.command_queue)
 
     def ensure_all_bound(self):
         for name in self.slots:

@@ -169,8 +169,8 @@ class NoiseEst(accel.Operation):
         if self._scratch is None:
             ctx = self.command_queue.context
             self._scratch = accel.DeviceArray(
-                ctx, (lib().kimg_noise_est_scratch_bytes() // 4,), np.uint32)
-            self._result = accel.DeviceArray(ctx, (1,), np.float32)
+                ctx, (lib().kimg_noise_est_scratch_bytes() // 4,), np.uint32, queue=self.command_queue)
+            self._result = accel.DeviceArray(ctx, (1,), np.float32, queue=self.command_queue)
         rc = lib().kimg_noise_est(*_image_args(dirty), self.border_pixels,
                                   float(np.float32(_MEDIAN_TO_RMS)), self._scratch.ptr,
                                   self._result.ptr, self.command_queue.handle)
@@ -337,10 +337,18 @@ class _SubtractPsf(accel.Operation):
         check(rc, 'kimg_subtract_psf')
 
 
+CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2}     # KIMG_CLEAN_FORM_*
+
+
 class CleanTemplate:
-    """clean.py:729-753."""
-    def __init__(self, context, clean_parameters, dtype, num_polarizations):
+    """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'}``, the
+    form of the device-resident loop of :meth:`Clean.run_cycles` (results are identical)."""
+    def __init__(self, context, clean_parameters, dtype, num_polarizations, tuning=None):
         types.require_float32(dtype, 'CleanTemplate')
+        tuning = tuning or {}
+        if set(tuning) - {'form'} or tuning.get('form', 'auto') not in CLEAN_FORMS:
+            raise ValueError('bad CleanTemplate tuning {}'.format(tuning))
+        self.form = CLEAN_FORMS[tuning.get('form', 'auto')]
         self.context = context
         self.clean_parameters = clean_parameters
         self.dtype = np.dtype(dtype)
@@ -387,7 +395,7 @@ class Clean(accel.OperationSequence):
         super().__init__(command_queue, ops, compounds, allocator=allocator)
         self._state = accel.DeviceArray(
             command_queue.context, (lib().kimg_clean_state_bytes(image_shape[0], tile_shape[1], tile_shape[0]) // 4,),
-            np.int32)
+            np.int32, queue=command_queue)
         self._log = None
 
     def _run(self):
@@ -429,15 +437,15 @@ class Clean(accel.OperationSequence):
         cp = self.template.clean_parameters
         if self._log is None or self._log.shape[0] < max_cycles:
             self._log = accel.DeviceArray(self.command_queue.context, (max_cycles, 3 + P),
-                                          np.float32)
+                                          np.float32, queue=self.command_queue)
         tile_max = self.buffer('tile_max')
         rc = lib().kimg_clean_cycles(
             dirty.ptr, self.buffer('model').ptr, W, H * W, W, H, P,
             psf.ptr, psf.shape[2], psf.shape[1] * psf.shape[2], psf.shape[2], psf.shape[1],
             psf_patch[2], psf_patch[1], self._update_tiles.border_pixels, cp.mode,
             cp.loop_gain, threshold, tile_max.ptr, self.buffer('tile_pos').ptr,
-            tile_max.shape[1], tile_max.shape[0], max_cycles, self._state.ptr, self._log.ptr,
-            self.command_queue.handle)
+            tile_max.shape[1], tile_max.shape[0], max_cycles, self.template.form,
+            self._state.ptr, self._log.ptr, self.command_queue.handle)
         check(rc, 'kimg_clean_cycles')
         count = int(self._state.get(self.command_queue)[0])
         log = self._log.get(self.command_queue)[:count]

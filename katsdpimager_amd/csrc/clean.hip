@@ -249,7 +249,10 @@ struct clean_state {
     int count;          // cycles completed
     int done;           // threshold reached (or `limit` cycles done)
     int limit;          // maximum number of cycles for this call
+    float threshold;    // stop when the peak metric falls below it (kept here, not in the kernel
+                        // arguments, so that one captured graph serves every threshold)
     int pos_y, pos_x;
+    int pad[2];
     float scale[4];     // loop_gain * pixel at the current peak
 };
 
@@ -257,14 +260,15 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void cycle_find_peak_kernel(
     const float *__restrict__ dirty, float *__restrict__ model, int64_t row_stride,
     int64_t pol_stride, int P, const float *__restrict__ tile_max,
-    const int32_t *__restrict__ tile_pos, int num_tiles, float loop_gain, float threshold,
+    const int32_t *__restrict__ tile_pos, int num_tiles, float loop_gain,
     clean_state *__restrict__ state, float *__restrict__ log)
 {
     // The kernel is a chain of dependent memory round trips; keep it short: the state words are
     // fetched together with the tile maxima (not before them), and the pixel and model values of
     // all polarizations are fetched together before anything is stored.
-    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, -
+    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, threshold
     const int count = st.x, done = st.y, limit = st.z;
+    const float threshold = __int_as_float(st.w);
     float value;
     const int t = peak_tile(tile_max, num_tiles, value);
     const int p = threadIdx.x;          // one thread per polarization from here on
@@ -306,12 +310,11 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
     const clean_state *__restrict__ state)
 {
     // one round trip for all the state words (they share a cache line)
-    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, pos_y
-    const int done = st.y, py = st.w;
-    const int px = state->pos_x;
-    float scale[4];
-    for (int p = 0; p < 4; p++)
-        scale[p] = state->scale[p];
+    const int4 st = *reinterpret_cast<const int4 *>(state);    // count, done, limit, threshold
+    const int2 pos = *reinterpret_cast<const int2 *>(&state->pos_y);
+    const int done = st.y, py = pos.x, px = pos.y;
+    const float4 sc = *reinterpret_cast<const float4 *>(state->scale);
+    const float scale[4] = {sc.x, sc.y, sc.z, sc.w};
     if (done)
         return;
     const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
@@ -419,7 +422,8 @@ struct delta_t {
 };
 
 struct fused_state {
-    int count, done, limit, unused;
+    int count, done, limit;
+    float threshold;
     int pad[12];
 };
 
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     float *dirty, float *model, int64_t row_stride, int64_t pol_stride, int width, int height,
     int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
     int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
-    int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain, float threshold,
+    int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain,
     fused_scratch *scratch, int parity, float *log)
 {
     __shared__ key_t s_keys[16];
@@ -567,13 +571,14 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     // spans fewer than 32 tiles either way, so a cycle rewrites at most one tile per owner: the
     // delta table has one slot per thread and needs no search, and `owner_best` (each owner's best
     // two tiles) turns into the owner's candidate without touching the tile maxima.
-    const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, -
+    const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, threshold
     const int count = st.x, done = st.y, limit = st.z;
+    const float threshold = __int_as_float(st.w);
     const delta_t d = din[tid];
     const owner_best_t ob = scratch->owner_best[tid];
     if (done) {
         if (keeper && tid == 0)
-            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
+            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, st.w);
         return;
     }
     const bool live = d.tag == count + 1;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     const float value = __uint_as_float((unsigned) (best >> 32));
     if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
         if (keeper && tid == 0)
-            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, 0);
+            *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, st.w);
         return;
     }
     if (mykey == best) {        // exactly one thread: every tile has one owner
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
                 entry[0] = value;
                 entry[1] = __int_as_float(py);
                 entry[2] = __int_as_float(px);
-                *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, 0);
+                *reinterpret_cast<int4 *>(next) = make_int4(count + 1, 0, limit, st.w);
             }
             entry[3 + tid] = scale[tid];
             *mp = mod + scale[tid];                                 // clean.py:1047
@@ -995,9 +1000,10 @@ extern "C" size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int
 
 namespace {
 
-__global__ void init_state_kernel(clean_state *state, int limit)
+__global__ void init_state_kernel(clean_state *state, int limit, float threshold)
 {
     state->limit = limit;
+    state->threshold = threshold;
 }
 
 struct cycle_args {
@@ -1007,7 +1013,7 @@ struct cycle_args {
     const float *psf;
     int64_t psf_row_stride, psf_pol_stride;
     int psf_width, psf_height, patch_width, patch_height, border, mode;
-    float loop_gain, threshold;
+    float loop_gain;
     float *tile_max;
     int32_t *tile_pos;
     int tiles_x, tiles_y;
@@ -1029,19 +1035,19 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
                 a.dirty, a.model, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf,
                 a.psf_row_stride, a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width,
                 a.patch_height, a.border, a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y,
-                a.loop_gain, a.threshold, fs, index & 1, a.log);
+                a.loop_gain, fs, index & 1, a.log);
         else
             cycle_fused_kernel<KIMG_CLEAN_SUMSQ><<<g, 1024, 0, s>>>(
                 a.dirty, a.model, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf,
                 a.psf_row_stride, a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width,
                 a.patch_height, a.border, a.tile_max, a.tile_pos, a.tiles_x, a.tiles_y,
-                a.loop_gain, a.threshold, fs, index & 1, a.log);
+                a.loop_gain, fs, index & 1, a.log);
         return kimg_launch_status();
     }
     if (a.mode == KIMG_CLEAN_I) {
         cycle_find_peak_kernel<KIMG_CLEAN_I><<<1, 1024, 0, s>>>(
             a.dirty, a.model, a.row_stride, a.pol_stride, a.P, a.tile_max, a.tile_pos, num_tiles,
-            a.loop_gain, a.threshold, a.state, a.log);
+            a.loop_gain, a.state, a.log);
         cycle_subtract_update_kernel<KIMG_CLEAN_I><<<g, 256, 0, s>>>(
             a.dirty, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf, a.psf_row_stride,
             a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width, a.patch_height, a.border,
@@ -1049,7 +1055,7 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
     } else {
         cycle_find_peak_kernel<KIMG_CLEAN_SUMSQ><<<1, 1024, 0, s>>>(
             a.dirty, a.model, a.row_stride, a.pol_stride, a.P, a.tile_max, a.tile_pos, num_tiles,
-            a.loop_gain, a.threshold, a.state, a.log);
+            a.loop_gain, a.state, a.log);
         cycle_subtract_update_kernel<KIMG_CLEAN_SUMSQ><<<g, 256, 0, s>>>(
             a.dirty, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf, a.psf_row_stride,
             a.psf_pol_stride, a.psf_width, a.psf_height, a.patch_width, a.patch_height, a.border,
@@ -1062,23 +1068,40 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 // launch-bound, and replaying a captured graph costs far less host time than 2 launches
 // per cycle.  The device-side `limit` makes surplus cycles of the last replay no-ops.
 constexpr int GRAPH_CYCLES = 64;
-constexpr int GRAPH_CACHE = 16;     // argument sets (channels in flight x patch sizes)
+constexpr int GRAPH_CACHE = 32;     // argument sets (channels in flight x patch sizes)
 
 struct graph_entry {
     bool valid;
+    int users;              // calls that hold `exec` and have not finished enqueuing its replays
     cycle_args args;
     hipGraphExec_t exec;
+    hipEvent_t last_use;    // recorded after the last replay enqueued by a finished call
+    bool used;
 };
 graph_entry graph_cache[GRAPH_CACHE];
-int graph_next = 0;
 std::mutex graph_mutex;         // channels imaged concurrently share the cache
 
-hipGraphExec_t cycles_graph(const cycle_args &a, hipStream_t s)
+// The cached (or newly captured) graph for `a`; the entry stays pinned until graph_release().
+// An entry is only evicted when no call is using it and the replays enqueued from it have
+// completed (its event has fired), so a graph is never destroyed while it is in flight.
+graph_entry *cycles_graph(const cycle_args &a, hipStream_t s)
 {
     std::lock_guard<std::mutex> lock(graph_mutex);
     for (int i = 0; i < GRAPH_CACHE; i++)
-        if (graph_cache[i].valid && memcmp(&graph_cache[i].args, &a, sizeof(a)) == 0)
-            return graph_cache[i].exec;
+        if (graph_cache[i].valid && memcmp(&graph_cache[i].args, &a, sizeof(a)) == 0) {
+            graph_cache[i].users++;
+            return &graph_cache[i];
+        }
+    graph_entry *slot = nullptr;
+    for (int i = 0; i < GRAPH_CACHE && !slot; i++)
+        if (!graph_cache[i].valid)
+            slot = &graph_cache[i];
+    for (int i = 0; i < GRAPH_CACHE && !slot; i++)
+        if (graph_cache[i].users == 0
+            && (!graph_cache[i].used || hipEventQuery(graph_cache[i].last_use) == hipSuccess))
+            slot = &graph_cache[i];
+    if (!slot)
+        return nullptr;             // every entry busy: the caller enqueues plain launches
     hipGraph_t graph;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return nullptr;
@@ -1092,14 +1115,26 @@ hipGraphExec_t cycles_graph(const cycle_args &a, hipStream_t s)
     (void) hipGraphDestroy(graph);
     if (e != hipSuccess)
         return nullptr;
-    graph_entry &slot = graph_cache[graph_next];
-    graph_next = (graph_next + 1) % GRAPH_CACHE;
-    if (slot.valid)
-        (void) hipGraphExecDestroy(slot.exec);
-    slot.valid = true;
-    slot.args = a;
-    slot.exec = exec;
-    return exec;
+    if (slot->valid)
+        (void) hipGraphExecDestroy(slot->exec);
+    else if (hipEventCreateWithFlags(&slot->last_use, hipEventDisableTiming) != hipSuccess) {
+        (void) hipGraphExecDestroy(exec);
+        return nullptr;
+    }
+    slot->valid = true;
+    slot->used = false;
+    slot->users = 1;
+    slot->args = a;
+    slot->exec = exec;
+    return slot;
+}
+
+void graph_release(graph_entry *entry, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(graph_mutex);
+    (void) hipEventRecord(entry->last_use, s);
+    entry->used = true;
+    entry->users--;
 }
 
 } // namespace
@@ -1110,25 +1145,24 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                                  int psf_width, int psf_height, int patch_width, int patch_height,
                                  int border, int mode, float loop_gain, float threshold,
                                  float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
-                                 int max_cycles, void *state, float *log, void *stream)
+                                 int max_cycles, int form, void *state, float *log, void *stream)
 {
     KIMG_CHECK_ARG(dirty && model && psf && tile_max && tile_pos && state && log);
     KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && max_cycles >= 0);
     KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
+    KIMG_CHECK_ARG(form == KIMG_CLEAN_FORM_AUTO || form == KIMG_CLEAN_FORM_TWO_LAUNCH
+                   || form == KIMG_CLEAN_FORM_ONE_LAUNCH);
     hipStream_t s = (hipStream_t) stream;
     // one launch per cycle when the patch touches few lattice blocks (every workgroup then
-    // repeats the global peak search); KIMG_CLEAN_FUSED=0 forces the two-launch form
-    const char *fenv = getenv("KIMG_CLEAN_FUSED");
+    // repeats the global peak search)
     const int bx = kimg_divup(patch_width, TILE) + 1, by = kimg_divup(patch_height, TILE) + 1;
-    const char *benv = getenv("KIMG_CLEAN_FUSED_BLOCKS");       // timing experiments only
-    const int max_blocks = benv ? atoi(benv) : FUSED_MAX_BLOCKS;
-    const bool fused = bx * (by + 1) <= max_blocks && bx <= 32 && by <= 32
+    const bool fused = bx * (by + 1) <= FUSED_MAX_BLOCKS && bx <= 32 && by <= 32
                        && kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) <= FUSED_MAX_SLOTS
-                       && !(fenv && fenv[0] == '0');
+                       && form != KIMG_CLEAN_FORM_TWO_LAUNCH;
     KIMG_HIP(hipMemsetAsync(state, 0, sizeof(fused_scratch), s));
-    init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(state), max_cycles);
+    init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(state), max_cycles, threshold);
     if (fused)
         tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
             dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
@@ -1143,15 +1177,19 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     a.psf_row_stride = psf_row_stride; a.psf_pol_stride = psf_pol_stride;
     a.psf_width = psf_width; a.psf_height = psf_height; a.patch_width = patch_width;
     a.patch_height = patch_height; a.border = border; a.mode = mode; a.loop_gain = loop_gain;
-    a.threshold = threshold; a.tile_max = tile_max; a.tile_pos = tile_pos; a.tiles_x = tiles_x;
+    a.tile_max = tile_max; a.tile_pos = tile_pos; a.tiles_x = tiles_x;
     a.tiles_y = tiles_y; a.state = static_cast<clean_state *>(state); a.log = log;
     a.fused = fused;
     int done = 0;
     if (max_cycles >= GRAPH_CYCLES / 2) {
-        hipGraphExec_t exec = cycles_graph(a, s);
-        if (exec) {
-            for (; done < max_cycles; done += GRAPH_CYCLES)
-                KIMG_HIP(hipGraphLaunch(exec, s));
+        graph_entry *entry = cycles_graph(a, s);
+        if (entry) {
+            hipError_t e = hipSuccess;
+            for (; done < max_cycles && e == hipSuccess; done += GRAPH_CYCLES)
+                e = hipGraphLaunch(entry->exec, s);
+            graph_release(entry, s);
+            if (e != hipSuccess)
+                return -(int) e;
             done = max_cycles;
         }
     }

@@ -625,8 +625,8 @@ bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_
 size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
 {
     if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width)
-        || (tables_fit_lds(w_planes, oversample, kernel_width) && !getenv("KIMG_DEGRID_TABLE")))
-        return 0;       // (with the experiment variable set, scratch is reserved either way)
+        || tables_fit_lds(w_planes, oversample, kernel_width))
+        return 0;
     return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
 
@@ -634,10 +634,10 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                      int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
                      int w_planes, int oversample, int kernel_width, void *workspace,
-                     size_t workspace_bytes, hipStream_t stream)
+                     size_t workspace_bytes, int arith, hipStream_t stream)
 {
-    const char *tenv = getenv("KIMG_DEGRID_TABLE");        // "hbm": timing experiments only
-    const bool in_lds = tables_fit_lds(w_planes, oversample, kernel_width) && !(tenv && tenv[0]);
+    const bool f16 = arith == KIMG_ARITH_SPLIT_FP16;
+    const bool in_lds = tables_fit_lds(w_planes, oversample, kernel_width);
     if (!in_lds && (workspace == nullptr
                     || workspace_bytes < kimg_degrid_mfma_workspace_bytes(P, w_planes, oversample,
                                                                          kernel_width)))
@@ -670,14 +670,12 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
         tab_max_offset); else rc = launch<PP, NWV, TAPSV, TWOV, true, false>(g, grid_row_stride, \
         grid_pol_stride, grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis, \
         (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream, padded, 0); } while (0)
-                const char *fenv_tg = getenv("KIMG_DEGRID_F16");
-                const bool f16_tg = !(fenv_tg && fenv_tg[0] == '0');
+                const bool f16_tg = f16;
                 const size_t tab_max_offset = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
                 // Diagonal blocks of a wide kernel use the same taps for rows and columns: one
                 // table, handled exactly like a narrow kernel's.
                 const bool two = wide && jb != kb;
-                const bool single_in_lds = !(tenv && tenv[0])
-                    && lds_bytes(12, w_planes, oversample, 32) <= LDS_LIMIT;
+                const bool single_in_lds = lds_bytes(12, w_planes, oversample, 32) <= LDS_LIMIT;
                 if (two) {
                     if (!in_lds) {
                         if (pn == 1) LAUNCH_TG(1, 12, 32, true); else LAUNCH_TG(2, 8, 32, true);
@@ -687,10 +685,8 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                 } else if (!single_in_lds) {
                     if (pn == 1) LAUNCH_TG(1, 12, 32, false); else LAUNCH_TG(2, 8, 32, false);
                 } else if (pn == 1) {
-                    // fp16 hi/lo form (two window rows per matrix instruction) unless
-                    // KIMG_DEGRID_F16=0 asks for the exact-fp32 instruction
-                    const char *fenv = getenv("KIMG_DEGRID_F16");
-                    if (!(fenv && fenv[0] == '0')) {
+                    // KIMG_ARITH_SPLIT_FP16: fp16 hi/lo form (two window rows per matrix instruction)
+                    if (f16) {
                         if (doubled)
                             rc = launch<1, 12, 64, false, false, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,
@@ -701,8 +697,7 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                                 (const float2 *) convolve_kernel, w_planes, oversample, ts, P, stream);
                     } else if (doubled) LAUNCH(1, 12, 64, false); else LAUNCH(1, 12, 32, false);
                 } else {
-                    const char *fenv = getenv("KIMG_DEGRID_F16");
-                    if (!(fenv && fenv[0] == '0')) {
+                    if (f16) {
                         if (doubled)
                             rc = launch<2, 8, 64, false, false, true>(g, grid_row_stride, grid_pol_stride,
                                 grid_size, uv, w_plane, weights + p0, (float *) vis + 2 * p0, num_vis,

@@ -6,20 +6,19 @@
 // (grid_mfma.hip) does not cover: every tap is a global float atomic, so it runs at the
 // chip's atomic rate (~1.3 TB/s of added bytes), not at the FMA rate.
 #include "kimg_common.h"
-#include <stdlib.h>
 
 int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
                    int P, const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
                    const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
                    const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
-                   void *workspace, size_t workspace_bytes, hipStream_t stream);
+                   void *workspace, size_t workspace_bytes, int arith, hipStream_t stream);
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                      int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
                      int w_planes, int oversample, int kernel_width, void *workspace,
-                     size_t workspace_bytes, hipStream_t stream);
+                     size_t workspace_bytes, int arith, hipStream_t stream);
 size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 
@@ -265,9 +264,12 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
                          const int16_t *w_plane, const void *vis, int64_t num_vis,
                          const void *convolve_kernel, int w_planes, int oversample,
                          int kernel_width, void *workspace, size_t workspace_bytes, int variant,
-                         void *stream)
+                         int arith, void *stream)
 {
     KIMG_CHECK_ARG(grid && weights_grid && uv && w_plane && vis && convolve_kernel);
+    KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
+    KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
+                   || variant == KIMG_VARIANT_MFMA);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
                              kernel_width);
     if (rc)
@@ -277,15 +279,13 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     hipStream_t s = (hipStream_t) stream;
     const bool mfma_ok = kimg_grid_mfma_supported(num_polarizations, w_planes, oversample,
                                                   kernel_width);
-    if (variant == 2 && !mfma_ok)
+    if (variant == KIMG_VARIANT_MFMA && !mfma_ok)
         return KIMG_EUNSUPPORTED;
-    if (variant == 2 || (variant == 0 && mfma_ok))
+    if (variant == KIMG_VARIANT_MFMA || (variant == KIMG_VARIANT_AUTO && mfma_ok))
         return kimg_grid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
                               num_polarizations, weights_grid, wg_row_stride, wg_pol_stride, uv,
                               w_plane, vis, num_vis, convolve_kernel, w_planes, oversample,
-                              kernel_width, workspace, workspace_bytes, s);
-    if (variant != 0 && variant != 1)
-        return KIMG_EINVAL;
+                              kernel_width, workspace, workspace_bytes, arith, s);
     int blocks = kimg_divup(num_vis, 4);
     if (blocks > 8192)
         blocks = 8192;
@@ -314,9 +314,12 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
                            const int16_t *w_plane, const float *weights, void *vis,
                            int64_t num_vis, const void *convolve_kernel, int w_planes,
                            int oversample, int kernel_width, void *workspace,
-                           size_t workspace_bytes, void *stream)
+                           size_t workspace_bytes, int variant, int arith, void *stream)
 {
     KIMG_CHECK_ARG(grid && uv && w_plane && weights && vis && convolve_kernel);
+    KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
+    KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
+                   || variant == KIMG_VARIANT_MFMA);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
                              kernel_width);
     if (rc)
@@ -324,17 +327,15 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
     if (num_vis == 0)
         return 0;                                               // grid.py:989-990
     hipStream_t s = (hipStream_t) stream;
-    static int force_generic = -1;
-    if (force_generic < 0) {
-        const char *e = getenv("KIMG_DEGRID_VARIANT");      // "generic": A/B tests only
-        force_generic = e && e[0] == 'g';
-    }
-    if (!force_generic
-        && kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample, kernel_width))
+    const bool mfma_ok = kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample,
+                                                    kernel_width);
+    if (variant == KIMG_VARIANT_MFMA && !mfma_ok)
+        return KIMG_EUNSUPPORTED;
+    if (variant != KIMG_VARIANT_GENERIC && mfma_ok)
         return kimg_degrid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
                                 num_polarizations, uv, w_plane, weights, vis, num_vis,
                                 convolve_kernel, w_planes, oversample, kernel_width, workspace,
-                                workspace_bytes, s);
+                                workspace_bytes, arith, s);
     int blocks = kimg_divup(num_vis, 4);
     if (blocks > 16384)
         blocks = 16384;

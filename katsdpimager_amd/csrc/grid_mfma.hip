@@ -36,7 +36,6 @@
 // executed: 2 MFMA x 2048 MAC per visibility per polarization (32x32 window).
 #include "kimg_common.h"
 #include <limits.h>
-#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -880,19 +879,11 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
             hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
-    static int dbg = -1, blocks_max_env = 0;
-    if (dbg < 0) {
-        const char *e = getenv("KIMG_GRID_DEBUG");      // timing experiments only
-        dbg = e ? atoi(e) : 0;
-        const char *st = getenv("KIMG_GRID_STAGGER");   // percent; default 12
-        dbg |= ((st ? atoi(st) : 12) & 0xff) << 8;
-        const char *b = getenv("KIMG_GRID_BLOCKS");
-        blocks_max_env = b ? atoi(b) : 0;
-    }
+    const int dbg = 12 << 8;        // bits 8-15: span stagger of a SIMD's waves, percent
     // as many blocks resident per CU as the LDS (kernel table + staging) allows;
     // every block streams a contiguous span (a multiple of 64).
     const int per_cu = (!TG && lds <= LDS_LIMIT / 2) ? 2 : 1;
-    const int blocks_max = blocks_max_env > 0 ? blocks_max_env : 256 * per_cu;
+    const int blocks_max = 256 * per_cu;
     int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
     vis_per_block = (vis_per_block + 63) / 64 * 64;
     if (vis_per_block < 64 * NW)
@@ -924,16 +915,10 @@ bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_wi
 
 // Where the kernel reads its table from: LDS when it fits -- except for the off-diagonal tap
 // blocks of wide kernels, whose two single-row tables in LDS are no faster than doubled rows in
-// HBM (the diagonal blocks need one table and always take the LDS form when it fits).  KIMG_GRID_TABLE = lds / hbm32 / hbm64 overrides (experiments).
+// HBM (the diagonal blocks need one table and always take the LDS form when it fits).
 static bool table_in_lds(int P, int w_planes, int oversample, int kernel_width)
 {
-    const char *e = getenv("KIMG_GRID_TABLE");
-    const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
-    if (e && strcmp(e, "lds") == 0)
-        return fits;
-    if (e && strncmp(e, "hbm", 3) == 0)
-        return false;
-    return fits && kernel_width <= WIN;
+    return tables_fit_lds(P, w_planes, oversample, kernel_width) && kernel_width <= WIN;
 }
 
 // Scratch for the padded table copy (none when the kernel reads its table from LDS).
@@ -942,7 +927,7 @@ size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int k
     if (!kimg_grid_mfma_supported(P, w_planes, oversample, kernel_width))
         return 0;
     const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
-    if (fits && kernel_width <= WIN && !getenv("KIMG_GRID_TABLE"))
+    if (fits && kernel_width <= WIN)
         return 0;
     return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
@@ -951,26 +936,15 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    int P, const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
                    const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
                    const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
-                   void *workspace, size_t workspace_bytes, hipStream_t stream)
+                   void *workspace, size_t workspace_bytes, int arith, hipStream_t stream)
 {
-    static int table_env = -1;
-    if (table_env < 0) {
-        const char *e = getenv("KIMG_GRID_TABLE");      // "hbm32" / "hbm64": timing experiments
-        table_env = !e ? 0 : (strcmp(e, "hbm32") == 0 ? 32 : (strcmp(e, "hbm64") == 0 ? 64 : 0));
-    }
+    const bool f16 = arith == KIMG_ARITH_SPLIT_FP16;
     const bool in_lds = table_in_lds(P, w_planes, oversample, kernel_width);
-    const char *tenv = getenv("KIMG_GRID_TABLE");
-    const bool lds_env_hbm = tenv && strncmp(tenv, "hbm", 3) == 0;
     if (!in_lds && (workspace == nullptr
                     || workspace_bytes < kimg_grid_mfma_workspace_bytes(P, w_planes, oversample,
                                                                        kernel_width)))
         return KIMG_EWORKSPACE;
     unsigned char *padded = static_cast<unsigned char *>(workspace);
-    static int nw_env = -1;
-    if (nw_env < 0) {
-        const char *e = getenv("KIMG_GRID_WAVES");      // timing experiments only
-        nw_env = e ? atoi(e) : 0;
-    }
     const int K = kernel_width;
     const bool wide = K > WIN;
     const int Kh = wide ? (K + 1) / 2 : K;              // taps per block along one axis
@@ -990,8 +964,8 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                 ts.tu0 = kb * Kh;
                 ts.Ku = kb ? K - Kh : Kh;
                 int rc;
-                // GO(P, ROW, NW, TWO, TG): the fp16 hi/lo form (two visibilities per matrix
-                // instruction) unless KIMG_GRID_F16=0 asks for the exact-fp32 instruction
+                // GO(P, ROW, NW, TWO, TG): exact-fp32 instruction, or with KIMG_ARITH_SPLIT_FP16 the
+                // fp16 hi/lo form (two visibilities per matrix instruction)
 #define GO(PP, ROWV, NWV, TWOV, TGV) do { \
         if (f16) rc = launch<PP, ROWV, NWV, TWOV, TGV, true>(g, grid_row_stride, grid_pol_stride, \
             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
@@ -999,15 +973,12 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
         else rc = launch<PP, ROWV, NWV, TWOV, TGV, false>(g, grid_row_stride, grid_pol_stride, \
             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
             oversample, ts, P, stream, padded, tab_max_offset); } while (0)
-                const char *fenv = getenv("KIMG_GRID_F16");
-                const bool f16 = !(fenv && fenv[0] == '0');
                 const size_t tab_max_offset = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
                 // Diagonal blocks of a wide kernel take row and column taps from the same half of
                 // the table: one table, which fits LDS whenever a narrow kernel's would.
                 const bool two = wide && jb != kb;
                 const bool single_in_lds = two ? false
-                    : wide ? (!table_env && !lds_env_hbm
-                              && lds_bytes(pn, 8, w_planes, oversample, 32) <= LDS_LIMIT)
+                    : wide ? lds_bytes(pn, 8, w_planes, oversample, 32) <= LDS_LIMIT
                            : in_lds;
                 if (two) {
                     // two tables: doubled rows in HBM, 12-wave blocks (P = 1) as for the LDS form
@@ -1017,7 +988,7 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                         else
                             GO(2, 64, 8, true, true);
                     } else if (pn == 1) {
-                        if (lds_bytes(1, 12, w_planes, oversample, 32, 2) <= LDS_LIMIT && nw_env != 8)
+                        if (lds_bytes(1, 12, w_planes, oversample, 32, 2) <= LDS_LIMIT)
                             GO(1, 32, 12, true, false);
                         else
                             GO(1, 32, 8, true, false);
@@ -1025,15 +996,13 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                         GO(2, 32, 8, true, false);
                     }
                 } else if (!single_in_lds) {
-                    if (pn == 1 && table_env != 32)
+                    if (pn == 1)
                         GO(1, 64, 12, false, true);     // doubled rows: 5 % faster than single rows
-                    else if (pn == 1)
-                        GO(1, 32, 12, false, true);
                     else
                         GO(2, 64, 8, false, true);
                 } else if (pn == 1) {
                     // 12-wave blocks, one per CU (LDS-bound), when the doubled table leaves room
-                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT && nw_env != 8)
+                    if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT)
                         GO(1, 64, 12, false, false);
                     else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)
                         GO(1, 64, 8, false, false);

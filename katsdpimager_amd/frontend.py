@@ -168,7 +168,7 @@ def find_peak(queue, image, pbeam, noise):
     from . import accel
     from ._lib import lib, check
     P, H, W = image.shape
-    out = accel.DeviceArray(queue.context, (1,), np.float32)
+    out = accel.DeviceArray(queue.context, (1,), np.float32, queue=queue)
     check(lib().kimg_image_peak(image.ptr, W, H * W, pbeam.ptr if pbeam is not None else None, W,
                                 W, H, P, float(noise), out.ptr, queue.handle), 'kimg_image_peak')
     peak = float(out.get(queue)[0])
@@ -182,7 +182,7 @@ def get_totals(queue, image, restoring_beam):
     from . import accel
     from ._lib import lib, check
     P, H, W = image.shape
-    sums = accel.DeviceArray(queue.context, (P,), np.float64)
+    sums = accel.DeviceArray(queue.context, (P,), np.float64, queue=queue)
     check(lib().kimg_image_nansum(image.ptr, W, H * W, W, H, P, sums.ptr, queue.handle),
           'kimg_image_nansum')
     beam_area = 2 * math.pi * restoring_beam.major * restoring_beam.minor / (8 * math.log(2))
@@ -206,6 +206,12 @@ def process_channels(jobs, workers=2):
     queues = {id(job['imager'].command_queue) for job in jobs}
     if len(queues) != len(jobs):
         raise ValueError('concurrent channels need one command queue each')
+    def run(job):
+        # the current HIP device is per host thread and new threads start on device 0: select the
+        # device of the job's command queue before anything is launched on its stream
+        import torch
+        with torch.cuda.device(job['imager'].command_queue.context.device):
+            return process_channel(**job)
     with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-        futures = [pool.submit(process_channel, **job) for job in jobs]
+        futures = [pool.submit(run, job) for job in jobs]
         return [f.result() for f in futures]

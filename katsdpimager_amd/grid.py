@@ -209,12 +209,29 @@ def shared_kernel_device(context, image_parameters, grid_parameters, pad=0):
 # --------------------------------------------------------------------------
 # Operators
 # --------------------------------------------------------------------------
-GRID_VARIANTS = {'auto': 0, 'generic': 1, 'mfma': 2}
+GRID_VARIANTS = {'auto': 0, 'generic': 1, 'mfma': 2}           # KIMG_VARIANT_*
+#: Arithmetic of the matrix instructions (KIMG_ARITH_*): ``fp32`` = v_mfma_f32_32x32x2_f32, every
+#: product and sum in float32 like the reference (grid.py:1049-1052), the default; ``split_fp16`` =
+#: operands as fp16 hi/lo pairs with float32 accumulation (faster, 22-bit operands; opt-in).
+GRID_ARITH = {'fp32': 0, 'split_fp16': 1}
+
+
+def _tuning(tuning):
+    tuning = tuning or {}
+    unknown = set(tuning) - {'variant', 'arith'}
+    if unknown:
+        raise ValueError('unknown tuning keys: {}'.format(sorted(unknown)))
+    try:
+        return GRID_VARIANTS[tuning.get('variant', 'auto')], GRID_ARITH[tuning.get('arith', 'fp32')]
+    except KeyError as e:
+        raise ValueError('unknown tuning value {}'.format(e)) from None
 
 
 class GridderTemplate:
-    """grid.py:549-653.  ``tuning`` may hold ``{'variant': 'auto'|'generic'|'mfma'}``;
-    there is no autotuner -- the kernel geometry is fixed by the MFMA tile shape."""
+    """grid.py:549-653.  ``tuning`` may hold ``{'variant': 'auto'|'generic'|'mfma',
+    'arith': 'fp32'|'split_fp16'}`` (the reference's tuning dict carries its autotuned work-group
+    shape; there is no autotuner here -- the kernel geometry is fixed by the MFMA tile shape).
+    Both are per template, passed to the C ABI on every call: nothing is read from the environment."""
 
     def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
         types.require_float32(fixed_image_parameters.real_dtype, 'GridderTemplate')
@@ -222,7 +239,7 @@ class GridderTemplate:
         self.context = context
         self.fixed_image_parameters = fixed_image_parameters
         self.fixed_grid_parameters = fixed_grid_parameters
-        self.variant = GRID_VARIANTS[(tuning or {}).get('variant', 'auto')]
+        self.variant, self.arith = _tuning(tuning)
         self.kernel_pad = 0
 
     def instantiate(self, *args, **kwargs):
@@ -307,7 +324,8 @@ class Gridder(GridDegrid):
         self._workspace = None
         self._workspace_bytes = nbytes
         if nbytes:
-            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8)
+            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
+                                                queue=self.command_queue)
 
     def _run(self):
         grid = self.buffer('grid')
@@ -320,12 +338,13 @@ class Gridder(GridDegrid):
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('vis').ptr,
             self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None,
-            self._workspace_bytes, self.template.variant, self.command_queue.handle)
+            self._workspace_bytes, self.template.variant, self.template.arith,
+            self.command_queue.handle)
         check(rc, 'kimg_grid')
 
 
 class DegridderTemplate:
-    """grid.py:870-970."""
+    """grid.py:870-970.  ``tuning`` as for :class:`GridderTemplate`."""
 
     def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
         types.require_float32(fixed_image_parameters.real_dtype, 'DegridderTemplate')
@@ -333,6 +352,7 @@ class DegridderTemplate:
         self.context = context
         self.fixed_image_parameters = fixed_image_parameters
         self.fixed_grid_parameters = fixed_grid_parameters
+        self.variant, self.arith = _tuning(tuning)
         self.kernel_pad = 0
 
     def instantiate(self, *args, **kwargs):
@@ -357,7 +377,8 @@ class Degridder(GridDegrid):
         self._workspace = None
         self._workspace_bytes = nbytes
         if nbytes:
-            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8)
+            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
+                                                queue=self.command_queue)
 
     def _run(self):
         grid = self.buffer('grid')
@@ -368,5 +389,5 @@ class Degridder(GridDegrid):
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('weights').ptr,
             self.buffer('vis').ptr, self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None, self._workspace_bytes,
-            self.command_queue.handle)
+            self.template.variant, self.template.arith, self.command_queue.handle)
         check(rc, 'kimg_degrid')

@@ -20,7 +20,9 @@ from . import accel, clean, grid, image, predict, weight
 
 
 class ImagingTemplate:
-    """Holds all operator templates (imaging.py:11-51)."""
+    """Holds all operator templates (imaging.py:11-51).  ``tuning`` maps 'gridder', 'degridder'
+    and 'clean' to the tuning dicts of those templates (the reference's per-template autotuning
+    results travel the same way, imaging.py:24-29)."""
 
     def __init__(self, context, array_parameters, fixed_image_parameters,
                  weight_parameters, fixed_grid_parameters, clean_parameters, tuning=None):
@@ -40,12 +42,13 @@ class ImagingTemplate:
         self.grid_image = image.GridImageTemplate(context, dtype)
         self.psf_patch = clean.PsfPatchTemplate(context, dtype, num_pols)
         self.noise_est = clean.NoiseEstTemplate(context, dtype, num_pols)
-        self.clean = clean.CleanTemplate(context, clean_parameters, dtype, num_pols)
+        self.clean = clean.CleanTemplate(context, clean_parameters, dtype, num_pols,
+                                         tuning.get('clean'))
         self.scale = image.ScaleTemplate(context, dtype, num_pols)
         self.add_image = image.AddImageTemplate(context, dtype, num_pols)
         self.apply_primary_beam = image.ApplyPrimaryBeamTemplate(context, dtype, num_pols)
         self.degridder = grid.DegridderTemplate(
-            context, fixed_image_parameters, fixed_grid_parameters) \
+            context, fixed_image_parameters, fixed_grid_parameters, tuning.get('degridder')) \
             if fixed_grid_parameters.degrid else None
 
     def instantiate(self, *args, **kwargs):

@@ -66,10 +66,10 @@ class _SliceStore:
     def _allocate(self, rows):
         P = self.P
         arrays = dict(
-            uv=accel.DeviceArray(self.context, (rows, 4), np.int16),
-            w_plane=accel.DeviceArray(self.context, (rows,), np.int16),
-            weights=accel.DeviceArray(self.context, (rows, P), np.float32),
-            vis=accel.DeviceArray(self.context, (rows, P), np.complex64))
+            uv=accel.DeviceArray(self.context, (rows, 4), np.int16, queue=self.queue),
+            w_plane=accel.DeviceArray(self.context, (rows,), np.int16, queue=self.queue),
+            weights=accel.DeviceArray(self.context, (rows, P), np.float32, queue=self.queue),
+            vis=accel.DeviceArray(self.context, (rows, P), np.complex64, queue=self.queue))
         for a in arrays.values():
             a.zero(self.queue)       # the slack rows are read (and masked) by full-block views
         return arrays
@@ -162,9 +162,9 @@ class VisibilityCollectorDevice:
         self._lib = lib()
         B = self.buffer_size
         ctx = self.context
-        self._key = accel.DeviceArray(ctx, (B, 6), np.int16)
-        self._cw = accel.DeviceArray(ctx, (B, P), np.float32)
-        self._cvis = accel.DeviceArray(ctx, (B, P), np.complex64)
+        self._key = accel.DeviceArray(ctx, (B, 6), np.int16, queue=self.queue)
+        self._cw = accel.DeviceArray(ctx, (B, P), np.float32, queue=self.queue)
+        self._cvis = accel.DeviceArray(ctx, (B, P), np.complex64, queue=self.queue)
         # two sets of compress outputs + slice counts: the host reads the counts of buffer i
         # (needed to place its records) while the device already works on buffer i + 1
         max_slices = max(gp.w_slices for gp in self.grid_parameters)
@@ -172,17 +172,17 @@ class VisibilityCollectorDevice:
         self._sets = []
         for _ in range(2):
             out = dict(
-                uv=accel.DeviceArray(ctx, (B, 4), np.int16),
-                w_plane=accel.DeviceArray(ctx, (B,), np.int16),
-                weights=accel.DeviceArray(ctx, (B, P), np.float32),
-                vis=accel.DeviceArray(ctx, (B, P), np.complex64))
-            counts = accel.DeviceArray(ctx, (max_slices,), np.int64)
+                uv=accel.DeviceArray(ctx, (B, 4), np.int16, queue=self.queue),
+                w_plane=accel.DeviceArray(ctx, (B,), np.int16, queue=self.queue),
+                weights=accel.DeviceArray(ctx, (B, P), np.float32, queue=self.queue),
+                vis=accel.DeviceArray(ctx, (B, P), np.complex64, queue=self.queue))
+            counts = accel.DeviceArray(ctx, (max_slices,), np.int64, queue=self.queue)
             host = torch.empty((max_slices,), dtype=torch.int64).pin_memory()
             self._sets.append((out, counts, host, torch.cuda.Event()))
         self._ws_bytes = int(self._lib.kimg_preprocess_workspace_bytes(B, P))
         if self._ws_bytes == 0:
             raise ValueError('unsupported buffer_size / polarizations')
-        self._ws = accel.DeviceArray(ctx, (self._ws_bytes,), np.uint8)
+        self._ws = accel.DeviceArray(ctx, (self._ws_bytes,), np.uint8, queue=self.queue)
 
     @property
     def num_channels(self):

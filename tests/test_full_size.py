@@ -16,15 +16,15 @@ from oracle import kimg_oracle as orc               # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _setup(pixels, n_vis, w_planes, P, K=28, variant='auto', vis_block=1048576):
+def _setup(pixels, n_vis, w_planes, P, K=28, variant='auto', vis_block=1048576, arith='fp32'):
     import torch
     import synth
     from katsdpimager_amd import accel, grid
     ctx, q = context_queue()
     obs = synth.make_observation(pixels, n_vis, w_planes, P, device=ctx.device)
     ip, gp, ap = synth.make_parameters(obs, P, K)
-    fn = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': variant}).instantiate(
-        q, ap, ip, gp, vis_block)
+    fn = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': variant, 'arith': arith}) \
+        .instantiate(q, ap, ip, gp, vis_block)
     Gg = fn.slots['grid'].shape[1]
     gen = torch.Generator(device=ctx.device)
     gen.manual_seed(2)
@@ -252,18 +252,15 @@ def test_full_size_noise_estimate_and_clean_rate_invariants(G, P):
 
 
 def test_c2_f16_form_vs_exact_and_repeatable():
-    """Config 2 geometry, 2.2 M visibilities: the default fp16 hi/lo form of the gridder against the
-    exact-fp32 form (KIMG_GRID_F16=0) and against itself (the only run-to-run difference allowed is the
-    order of the float atomics)."""
+    """Config 2 geometry, 2.2 M visibilities: the fp16 hi/lo form of the gridder (tuning arith =
+    'split_fp16') against the exact-fp32 form and against itself (the only run-to-run difference
+    allowed is the order of the float atomics)."""
     ctx, q, obs, fn, wg = _setup(4096, 2_200_000, 32, 1)
-
-    def run(flag):
-        os.environ['KIMG_GRID_F16'] = flag
-        try:
-            return _grid_all(ctx, q, obs, fn).clone()
-        finally:
-            os.environ.pop('KIMG_GRID_F16', None)
-    exact, split, again = run('0'), run('1'), run('1')
+    _, _, _, fn_split, _ = _setup(4096, 2_200_000, 32, 1, arith='split_fp16')
+    fn_split.bind(weights_grid=wg)
+    exact = _grid_all(ctx, q, obs, fn).clone()
+    split = _grid_all(ctx, q, obs, fn_split).clone()
+    again = _grid_all(ctx, q, obs, fn_split).clone()
     peak = float(exact.abs().max())
     assert float((split - exact).abs().max()) <= 2e-6 * peak
     assert float((split - again).abs().max()) <= 5e-7 * peak

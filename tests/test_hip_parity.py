@@ -17,11 +17,17 @@ pytestmark = pytest.mark.gpu
 GRID_TOL = 1e-5
 
 
+ARITHS = ['fp32', 'split_fp16']         # KIMG_ARITH_*: both forms of the window kernels
+
+
 def _gridder(c, variant, max_vis=1280):
+    """`variant` = 'generic' | 'mfma' | 'auto', optionally followed by ':' and the arithmetic."""
     from katsdpimager_amd import grid
     ctx, q = context_queue()
     ip, gp, ap = make_params(c)
-    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': variant})
+    variant, _, arith = variant.partition(':')
+    template = grid.GridderTemplate(ctx, ip.fixed, gp.fixed,
+                                    {'variant': variant, 'arith': arith or 'fp32'})
     fn = template.instantiate(q, ap, ip, gp, max_vis)
     fn.ensure_all_bound()
     return fn, q
@@ -41,7 +47,7 @@ def _run_gridder(fn, q, t):
     return fn.buffer('grid').get(q)
 
 
-@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 @pytest.mark.parametrize('name', ['p4_f32', 'p1_k8', 'p2_k60'])
 def test_gridder_vs_golden(golden, name, variant):
     """G2: reference GridderHost output on the test_grid.py track recipe."""
@@ -53,7 +59,7 @@ def test_gridder_vs_golden(golden, name, variant):
     assert relerr(actual, expected) < GRID_TOL
 
 
-@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 @pytest.mark.parametrize('P', [1, 2, 3, 4])
 def test_gridder_bruteforce(variant, P):
     """test_grid.py:91-112 (do_grid) at the reference test's own size (256^2, K=28, 32 planes,
@@ -85,7 +91,7 @@ def test_gridder_bruteforce(variant, P):
     assert relerr(actual, G_or) < GRID_TOL
 
 
-@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 @pytest.mark.parametrize('K,P', [(33, 1), (45, 2), (60, 1), (60, 4), (64, 3)])
 def test_gridder_wide_kernels(variant, K, P):
     """Kernel widths 33..64 (60 is the reference's CLI default, frontend.py:325): the MFMA
@@ -113,9 +119,10 @@ def test_gridder_wide_kernels(variant, K, P):
     assert relerr(actual, expected) < GRID_TOL
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('K,OV,W,P', [(1, 8, 3, 1), (2, 4, 8, 2), (7, 16, 4, 1), (15, 2, 8, 3),
                                       (31, 8, 5, 1), (32, 8, 8, 2), (32, 4, 1, 4), (27, 2, 7, 1)])
-def test_grid_degrid_odd_shapes(K, OV, W, P):
+def test_grid_degrid_odd_shapes(K, OV, W, P, arith):
     """Unusual kernel widths (1, odd, exactly the window width: no slack), oversampling factors and
     plane counts through the MFMA gridder and degridder, smooth and scattered positions."""
     from katsdpimager_amd import grid
@@ -129,11 +136,11 @@ def test_grid_degrid_odd_shapes(K, OV, W, P):
         sub_uv=rs.randint(0, OV, (n2, 2)).astype(np.int16),
         w_plane=rs.randint(0, W, n2).astype(np.int16), weights_grid=t['weights_grid'],
         vis=rs.complex_uniform(-1, 1, size=(n2, P)).astype(np.complex64))
-    fn, q = _gridder(c, 'mfma', max_vis=2048)
+    fn, q = _gridder(c, 'mfma:' + arith, max_vis=2048)
     kernel = fn.convolve_kernel.data
     assert kernel.shape == (W, OV, K)
     ip, gp, ap = make_params(c)
-    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 2048)
     dg.ensure_all_bound()
     G = dg.buffer('grid').shape[-1]
     gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
@@ -161,15 +168,16 @@ def test_grid_degrid_odd_shapes(K, OV, W, P):
         assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('K,W,P', [(28, 128, 1), (28, 300, 2), (16, 96, 4), (60, 48, 1), (45, 64, 3)])
-def test_gridder_many_w_planes(K, W, P):
+def test_gridder_many_w_planes(K, W, P, arith):
     """More W planes than an LDS-resident table allows (the reference's default w-step gives
     hundreds per slice): the MFMA gridder reads a padded copy of the table from HBM instead.
     Smooth track and scattered positions over all planes, against the oracle; the result must
     also agree with the per-tap kernel."""
     c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1500)
     t = gi.grid_track(c)
-    fn, q = _gridder(c, 'mfma', max_vis=2048)
+    fn, q = _gridder(c, 'mfma:' + arith, max_vis=2048)
     assert fn._workspace_bytes > 0
     kernel = fn.convolve_kernel.data
     rs = gi.RandomState(K + W)
@@ -191,15 +199,16 @@ def test_gridder_many_w_planes(K, W, P):
         assert relerr(_run_gridder(fg, q, data), actual) < GRID_TOL
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('K,W,P', [(28, 128, 1), (28, 300, 2), (16, 96, 4), (60, 48, 1), (45, 64, 3)])
-def test_degridder_many_w_planes(K, W, P):
+def test_degridder_many_w_planes(K, W, P, arith):
     """The degridder with its table in HBM (more W planes than LDS holds), against the oracle."""
     from katsdpimager_amd import grid
     ctx, q = context_queue()
     c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1500)
     t = gi.grid_track(c)
     ip, gp, ap = make_params(c)
-    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 2048)
     fn.ensure_all_bound()
     assert fn._workspace_bytes > 0
     G = fn.buffer('grid').shape[-1]
@@ -267,11 +276,12 @@ def test_kernel_wider_than_mfma_window():
     assert np.abs(dg.buffer('vis').get(q)[:n] - want).max() <= 1e-5 * np.abs(want).max()
 
 
-def test_gridder_64_planes():
+@pytest.mark.parametrize('arith', ARITHS)
+def test_gridder_64_planes(arith):
     """64 W-planes: the doubled LDS table does not fit, single-row variant (config 4)."""
     c = gi.make_config(256, 0.0001, 0.01, 2, 28, 64, grid_cover=180, n_vis=1000)
     t = gi.grid_track(c)
-    fn, q = _gridder(c, 'mfma')
+    fn, q = _gridder(c, 'mfma:' + arith)
     actual = _run_gridder(fn, q, t)
     expected = np.zeros(actual.shape, np.complex64)
     wg = np.zeros(actual.shape, np.float32)
@@ -280,7 +290,7 @@ def test_gridder_64_planes():
     assert relerr(actual, expected) < GRID_TOL
 
 
-@pytest.mark.parametrize('variant', ['generic', 'mfma'])
+@pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 def test_gridder_edge_cases(variant):
     """Empty input (grid.py:810-811), a single visibility, odd counts, batches that are not a
     multiple of 64, large jumps between consecutive visibilities, repeated positions."""
@@ -330,8 +340,9 @@ def test_gridder_too_small_image():
         template.instantiate(q, ap, ip, gp, 100)
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('name', ['p4_f32', 'p1_k8', 'p2_k60'])
-def test_degridder_vs_golden(golden, name):
+def test_degridder_vs_golden(golden, name, arith):
     """G3: reference DegridderHost residuals (rtol 1e-5 as test_grid.py:135, plus an absolute
     floor for values that cancel)."""
     from katsdpimager_amd import grid
@@ -340,7 +351,7 @@ def test_degridder_vs_golden(golden, name):
     t = gi.grid_track(c)
     dg = gi.degrid_inputs(c)
     ip, gp, ap = make_params(c)
-    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 2048)
     fn.ensure_all_bound()
     n = c['n_vis']
     fn.buffer('grid').set(q, gi.middle(dg['grid'], fn.buffer('grid').shape))
@@ -357,8 +368,9 @@ def test_degridder_vs_golden(golden, name):
     fn()                                      # grid.py:989-990
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('P,W', [(1, 32), (2, 32), (3, 32), (4, 32), (1, 64), (4, 64)])
-def test_degridder_adversarial(P, W):
+def test_degridder_adversarial(P, W, arith):
     """Uniformly random positions (every 16-group needs several window passes), repeated
     positions, ragged counts and zero visibilities, against the oracle.  W = 64 planes does not
     fit the doubled LDS table and takes the single-row (wrapping) variant."""
@@ -366,7 +378,7 @@ def test_degridder_adversarial(P, W):
     ctx, q = context_queue()
     c = gi.make_config(256, 0.0001, 0.01, P, 28, W, grid_cover=180, n_vis=1000)
     ip, gp, ap = make_params(c)
-    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 4096)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 4096)
     fn.ensure_all_bound()
     G = fn.buffer('grid').shape[-1]
     rs = gi.RandomState(7)
@@ -397,8 +409,9 @@ def test_degridder_adversarial(P, W):
         np.testing.assert_allclose(actual, expected, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('K,P', [(33, 1), (45, 2), (60, 1), (60, 4), (64, 3)])
-def test_degridder_wide_kernels(K, P):
+def test_degridder_wide_kernels(K, P, arith):
     """Kernel widths 33..64 through the MFMA degridder (2 x 2 tap blocks, each subtracting its
     partial sum) against the oracle: a smooth track and positions without any locality."""
     from katsdpimager_amd import grid
@@ -406,7 +419,7 @@ def test_degridder_wide_kernels(K, P):
     c = gi.make_config(512, 0.0001, 0.01, P, K, 16, grid_cover=300, n_vis=1500)
     t = gi.grid_track(c)
     ip, gp, ap = make_params(c)
-    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
+    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 2048)
     fn.ensure_all_bound()
     G = fn.buffer('grid').shape[-1]
     rs = gi.RandomState(K)
@@ -964,8 +977,9 @@ def test_restore_step():
                                atol=1e-5 * np.abs(expected).max())
 
 
+@pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('seed', range(12))
-def test_grid_degrid_fuzz(seed):
+def test_grid_degrid_fuzz(seed, arith):
     """Seeded random configurations (kernel width 1..64, oversampling, plane count incl. tables that
     do not fit LDS, polarizations, chunk sizes, track speed from static to teleporting) through the
     automatic gridder and degridder variants, against the oracle."""
@@ -991,7 +1005,7 @@ def test_grid_degrid_fuzz(seed):
     uv = uv[0] + np.round((uv - uv[0]) * speed).astype(np.int64)
     uv = ((uv + half) % (2 * half)) - half
     t['uv'] = uv.astype(np.int16)
-    fn, q = _gridder(c, 'auto', max_vis=4096)
+    fn, q = _gridder(c, 'auto:' + arith, max_vis=4096)
     kernel = fn.convolve_kernel.data
     actual = _run_gridder(fn, q, t)
     expected = np.zeros(actual.shape, np.complex64)
@@ -1000,7 +1014,7 @@ def test_grid_degrid_fuzz(seed):
     orc.grid(kernel, expected, wg, t['uv'], t['sub_uv'], t['w_plane'], t['vis'])
     assert relerr(actual, expected) < GRID_TOL, (K, OV, W, P, n, speed)
     ip, gp, ap = make_params(c)
-    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 4096)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, 4096)
     dg.ensure_all_bound()
     G = dg.buffer('grid').shape[-1]
     gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
@@ -1290,23 +1304,23 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
     full_patch = (P,) + patch
 
     def run(fused):
-        os.environ['KIMG_CLEAN_FUSED'] = '1' if fused else '0'
-        try:
-            fn = clean.CleanTemplate(ctx, cp, np.float32, P).instantiate(q, ip)
-            fn.ensure_all_bound()
-            fn.buffer('dirty').set(q, dirty)
-            fn.buffer('psf').set(q, psf)
-            fn.buffer('model').zero(q)
-            fn.reset()
-            log = fn.run_cycles(full_patch, 0.0, 150)
-            log.append(fn(full_patch, 0.0))                  # a single cycle on the tiles left behind
-            log += fn.run_cycles(full_patch, 0.0, 37)        # odd count, below the graph size
-            first = log[0][0]
-            log += fn.run_cycles(full_patch, 0.7 * first, 500)        # stops at the threshold
-            return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
-                    fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
-        finally:
-            os.environ.pop('KIMG_CLEAN_FUSED', None)
+        form = 'one_launch' if fused else 'two_launch'
+        fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form}).instantiate(q, ip)
+        fn.ensure_all_bound()
+        fn.buffer('dirty').set(q, dirty)
+        fn.buffer('psf').set(q, psf)
+        fn.buffer('model').zero(q)
+        fn.reset()
+        log = fn.run_cycles(full_patch, 0.0, 150)
+        log.append(fn(full_patch, 0.0))                  # a single cycle on the tiles left behind
+        log += fn.run_cycles(full_patch, 0.0, 37)        # odd count, below the graph size
+        first = log[0][0]
+        log += fn.run_cycles(full_patch, 0.7 * first, 500)        # stops at the threshold
+        # a different threshold replays the same captured graph (the threshold lives in device
+        # state, not in the kernel arguments)
+        log += fn.run_cycles(full_patch, 0.5 * first, 500)
+        return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
+                fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
     a, b = run(True), run(False)
     assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 688
     for u, w in zip(a[0], b[0]):
@@ -1386,15 +1400,11 @@ def test_gridder_f16_form_ranges(pattern, P, K, W):
         t['vis'][100, 0] = np.nan
         t['vis'][700, -1] = complex(np.inf, 1.0)
 
-    def run(flag):
-        os.environ['KIMG_GRID_F16'] = flag
-        try:
-            fn, q = _gridder(c, 'mfma', max_vis=2048)
-            return _run_gridder(fn, q, t), fn.convolve_kernel.data
-        finally:
-            os.environ.pop('KIMG_GRID_F16', None)
-    exact, kernel = run('0')
-    split, _ = run('1')
+    def run(arith):
+        fn, q = _gridder(c, 'mfma:' + arith, max_vis=2048)
+        return _run_gridder(fn, q, t), fn.convolve_kernel.data
+    exact, kernel = run('fp32')
+    split, _ = run('split_fp16')
     if pattern == 'nan':
         bad = ~np.isfinite(exact)
         assert 0 < bad.sum() < 0.2 * exact.size
@@ -1434,8 +1444,10 @@ def test_degridder_f16_form_ranges(pattern, W):
     ip, gp, ap = make_params(c)
     n = c['n_vis']
     rs = np.random.RandomState(11)
-    fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 2048)
-    fn.ensure_all_bound()
+    fns = {arith: grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(
+        q, ap, ip, gp, 2048) for arith in ARITHS}
+    for fn in fns.values():
+        fn.ensure_all_bound()
     shape = fn.buffer('grid').shape
     model = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
     if pattern == 'spike':
@@ -1452,20 +1464,17 @@ def test_degridder_f16_form_ranges(pattern, W):
     vis0 = (rs.standard_normal((n, 1)) + 1j * rs.standard_normal((n, 1))).astype(np.complex64)
     weights = rs.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
 
-    def run(flag):
-        os.environ['KIMG_DEGRID_F16'] = flag
-        try:
-            fn.buffer('grid').set(q, model)
-            fn.num_vis = n
-            fn.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
-            fn.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
-            fn.buffer('vis').set_region(q, vis0, np.s_[:n], np.s_[:])
-            fn.buffer('weights').set_region(q, weights, np.s_[:n], np.s_[:])
-            fn()
-            return fn.buffer('vis').get(q)[:n]
-        finally:
-            os.environ.pop('KIMG_DEGRID_F16', None)
-    exact, split = run('0'), run('1')
+    def run(arith):
+        fn = fns[arith]
+        fn.buffer('grid').set(q, model)
+        fn.num_vis = n
+        fn.buffer('uv').set_region(q, np.concatenate((t['uv'], t['sub_uv']), axis=1), np.s_[:n], np.s_[:])
+        fn.buffer('w_plane').set_region(q, t['w_plane'], np.s_[:n], np.s_[:])
+        fn.buffer('vis').set_region(q, vis0, np.s_[:n], np.s_[:])
+        fn.buffer('weights').set_region(q, weights, np.s_[:n], np.s_[:])
+        fn()
+        return fn.buffer('vis').get(q)[:n]
+    exact, split = run('fp32'), run('split_fp16')
     bad = ~np.isfinite(exact)
     np.testing.assert_array_equal(~np.isfinite(split), bad)
     assert (pattern == 'nan') == bool(bad.any())

@@ -24,7 +24,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     assert declared == set(_lib.PROTOTYPES)
     lib = _lib.lib()
-    assert lib.kimg_version() == 1
+    version = int(re.search(r'#define KIMG_VERSION (\d+)', header).group(1))
+    assert lib.kimg_version() == version == _lib.VERSION
+    assert not re.search(r'\bgetenv\b', ''.join(
+        open(os.path.join(ROOT, 'katsdpimager_amd', 'csrc', f)).read()
+        for f in os.listdir(os.path.join(ROOT, 'katsdpimager_amd', 'csrc')) if f.endswith(('.hip', '.h')))), \
+        'the C ABI takes every choice as an argument; nothing is read from the environment'
     assert _lib.error_string(0) == 'success'
     assert 'unsupported' in _lib.error_string(-10002)
 
@@ -34,6 +39,14 @@ def test_argument_errors_without_gpu():
     from katsdpimager_amd import _lib
     lib = _lib.lib()
     assert lib.kimg_fill(None, 10, 1.0, None) == -10001
+    # arithmetic / variant / form selectors are validated like any other argument
+    one = ctypes.c_void_p(1)
+    assert lib.kimg_grid(one, 8, 64, 8, 1, one, 8, 64, one, one, one, 4, one, 1, 8, 4, None, 0,
+                         0, 7, None) == -10001
+    assert lib.kimg_grid(one, 8, 64, 8, 1, one, 8, 64, one, one, one, 4, one, 1, 8, 4, None, 0,
+                         3, 0, None) == -10001
+    assert lib.kimg_degrid(one, 8, 64, 8, 1, one, one, one, one, 4, one, 1, 8, 4, None, 0,
+                           0, 2, None) == -10001
     assert lib.kimg_grid_weights(None, 1, 1, 2, 2, 1, None, None, 0, None) == -10001
     with pytest.raises(_lib.KimgError):
         _lib.check(-10001, 'kimg_fill')

@@ -106,3 +106,34 @@ def test_synthetic_observation_matches_oracle_quantisation():
     np.testing.assert_array_equal(pix, tp.numpy())
     np.testing.assert_array_equal(sub, (xs - tp * 8).numpy())
     assert bl.shape == (2016, 3)
+
+
+def test_bench_torchrun_rehearsal_world2():
+    """`bench.py --gpus 2` under torchrun exactly as the driver launches it, with `--rehearse`
+    (gloo, CPU tensors, no device work): rendezvous, broadcast, per-rank channels, barriers,
+    max-over-ranks timing and ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--rehearse']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert out['config']['band_channels'] == [7, 3]     # rank 0 keeps the N = 1 channel
+    assert out['ms_per_step'] >= 2.0                    # the slower rank (2 ms per step) sets it
+
+
+def test_bench_channel_assignment_is_the_same_workload_for_every_n():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 4, 8):
+        chans = [bench.rank_channel(r, world) for r in range(world)]
+        assert chans[0] == 7 and len(set(chans)) == world
+        assert all(0.94 < bench.channel_scale(c) <= 1.0 for c in chans)
+    assert bench.channel_scale(7) == 1.0

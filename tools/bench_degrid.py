@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--kernel-width', type=int, default=28)
     ap.add_argument('--pols', type=int, default=1)
     ap.add_argument('--chunks', type=int, default=8)
+    ap.add_argument('--arith', default='fp32', choices=['fp32', 'split_fp16'])
     args = ap.parse_args()
     import torch
     import synth
@@ -29,7 +30,8 @@ def main():
     obs = synth.make_observation(args.pixels, args.vis, args.w_planes, P, device=ctx.device)
     ip, gp, ap_ = synth.make_parameters(obs, P, args.kernel_width, degrid=True)
     vb = 1 << 20
-    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap_, ip, gp, vb)
+    dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': args.arith}).instantiate(
+        q, ap_, ip, gp, vb)
     Gg = dg.slots['grid'].shape[1]
     gen = torch.Generator(device=ctx.device)
     gen.manual_seed(1)

@@ -136,3 +136,111 @@ def make_parameters(obs, num_polarizations=1, kernel_width=28, antialias_width=7
     gp = parameters.GridParameters(fixed_g, obs.w_slices, obs.w_planes)
     ap = parameters.ArrayParameters(13.5, obs.longest_baseline)
     return ip, gp, ap
+
+
+# ---- input orders --------------------------------------------------
+def _track_indices(obs):
+    """(baseline, time sample) of every visibility of a baseline-major observation."""
+    nb = baselines_equatorial().shape[0]
+    T = -(-obs.n_vis // nb)
+    idx = torch.arange(obs.n_vis, device=obs.uv.device)
+    return idx // T, idx % T, nb, T
+
+
+def _copy_with(obs, uv, w_plane, vis, weights):
+    out = Observation()
+    out.__dict__.update(obs.__dict__)
+    out.uv, out.w_plane, out.vis, out.weights = uv.contiguous(), w_plane.contiguous(), \
+        vis.contiguous(), weights.contiguous()
+    out.n_vis = int(uv.shape[0])
+    for name in ('uvw', 'w_slice'):
+        out.__dict__.pop(name, None)        # (not reordered: unused by the consumers of these)
+    return out
+
+
+def _reordered(obs, order):
+    return _copy_with(obs, obs.uv[order], obs.w_plane[order], obs.vis[order], obs.weights[order])
+
+
+def order_time_major(obs):
+    """All baselines of dump 0, then of dump 1, ...: consecutive visibilities never share a
+    baseline (the order of a time-sorted measurement set read without the loaders' sort)."""
+    b, t, nb, T = _track_indices(obs)
+    order = torch.argsort(t * nb + b)
+    return {'obs': _reordered(obs, order), 'note': 'time-major: a baseline jump at every record'}
+
+
+def order_shuffled(obs, seed=3):
+    """No locality at all (SURVEY 8d "adversarial")."""
+    gen = torch.Generator(device=obs.uv.device)
+    gen.manual_seed(seed)
+    order = torch.randperm(obs.n_vis, generator=gen, device=obs.uv.device)
+    return {'obs': _reordered(obs, order), 'note': 'uniformly shuffled'}
+
+
+def compress_adjacent(obs):
+    """Merge runs of adjacent records with equal (u, v, sub_u, sub_v, w_plane), summing their
+    visibilities and weights: what the reference's preprocessor hands to the gridder
+    (preprocess.cpp:334-397; sums here in atomic order, which only matters to the last bit)."""
+    uv = obs.uv.to(torch.int64)
+    key = ((uv[:, 0] + 32768) << 48) | ((uv[:, 1] + 32768) << 32) | (uv[:, 2] << 24) \
+        | (uv[:, 3] << 16) | obs.w_plane.to(torch.int64)
+    head = torch.ones(obs.n_vis, dtype=torch.bool, device=key.device)
+    head[1:] = key[1:] != key[:-1]
+    seg = torch.cumsum(head.to(torch.int64), 0) - 1
+    m = int(seg[-1]) + 1
+    P = obs.vis.shape[1]
+    vis = torch.zeros((m, P, 2), dtype=torch.float32, device=key.device)
+    vis.index_add_(0, seg, torch.view_as_real(obs.vis))
+    weights = torch.zeros((m, P), dtype=torch.float32, device=key.device)
+    weights.index_add_(0, seg, obs.weights)
+    heads = torch.nonzero(head)[:, 0]
+    return _copy_with(obs, obs.uv[heads], obs.w_plane[heads], torch.view_as_complex(vis), weights)
+
+
+def order_loader_blocks(obs, dumps=256):
+    """The stream the reference's gridder sees: the loaders deliver blocks of `dumps` consecutive
+    dumps (--vis-load 32 Mi over a batch of 16 channels: about 250 dumps of a 64-antenna katdal
+    file, loader_katdal.py:326, about 1000 rows per baseline of a measurement set,
+    loader_ms.py:383), each block sorted by baseline (loader_ms.py:465-467), and the preprocessor
+    merges adjacent records that fall on the same sub-cell (preprocess.cpp:334-397)."""
+    b, t, nb, T = _track_indices(obs)
+    order = torch.argsort((t // dumps) * (nb * dumps) + b * dumps + (t % dumps))
+    merged = compress_adjacent(_reordered(obs, order))
+    return {'obs': merged,
+            'note': 'baseline-sorted blocks of {} dumps, adjacent-merged: {} of {} records kept '
+                    '({:.1f} %); the rate counts merged records'.format(
+                        dumps, merged.n_vis, obs.n_vis, 100.0 * merged.n_vis / obs.n_vis)}
+
+
+def grid_truth_fp64(kernel, uv, w_plane, vis, weights_grid, kernel_width, batch=16384):
+    """float64 evaluation of the gridding sum (grid.py:1032-1052) with torch on the tensors' device:
+    grid[p][v0+j][u0+k] += vis * wgrid[p][v+G/2][u+G/2] * conj(kern[w][sv][j] kern[w][su][k]).
+    `kernel`: numpy complex64 [W][OV][K]; returns complex128 [P][G][G].  Test / bench
+    infrastructure (an independent check of both gridder forms), not part of the product."""
+    dev = uv.device
+    kern = torch.from_numpy(np.ascontiguousarray(kernel)).to(dev).to(torch.complex128)
+    P, G = weights_grid.shape[0], weights_grid.shape[-1]
+    K = kernel_width
+    half = G // 2
+    bias = (K - 1) // 2 - half
+    out = torch.zeros((P, G * G, 2), dtype=torch.float64, device=dev)
+    taps = torch.arange(K, device=dev)
+    n = uv.shape[0]
+    for s in range(0, n, batch):
+        e = min(s + batch, n)
+        u = uv[s:e, 0].to(torch.int64)
+        v = uv[s:e, 1].to(torch.int64)
+        su = uv[s:e, 2].to(torch.int64)
+        sv = uv[s:e, 3].to(torch.int64)
+        wp = w_plane[s:e].to(torch.int64)
+        kv = torch.conj(kern[wp, sv])                       # [B][K]
+        ku = torch.conj(kern[wp, su])
+        idx = ((v - bias)[:, None, None] + taps[None, :, None]) * G \
+            + ((u - bias)[:, None, None] + taps[None, None, :])
+        for p in range(P):
+            wgt = weights_grid[p][v + half, u + half].to(torch.float64)
+            smp = vis[s:e, p].to(torch.complex128) * wgt
+            vals = smp[:, None, None] * kv[:, :, None] * ku[:, None, :]
+            out[p].index_add_(0, idx.reshape(-1), torch.view_as_real(vals).reshape(-1, 2))
+    return torch.view_as_complex(out).reshape(P, G, G)
