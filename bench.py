@@ -624,7 +624,10 @@ def major_cycle_loop(args, ctx, q, obs, extras=False):
     n = obs.n_vis
     im = template.instantiate(q, ipd, gpd, n, 0, 2)
     im.ensure_all_bound()
-    vis = torch.where(torch.isfinite(obs.vis.real), obs.vis, torch.zeros_like(obs.vis))
+    # a sky with something to CLEAN: 200 point sources + noise (the gridder measurements above
+    # used uniform random visibilities, as the reference's own tests do)
+    synth.add_point_sources(obs, 200, seed=4, noise=0.01)
+    vis = obs.vis
     chunk = _pp.DeviceChunk(
         n, accel.DeviceArray(ctx, (n, 4), np.int16, tensor=obs.uv),
         accel.DeviceArray(ctx, (n,), np.int16, tensor=obs.w_plane),

@@ -1322,7 +1322,7 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
         return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
                 fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
     a, b = run(True), run(False)
-    assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 688
+    assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 1188
     for u, w in zip(a[0], b[0]):
         assert u[0] == w[0] and tuple(u[1]) == tuple(w[1])
         np.testing.assert_array_equal(u[2], w[2])

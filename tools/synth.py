@@ -244,3 +244,47 @@ def grid_truth_fp64(kernel, uv, w_plane, vis, weights_grid, kernel_width, batch=
             vals = smp[:, None, None] * kv[:, :, None] * ku[:, None, :]
             out[p].index_add_(0, idx.reshape(-1), torch.view_as_real(vals).reshape(-1, 2))
     return torch.view_as_complex(out).reshape(P, G, G)
+
+
+def add_point_sources(obs, n_sources=200, seed=4, flux=(0.5, 2.0), noise=0.01, batch=1 << 18):
+    """Replace obs.vis by weights * (visibilities of `n_sources` point sources + noise): a sky that
+    gives CLEAN something to do (BASELINE config 5).  Sources sit on pixel centres of the inner 60 %
+    of the image; V = sum_s flux_s exp(-2 pi i (l u + m v + (n - 1) w)) with (u, v, w) the exact
+    (unquantised) coordinates in wavelengths after the w >= 0 flip, i.e. matching obs.uv.
+    Returns (pixel positions int [S][2] as (y, x), flux [S])."""
+    dev = obs.uv.device
+    rs = np.random.RandomState(seed)
+    G = obs.pixels
+    pos = rs.randint(int(0.2 * G), int(0.8 * G), (n_sources, 2))
+    fl = rs.uniform(flux[0], flux[1], n_sources)
+    l = (pos[:, 1] - 0.5 * G) * obs.pixel_size
+    m = (pos[:, 0] - 0.5 * G) * obs.pixel_size
+    n1 = np.sqrt(1.0 - l * l - m * m) - 1.0
+    lt = torch.from_numpy(l.astype(np.float32)).to(dev)
+    mt = torch.from_numpy(m.astype(np.float32)).to(dev)
+    nt = torch.from_numpy(n1.astype(np.float32)).to(dev)
+    ft = torch.from_numpy(fl.astype(np.float32)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    P = obs.vis.shape[1]
+    inv_wl = 1.0 / obs.wavelength
+    # what a telescope delivers for obs.uvw: unweighted, before the w >= 0 flip (the
+    # preprocessor's input; obs.vis is its output: flipped / conjugated and times the weight)
+    raw = torch.empty_like(obs.vis)
+    for s in range(0, obs.n_vis, batch):
+        e = min(s + batch, obs.n_vis)
+        uvw = obs.uvw[s:e]
+        sign = torch.where(uvw[:, 2] < 0, -inv_wl, inv_wl).to(torch.float32)
+        u, v, w = uvw[:, 0] * sign, uvw[:, 1] * sign, uvw[:, 2] * sign
+        turns = u[:, None] * lt[None, :] + v[:, None] * mt[None, :] + w[:, None] * nt[None, :]
+        turns = turns - torch.floor(turns)
+        ang = turns * (-2.0 * math.pi)
+        re = (torch.cos(ang) * ft[None, :]).sum(dim=1)
+        im = (torch.sin(ang) * ft[None, :]).sum(dim=1)
+        nre = torch.randn((e - s, P), generator=gen, device=dev) * noise
+        nim = torch.randn((e - s, P), generator=gen, device=dev) * noise
+        model = torch.complex(re[:, None] + nre, im[:, None] + nim)
+        obs.vis[s:e] = model * obs.weights[s:e]
+        raw[s:e] = torch.where((uvw[:, 2] < 0)[:, None], torch.conj(model), model)
+    obs.raw_vis = raw
+    return pos, fl
