@@ -131,3 +131,32 @@ def write_fits_image(image, image_parameters, filename, channel, phase_centre, b
         pass
     write_fits(filename, out, cards)
     return out, cards
+
+
+def write_fits_grid(grid, image_parameters, filename, channel):
+    """io.py:228-270: a UV grid as a FITS cube.  ``grid`` complex [polarization][v][u]; the file
+    holds float32 [complex part][polarization][v][u] with axes 1, 2 in metres about the centre
+    cell, a STOKES axis and a COMPLEX axis.  ``filename`` may contain a printf-style place for
+    ``channel``.  ValueError if the polarizations are not a linear FITS sequence.
+    Returns (the array as written, the header as a list of (key, value))."""
+    grid = np.asarray(grid)
+    if grid.ndim != 3 or not np.iscomplexobj(grid):
+        raise ValueError('grid must be complex [polarization][v][u]')
+    real = np.dtype(image_parameters.fixed.real_dtype)
+    parts = np.stack([grid.real, grid.imag]).astype(real)      # [2][P][v][u]
+    ref, step, order = fits_polarization_axis(image_parameters.fixed.polarizations)
+    cell = float(image_parameters.cell_size)
+    cards = [
+        ('BUNIT', 'Jy'), ('ORIGIN', 'katsdpimager_amd'),
+        ('CUNIT1', 'm'), ('CRPIX1', grid.shape[2] // 2 + 1.0), ('CRVAL1', 0.0), ('CDELT1', cell),
+        ('CUNIT2', 'm'), ('CRPIX2', grid.shape[1] // 2 + 1.0), ('CRVAL2', 0.0), ('CDELT2', cell),
+        ('CTYPE3', 'STOKES'), ('CRPIX3', 1.0), ('CRVAL3', float(ref)), ('CDELT3', float(step)),
+        ('CTYPE4', 'COMPLEX'), ('CRPIX4', 1.0), ('CRVAL4', 1.0), ('CDELT4', 1.0),
+    ]
+    out = parts[:, order, :, :]
+    try:
+        filename = filename % channel
+    except TypeError:
+        pass
+    write_fits(filename, out, cards)
+    return out, cards

@@ -519,3 +519,89 @@ def test_write_fits_image(tmp_path):
     keys = [k for k, _ in cards]
     assert 'DATAMIN' not in keys and 'BUNIT' not in keys and 'BMAJ' not in keys
     assert _read_fits(str(tmp_path / 'nan.fits'))[2].shape == (1, 1, 48, 48)
+
+
+def test_write_fits_grid(tmp_path):
+    """io.write_fits_grid (io.py:228-270): float32 [complex][polarization][v][u], axes in metres
+    about the centre cell, STOKES axis with the reference's permutation, COMPLEX axis."""
+    from katsdpimager_amd import io, parameters, polarization
+    pols = [polarization.STOKES_Q, polarization.STOKES_I]       # FITS order is I, Q: permuted
+    fixed = parameters.FixedImageParameters(pols, np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.21, None, pixel_size=2e-5, pixels=64)
+    rs = np.random.RandomState(5)
+    grid = (rs.standard_normal((2, 30, 30)) + 1j * rs.standard_normal((2, 30, 30))).astype(np.complex64)
+    out, cards = io.write_fits_grid(grid, ip, str(tmp_path / 'grid-%03d.fits'), 7)
+    header, history, data = _read_fits(str(tmp_path / 'grid-007.fits'))
+    assert data.shape == (2, 2, 30, 30) and data.dtype == np.dtype('>f4')
+    np.testing.assert_array_equal(data[0], grid.real[[1, 0]])
+    np.testing.assert_array_equal(data[1], grid.imag[[1, 0]])
+    cell = float(ip.cell_size)
+    assert header == {
+        'SIMPLE': True, 'BITPIX': -32, 'NAXIS': 4, 'NAXIS1': 30, 'NAXIS2': 30, 'NAXIS3': 2,
+        'NAXIS4': 2, 'BUNIT': 'Jy', 'ORIGIN': 'katsdpimager_amd', 'CUNIT1': 'm', 'CRPIX1': 16.0,
+        'CRVAL1': 0.0, 'CDELT1': cell, 'CUNIT2': 'm', 'CRPIX2': 16.0, 'CRVAL2': 0.0, 'CDELT2': cell,
+        'CTYPE3': 'STOKES', 'CRPIX3': 1.0, 'CRVAL3': 1.0, 'CDELT3': 1.0, 'CTYPE4': 'COMPLEX',
+        'CRPIX4': 1.0, 'CRVAL4': 1.0, 'CDELT4': 1.0}
+    with pytest.raises(ValueError):
+        io.write_fits_grid(grid.real, ip, str(tmp_path / 'x.fits'), 0)
+    fixed3 = parameters.FixedImageParameters(
+        [polarization.STOKES_I, polarization.STOKES_Q, polarization.STOKES_V], np.float32)
+    ip3 = parameters.ImageParameters(fixed3, 1.0, None, 0.21, None, pixel_size=2e-5, pixels=64)
+    with pytest.raises(ValueError):
+        io.write_fits_grid(np.zeros((3, 8, 8), np.complex64), ip3, str(tmp_path / 'y.fits'), 0)
+
+
+def _loader_arrays(rows=600, channels=3, pols=2, antennas=5, seed=8):
+    from katsdpimager_amd import loader, polarization
+    rs = np.random.RandomState(seed)
+    i, j = np.triu_indices(antennas, 1)
+    nb = len(i)
+    dumps = rows // nb
+    rows = dumps * nb
+    # time order: every baseline of dump 0, then of dump 1, ...
+    baseline = np.tile(i * antennas + j, dumps)
+    uvw = rs.uniform(-900, 900, (rows, 3)).astype(np.float32)
+    vis = (rs.standard_normal((rows, channels, pols))
+           + 1j * rs.standard_normal((rows, channels, pols))).astype(np.complex64)
+    weights = rs.uniform(0.5, 2, (rows, channels, pols)).astype(np.float32)
+    freq = 1.4e9 + 1e6 * np.arange(channels)
+    return loader.LoaderArrays(uvw, vis, weights, baseline, freq,
+                               [polarization.STOKES_XX, polarization.STOKES_YY],
+                               phase_centre=(0.3, -0.5), longest_baseline=1500.0), nb, dumps
+
+
+def test_loader_blocks_are_baseline_sorted(tmp_path):
+    """loader.LoaderArrays.data_iter shapes the stream like loader_ms.py:377-467: blocks of at most
+    max_chunk_vis visibilities over the selected channels, each block in a stable sort by baseline
+    (so a baseline's dumps are adjacent and in time order), channel axis first; round trip
+    through the .npz file; loader.data_iter truncates at vis_limit rows (loader.py:36-59)."""
+    from katsdpimager_amd import loader
+    ds, nb, dumps = _loader_arrays()
+    path = str(tmp_path / 'vis.npz')
+    ds.save(path)
+    ds2 = loader.load(path)
+    assert ds2.num_channels() == 3 and ds2.polarizations() == ds.polarizations()
+    assert ds2.phase_centre() == (0.3, -0.5) and ds2.longest_baseline() == 1500.0
+    assert ds2.array_parameters().longest_baseline == 1500.0 and not ds2.has_feed_angles()
+    assert ds2.wavelength(1) == pytest.approx(299792458.0 / 1.401e9)
+    with pytest.raises(ValueError):
+        loader.load(str(tmp_path / 'vis.ms'))
+    rows = nb * dumps
+    per_block = 7 * nb + 3                  # blocks cut inside a dump
+    seen = 0
+    for chunk in ds2.data_iter(1, 3, per_block * 2):
+        n = len(chunk['uvw'])
+        assert n <= per_block and chunk['vis'].shape == (2, n, 2) == chunk['weights'].shape
+        assert np.all(np.diff(chunk['baselines']) >= 0)
+        # stable: inside a baseline the rows keep their time order = increasing row index
+        start = seen
+        order = np.argsort(ds.baseline[start:start + n], kind='stable') + start
+        np.testing.assert_array_equal(chunk['uvw'], ds.uvw[order])
+        np.testing.assert_array_equal(chunk['vis'], np.swapaxes(ds.vis[order][:, 1:3], 0, 1))
+        seen += n
+        assert chunk['progress'] == seen and chunk['total'] == rows
+    assert seen == rows
+    got = sum(len(c['uvw']) for c in loader.data_iter(ds2, 100, per_block * 3, 0, 3))
+    assert got == 100
+    with pytest.raises(ValueError):
+        next(ds2.data_iter(2, 2))

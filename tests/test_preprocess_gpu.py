@@ -487,3 +487,44 @@ def test_preprocess_fuzz(seed):
     ref = orc.VisibilityCollector(configs, P, buffer_size)
     ref.add(*batch)
     _compare(coll, ref, configs, not feed, P)
+
+
+def test_loader_to_store_in_loader_order():
+    """loader.LoaderArrays (time-ordered rows -> baseline-sorted blocks, as the
+    reference's loaders deliver them) -> loader.preprocess_visibilities -> device collector: the
+    same records, bit for bit, as the restated collector fed with the same blocks; sorting the
+    blocks by baseline is what lets the adjacent-merge compression find its runs."""
+    from katsdpimager_amd import loader, preprocess
+    import test_host_logic as th
+    ds, nb, dumps = th._loader_arrays(rows=40000, channels=2, pols=2, antennas=12, seed=3)
+    # slow tracks: a baseline moves a small fraction of a cell per dump, so that consecutive
+    # dumps of a baseline often fall on the same sub-cell
+    rs = np.random.RandomState(4)
+    base = rs.uniform(-250, 250, (nb, 3)).astype(np.float32)
+    drift = rs.uniform(-0.02, 0.02, (nb, 3)).astype(np.float32)
+    t = np.repeat(np.arange(dumps, dtype=np.float32), nb)
+    b = np.tile(np.arange(nb), dumps)
+    ds.uvw[:] = base[b] + drift[b] * t[:, None]
+    configs = [dict(max_w=320.0, w_slices=2, w_planes=16, oversample=8, cell_size=1.7),
+               dict(max_w=300.0, w_slices=2, w_planes=8, oversample=4, cell_size=0.9)]
+    ctx, q = context_queue()
+    ips, gps = _params(configs, 2)
+    ident = np.identity(2, np.complex64)
+    vis_load = 2 * 4000                    # rows x channels per block
+    coll = preprocess.VisibilityCollectorDevice(q, ips, gps, 4096)
+    loader.preprocess_visibilities(ds, coll, 0, 2, (ident, None), vis_load=vis_load)
+    ref = orc.VisibilityCollector(configs, 2, 4096)
+    blocks = 0
+    for chunk in ds.data_iter(0, 2, vis_load):
+        ref.add(chunk['uvw'], chunk['weights'], chunk['vis'], None, None, ident, None)
+        blocks += 1
+    assert blocks == 10
+    _compare(coll, ref, configs, True, 2)
+    with pytest.raises(RuntimeError):
+        coll.add(ds.uvw[:4], np.swapaxes(ds.weights[:4], 0, 1), np.swapaxes(ds.vis[:4], 0, 1),
+                 None, None, ident, None)           # closed by preprocess_visibilities
+    # the same rows in time order (no baseline sort): far fewer merges
+    unsorted = orc.VisibilityCollector(configs, 2, 4096)
+    unsorted.add(ds.uvw, np.ascontiguousarray(np.swapaxes(ds.weights, 0, 1)),
+                 np.ascontiguousarray(np.swapaxes(ds.vis, 0, 1)), None, None, ident, None)
+    assert ref.num_output < 0.6 * unsorted.num_output
