@@ -584,8 +584,10 @@ def geometry_sweep(args, ctx, q, dev):
         for _ in range(reps):
             op._run()
         q.finish()
+        taken.append(op.last_variant)
         return round(reps * n / (time.perf_counter() - t0) / 1e6, 1)
 
+    taken = []
     obs2 = synth.make_observation(G, n2, 256, P, device=dev, seed=5)
     out['grid_256_planes_Mvis_per_s'] = rate(obs2, K)
     if K != 60:
@@ -602,8 +604,7 @@ def geometry_sweep(args, ctx, q, dev):
                            ('shuffled', synth.order_shuffled)):
         o = fn_order(obs3)
         out['order_%s_Mvis_per_s' % name] = rate(o['obs'], K)
-        if 'note' in o:
-            out['order_%s_note' % name] = o['note']
+        out['order_%s_note' % name] = o['note'] + '; variant taken by auto: ' + str(taken[-1])
     return out
 
 

@@ -49,6 +49,11 @@ extern "C" {
 #define KIMG_VARIANT_AUTO 0     /* MFMA window kernel when the parameters allow it */
 #define KIMG_VARIANT_GENERIC 1  /* one wave per visibility, any kernel width */
 #define KIMG_VARIANT_MFMA 2     /* MFMA window kernel or KIMG_EUNSUPPORTED */
+#define KIMG_VARIANT_BINNED 3   /* kimg_grid only: sort the visibilities by grid tile on the device
+                                 * (bins of window-slack cells, stable radix sort, gather), then the
+                                 * MFMA window kernel over the sorted copies -- for streams without
+                                 * locality (time order, shuffled); needs the scratch of
+                                 * kimg_grid_binned_workspace_bytes; KIMG_EUNSUPPORTED where MFMA is */
 
 /* Form of the device-resident CLEAN loop (argument `form` of kimg_clean_cycles) */
 #define KIMG_CLEAN_FORM_AUTO 0      /* one launch per cycle when the patch's lattice blocks fit the CUs */
@@ -99,6 +104,17 @@ int kimg_kernel_table(void *table, const double *ws, int w_planes, int kernel_wi
  */
 size_t kimg_grid_workspace_bytes(int64_t max_vis, int num_polarizations, int w_planes,
                                  int oversample, int kernel_width);
+/* Scratch of kimg_grid with KIMG_VARIANT_BINNED (includes the above): sort keys and indices, the
+ * sorted copies of uv / w_plane / vis (18 + 8 P bytes per visibility) and the sort's own scratch. */
+size_t kimg_grid_binned_workspace_bytes(int64_t max_vis, int num_polarizations, int w_planes,
+                                        int oversample, int kernel_width);
+/* How well a visibility stream suits the window kernel: *count (device uint32, zeroed by the call)
+ * receives the number of records whose (u, v) cell differs from their predecessor's by more than
+ * the window slack (32 - kernel_width; 32 - (kernel_width + 1) / 2 for widths 33..64) along
+ * either axis: each of them costs a whole-window flush in the direct window kernel.  A caller may
+ * choose KIMG_VARIANT_BINNED when count / num_vis is more than a few percent. */
+int kimg_grid_jumps(const int16_t *uv, int64_t num_vis, int kernel_width, uint32_t *count,
+                    void *stream);
 int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
               int num_polarizations,
               const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,

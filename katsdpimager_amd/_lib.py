@@ -25,6 +25,8 @@ PROTOTYPES = {
     'kimg_error_string': (c_char_p, [I]),
     'kimg_kernel_table': (c_int, [P, P, I, I, I, I, c_double, c_double, c_double, P]),
     'kimg_grid_workspace_bytes': (c_size_t, [L, I, I, I, I]),
+    'kimg_grid_binned_workspace_bytes': (c_size_t, [L, I, I, I, I]),
+    'kimg_grid_jumps': (c_int, [P, L, I, P, P]),
     'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
     'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
     'kimg_degrid_workspace_bytes': (c_size_t, [I, I, I, I]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libkimg.so')
 
-SOURCES = ['api.hip', 'grid.hip', 'grid_mfma.hip', 'degrid_mfma.hip', 'image.hip', 'fft.hip', 'weight.hip',
+SOURCES = ['api.hip', 'grid.hip', 'grid_mfma.hip', 'grid_binned.hip', 'degrid_mfma.hip', 'image.hip', 'fft.hip', 'weight.hip',
            'clean.hip', 'preprocess.hip', 'ktable.hip']
 
 # -ffp-contract=off: a*b+c is fused only where the source says fmaf(); the image/CLEAN

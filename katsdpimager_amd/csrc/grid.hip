@@ -12,6 +12,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
                    const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
                    void *workspace, size_t workspace_bytes, int arith, hipStream_t stream);
+int kimg_grid_binned(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
+                     int P, const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
+                     const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
+                     const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
+                     void *workspace, size_t workspace_bytes, int arith, hipStream_t stream);
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
@@ -269,7 +274,7 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     KIMG_CHECK_ARG(grid && weights_grid && uv && w_plane && vis && convolve_kernel);
     KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
     KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
-                   || variant == KIMG_VARIANT_MFMA);
+                   || variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
                              kernel_width);
     if (rc)
@@ -279,8 +284,13 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     hipStream_t s = (hipStream_t) stream;
     const bool mfma_ok = kimg_grid_mfma_supported(num_polarizations, w_planes, oversample,
                                                   kernel_width);
-    if (variant == KIMG_VARIANT_MFMA && !mfma_ok)
+    if ((variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED) && !mfma_ok)
         return KIMG_EUNSUPPORTED;
+    if (variant == KIMG_VARIANT_BINNED)
+        return kimg_grid_binned(grid, grid_row_stride, grid_pol_stride, grid_size,
+                                num_polarizations, weights_grid, wg_row_stride, wg_pol_stride, uv,
+                                w_plane, vis, num_vis, convolve_kernel, w_planes, oversample,
+                                kernel_width, workspace, workspace_bytes, arith, s);
     if (variant == KIMG_VARIANT_MFMA || (variant == KIMG_VARIANT_AUTO && mfma_ok))
         return kimg_grid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
                               num_polarizations, weights_grid, wg_row_stride, wg_pol_stride, uv,

@@ -209,11 +209,18 @@ def shared_kernel_device(context, image_parameters, grid_parameters, pad=0):
 # --------------------------------------------------------------------------
 # Operators
 # --------------------------------------------------------------------------
-GRID_VARIANTS = {'auto': 0, 'generic': 1, 'mfma': 2}           # KIMG_VARIANT_*
+GRID_VARIANTS = {'auto': 0, 'generic': 1, 'mfma': 2, 'binned': 3}           # KIMG_VARIANT_*
 #: Arithmetic of the matrix instructions (KIMG_ARITH_*): ``fp32`` = v_mfma_f32_32x32x2_f32, every
 #: product and sum in float32 like the reference (grid.py:1049-1052), the default; ``split_fp16`` =
 #: operands as fp16 hi/lo pairs with float32 accumulation (faster, 22-bit operands; opt-in).
 GRID_ARITH = {'fp32': 0, 'split_fp16': 1}
+
+
+#: `auto` variant: calls smaller than this go straight to the window kernel ...
+AUTO_MIN_VIS = 65536
+#: ... larger ones are binned when this fraction of their records would force a window flush (a
+#: flush costs about what 25 visibilities cost; sorting costs about what gridding twice costs)
+AUTO_JUMP_FRACTION = 0.05
 
 
 def _tuning(tuning):
@@ -228,10 +235,17 @@ def _tuning(tuning):
 
 
 class GridderTemplate:
-    """grid.py:549-653.  ``tuning`` may hold ``{'variant': 'auto'|'generic'|'mfma',
+    """grid.py:549-653.  ``tuning`` may hold ``{'variant': 'auto'|'generic'|'mfma'|'binned',
     'arith': 'fp32'|'split_fp16'}`` (the reference's tuning dict carries its autotuned work-group
     shape; there is no autotuner here -- the kernel geometry is fixed by the MFMA tile shape).
-    Both are per template, passed to the C ABI on every call: nothing is read from the environment."""
+    Both are per template, passed to the C ABI on every call: nothing is read from the environment.
+
+    ``mfma`` is the window kernel on the stream as it comes; ``binned`` first sorts the visibilities
+    by grid tile on the device (for streams without locality: time order, shuffled).  ``auto``
+    measures the stream (``kimg_grid_jumps``: records that would force a whole-window flush, one
+    4-byte read-back per call of at least :data:`AUTO_MIN_VIS` visibilities) and takes ``binned``
+    when more than :data:`AUTO_JUMP_FRACTION` of the records jump, unless the caller already knows
+    (``Gridder.locality_hint``)."""
 
     def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
         types.require_float32(fixed_image_parameters.real_dtype, 'GridderTemplate')
@@ -326,21 +340,62 @@ class Gridder(GridDegrid):
         if nbytes:
             self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
                                                 queue=self.command_queue)
+        self._binned_bytes = lib().kimg_grid_binned_workspace_bytes(
+            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2])
+        self._jumps = None
+        #: What the caller knows about the bound visibilities' order, for the `auto` variant: True =
+        #: consecutive records stay close (the window kernel as is), False = no locality (bin first),
+        #: None = measure on every call.  Reset it when other data is bound.
+        self.locality_hint = None
+        #: variant the last call took ('mfma', 'binned' or 'generic'), for tests and reports
+        self.last_variant = None
+
+    def jump_fraction(self):
+        """Fraction of the bound visibilities that would force a whole-window flush in the window
+        kernel (``kimg_grid_jumps``); synchronises with the queue."""
+        if self.num_vis < 2:
+            return 0.0
+        if self._jumps is None:
+            self._jumps = accel.DeviceArray(self.command_queue.context, (1,), np.uint32,
+                                            queue=self.command_queue)
+        check(lib().kimg_grid_jumps(self.buffer('uv').ptr, self.num_vis, self._kernel_args()[3],
+                                    self._jumps.ptr, self.command_queue.handle), 'kimg_grid_jumps')
+        return int(self._jumps.get(self.command_queue)[0]) / self.num_vis
+
+    def _choose_variant(self):
+        variant = self.template.variant
+        if variant != GRID_VARIANTS['auto'] or not self._binned_bytes:
+            return variant
+        if self.locality_hint is not None:
+            return GRID_VARIANTS['mfma' if self.locality_hint else 'binned']
+        if self.num_vis < AUTO_MIN_VIS:
+            return variant
+        return GRID_VARIANTS['binned' if self.jump_fraction() > AUTO_JUMP_FRACTION else 'mfma']
 
     def _run(self):
         grid = self.buffer('grid')
         wg = self.buffer('weights_grid')
         P, G = grid.shape[0], grid.shape[1]
         table, W, OV, K = self._kernel_args()
+        variant = self._choose_variant()
+        if variant == GRID_VARIANTS['binned'] and self._workspace_bytes < self._binned_bytes:
+            if not self._binned_bytes:
+                raise ValueError('the binned variant needs the MFMA window kernel (kernel width <= 64)')
+            # allocated on first use: 34 + 8 P bytes per visibility of max_vis
+            self._workspace = accel.DeviceArray(self.command_queue.context, (self._binned_bytes,),
+                                                np.uint8, queue=self.command_queue)
+            self._workspace_bytes = self._binned_bytes
         rc = lib().kimg_grid(
             grid.ptr, G, G * G, G, P,
             wg.ptr, G, G * G,
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('vis').ptr,
             self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None,
-            self._workspace_bytes, self.template.variant, self.template.arith,
+            self._workspace_bytes, variant, self.template.arith,
             self.command_queue.handle)
         check(rc, 'kimg_grid')
+        self.last_variant = {1: 'generic', 3: 'binned'}.get(variant, 'mfma' if self._binned_bytes
+                                                             else 'generic')
 
 
 class DegridderTemplate:

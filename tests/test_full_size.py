@@ -421,3 +421,39 @@ def test_c5_dirty_image_of_a_sub_band_vs_oracle():
     assert tapered_relerr(got, want, k1d) < 1e-5
     inner = np.s_[:, G // 8:-G // 8, G // 8:-G // 8]
     assert relerr(got[inner], want[inner]) < 1e-4
+
+
+def test_c2_orders_binned_vs_track_order():
+    """Config 2 geometry, 4 M visibilities: the same visibilities in track order (window kernel as
+    is), time-major and shuffled (both binned by `auto`) give the same grid; the loader-shaped,
+    adjacent-merged stream (tools/synth.order_loader_blocks) stays on the window kernel and gives
+    the same grid too (merging only reorders the float sums)."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel
+    n = 4 << 20
+    ctx, q, obs, fn, wg = _setup(4096, n, 32, 1, vis_block=n)
+
+    def run(o):
+        m = o.n_vis
+        pad = n - m
+        z = lambda t: torch.cat([t, torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype,
+                                                device=t.device)]) if pad else t
+        fn.bind(uv=accel.DeviceArray(ctx, (n, 4), np.int16, tensor=z(o.uv)),
+                w_plane=accel.DeviceArray(ctx, (n,), np.int16, tensor=z(o.w_plane)),
+                vis=accel.DeviceArray(ctx, (n, 1), np.complex64, tensor=z(o.vis)))
+        fn.num_vis = m
+        torch.cuda.synchronize()
+        fn.buffer('grid').zero(q)
+        fn()
+        q.finish()
+        return fn.buffer('grid').tensor.clone(), fn.last_variant
+
+    ref, v0 = run(obs)
+    assert v0 == 'mfma'
+    peak = float(ref.abs().max())
+    for order, want_variant in ((synth.order_time_major, 'binned'), (synth.order_shuffled, 'binned'),
+                                (synth.order_loader_blocks, 'mfma')):
+        got, variant = run(order(obs)['obs'])
+        assert variant == want_variant, order.__name__
+        assert float((got - ref).abs().max()) <= 1e-5 * peak, order.__name__

@@ -1482,3 +1482,77 @@ def test_degridder_f16_form_ranges(pattern, W):
     scale = max(float(pred.max()), 1e-30) if pred.size else 1.0
     # (plus one rounding of the stored residual, which is of the size of the visibility)
     assert np.abs(split[~bad] - exact[~bad]).max() <= 2e-6 * scale + 2.4e-7 * np.abs(exact[~bad]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('arith', ARITHS)
+@pytest.mark.parametrize('K,W,P', [(28, 32, 1), (8, 8, 2), (32, 16, 1), (60, 16, 1), (45, 160, 3)])
+def test_gridder_binned_variant(K, W, P, arith):
+    """KIMG_VARIANT_BINNED (device sort by grid tile + the window kernel) on a stream with no
+    locality -- a smooth track and scattered positions, shuffled together -- against the oracle, the
+    direct window kernel and the per-tap kernel; kimg_grid_jumps counts exactly the records whose
+    cell moved by more than the window slack."""
+    from katsdpimager_amd import grid
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=3000)
+    t = gi.grid_track(c)
+    rs = gi.RandomState(K + W)
+    half = t['weights_grid'].shape[-1] // 2 - 1
+    n2 = 2000
+    data = dict(
+        uv=np.concatenate([t['uv'], rs.randint(-half, half, (n2, 2)).astype(np.int16)]),
+        sub_uv=np.concatenate([t['sub_uv'], rs.randint(0, 8, (n2, 2)).astype(np.int16)]),
+        w_plane=np.concatenate([t['w_plane'], rs.randint(0, W, n2).astype(np.int16)]),
+        vis=np.concatenate([t['vis'], rs.complex_uniform(-1, 1, size=(n2, P)).astype(np.complex64)]),
+        weights_grid=t['weights_grid'])
+    order = np.random.RandomState(7).permutation(len(data['uv']))
+    for k in ('uv', 'sub_uv', 'w_plane', 'vis'):
+        data[k] = np.ascontiguousarray(data[k][order])
+    fb, q = _gridder(c, 'binned:' + arith, max_vis=8192)
+    binned = _run_gridder(fb, q, data)
+    assert fb.last_variant == 'binned' and fb._workspace_bytes >= fb._binned_bytes > 0
+    expected = np.zeros(binned.shape, np.complex64)
+    wg = np.zeros(binned.shape, np.float32)
+    gi.middle(wg, data['weights_grid'].shape)[:] = data['weights_grid']
+    orc.grid(fb.convolve_kernel.data, expected, wg, data['uv'], data['sub_uv'], data['w_plane'],
+             data['vis'])
+    assert relerr(binned, expected) < GRID_TOL
+    fd, _ = _gridder(c, 'mfma:' + arith, max_vis=8192)
+    assert relerr(_run_gridder(fd, q, data), binned) < GRID_TOL
+    # the jump count: by definition
+    slack = 32 - (K if K <= 32 else (K + 1) // 2)
+    d = np.abs(np.diff(data['uv'].astype(np.int32), axis=0))
+    want_jumps = int(np.count_nonzero((d[:, 0] > slack) | (d[:, 1] > slack)))
+    assert fd.jump_fraction() == want_jumps / len(data['uv'])
+    # a second call reuses the scratch; fewer visibilities than max_vis are fine
+    sub = {k: (v[:1234] if k != 'weights_grid' else v) for k, v in data.items()}
+    exp2 = np.zeros(binned.shape, np.complex64)
+    orc.grid(fb.convolve_kernel.data, exp2, wg, sub['uv'], sub['sub_uv'], sub['w_plane'], sub['vis'])
+    assert relerr(_run_gridder(fb, q, sub), exp2) < GRID_TOL
+
+
+@pytest.mark.gpu
+def test_gridder_auto_variant_follows_the_stream():
+    """`auto` measures the stream on the device: a track goes to the window kernel as it is, the
+    same visibilities shuffled are binned first, calls below AUTO_MIN_VIS are never measured, and
+    locality_hint overrides the measurement; every route gives the same grid."""
+    from katsdpimager_amd import grid
+    c = gi.make_config(512, 0.0001, 0.01, 1, 28, 32, grid_cover=300, n_vis=70000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'auto', max_vis=70000)
+    direct = _run_gridder(fn, q, t)
+    assert fn.last_variant == 'mfma' and fn.jump_fraction() < 0.03
+    order = np.random.RandomState(3).permutation(c['n_vis'])
+    shuffled = {k: (np.ascontiguousarray(v[order]) if k != 'weights_grid' else v) for k, v in t.items()}
+    got = _run_gridder(fn, q, shuffled)
+    assert fn.last_variant == 'binned' and fn.jump_fraction() > 0.9
+    assert relerr(got, direct) < GRID_TOL
+    fn.locality_hint = True                 # the caller insists: window kernel on the shuffled stream
+    assert relerr(_run_gridder(fn, q, shuffled), direct) < GRID_TOL and fn.last_variant == 'mfma'
+    fn.locality_hint = False
+    assert relerr(_run_gridder(fn, q, t), direct) < GRID_TOL and fn.last_variant == 'binned'
+    fn.locality_hint = None
+    small = {k: (v[:grid.AUTO_MIN_VIS - 1] if k != 'weights_grid' else v) for k, v in shuffled.items()}
+    _run_gridder(fn, q, small)
+    assert fn.last_variant == 'mfma'
+    with pytest.raises(ValueError):
+        grid.GridderTemplate(None, fn.image_parameters.fixed, fn.grid_parameters.fixed, {'variant': 'fast'})

@@ -44,7 +44,7 @@ def test_argument_errors_without_gpu():
     assert lib.kimg_grid(one, 8, 64, 8, 1, one, 8, 64, one, one, one, 4, one, 1, 8, 4, None, 0,
                          0, 7, None) == -10001
     assert lib.kimg_grid(one, 8, 64, 8, 1, one, 8, 64, one, one, one, 4, one, 1, 8, 4, None, 0,
-                         3, 0, None) == -10001
+                         4, 0, None) == -10001
     assert lib.kimg_degrid(one, 8, 64, 8, 1, one, one, one, one, 4, one, 1, 8, 4, None, 0,
                            0, 2, None) == -10001
     assert lib.kimg_grid_weights(None, 1, 1, 2, 2, 1, None, None, 0, None) == -10001
