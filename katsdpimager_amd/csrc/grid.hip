@@ -282,8 +282,10 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     if (num_vis == 0)
         return 0;                                               // grid.py:810-811
     hipStream_t s = (hipStream_t) stream;
-    const bool mfma_ok = kimg_grid_mfma_supported(num_polarizations, w_planes, oversample,
-                                                  kernel_width);
+    // (the window kernel packs first-tap coordinates into 16 bits)
+    const bool mfma_ok = grid_size <= 32000
+                         && kimg_grid_mfma_supported(num_polarizations, w_planes, oversample,
+                                                     kernel_width);
     if ((variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED) && !mfma_ok)
         return KIMG_EUNSUPPORTED;
     if (variant == KIMG_VARIANT_BINNED)

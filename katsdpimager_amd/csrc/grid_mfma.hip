@@ -132,6 +132,8 @@ struct vis_raw {
     float w[P];
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int GROUP = 8;        // visibilities sharing one window check
 // LDS kernel-table rows hold 32 zero-padded taps.  When the LDS budget allows, each row is
 // stored twice (ROW = 64) so that tap (lane - first_tap) mod 32 is a plain "lane + offset"
@@ -145,7 +147,7 @@ template <int P, int SUB>
 struct sub_ops {
     float2 c[P][SUB];
     float2 kv[SUB];
-    float b0[SUB], b1[SUB];
+    v2f b[SUB];             // (tile 0, tile 1) column operand: adjacent registers for v_pk_mul_f32
 };
 
 // min / max over each aligned group of 8 lanes with DPP (VALU rate, no LDS round trips)
@@ -220,8 +222,6 @@ __device__ inline float join_f16(unsigned packed)
 {
     return f16_bits_to_f32(packed & 0xffffu) + f16_bits_to_f32(packed >> 16);
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // A complex tap as it is kept in the tables of the fp16 form: (re_hi | im_hi << 16, re_lo | im_lo << 16)
 __device__ inline uint2 split_tap(float re, float im)
@@ -424,6 +424,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int lane_v = (lane & 31) * 8;                                 // row tap, bytes
     const int lane_u = ((lane & 31) >> 1) * 8 + (b_take_im ? 4 : 0);    // column tap component
     const int lane_s = h ? 8 : 0;                                       // (Re,Im) or (Im,-Re)
+    const unsigned lds_base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) unsigned char *) smem;
+    const uint64_t lane_uv = ((uint64_t) (lds_base + (unsigned) lane_v) << 32) | (lds_base + (unsigned) lane_u);
     // fp16 form: which member of a pair this lane serves, the (whole) column tap it reads, and how
     // its 6 k-slots come from the tap (re_hi, im_hi | re_lo, im_lo): even columns (real part of the
     // result) take (re_hi, im_hi, re_lo, im_lo, re_hi, im_hi) as stored, odd ones (-im_hi, re_hi,
@@ -510,11 +512,26 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         } else {
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
+            if constexpr (ROW == 64 && !TG) {
+                // both LDS addresses with ONE 64-bit add (v_lshl_add_u64): (rx, ry) + (lane_u,
+                // lane_v) with the table's LDS base folded into the lane constants; no carry can
+                // cross (LDS addresses are far below 2^32)
+                typedef const __attribute__((address_space(3))) v2f *lds_f2;
+                typedef const __attribute__((address_space(3))) float *lds_f;
+                const uint64_t sum = (((uint64_t) (unsigned) rec[t].y << 32) | (unsigned) rec[t].x)
+                                     + lane_uv;
+                const unsigned au = (unsigned) sum, av = (unsigned) (sum >> 32);
+                const v2f kvt = *reinterpret_cast<lds_f2>((uintptr_t) av);
+                o.kv[t] = make_float2(kvt.x, kvt.y);
+                o.b[t].x = *reinterpret_cast<lds_f>((uintptr_t) au);
+                o.b[t].y = *reinterpret_cast<lds_f>((uintptr_t) (au + 128));        // column + 16
+            } else {
             const unsigned au = addr_u(rec[t].x);
             o.kv[t] = *reinterpret_cast<const float2 *>(tbytes + addr_v(rec[t].y));
-            o.b0[t] = *reinterpret_cast<const float *>(tbytes + au);
-            o.b1[t] = *reinterpret_cast<const float *>(                                  // column + 16
+            o.b[t].x = *reinterpret_cast<const float *>(tbytes + au);
+            o.b[t].y = *reinterpret_cast<const float *>(                                 // column + 16
                 ROW == 64 ? tbytes + au + 128 : tbytes + (au ^ 128u));
+            }
 #pragma unroll
             for (int p = 0; p < P; p++)
                 o.c[p][t] = *reinterpret_cast<const float2 *>(
@@ -578,11 +595,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             return;
         } else {
         // all operands first, then the MFMAs back to back (no VALU -> MFMA wait states)
-        float a[P][SUB], b0[SUB], b1[SUB];
+        float a[P][SUB];
+        v2f b[SUB];
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
-            b0[t] = o.b0[t] * b_sign;
-            b1[t] = o.b1[t] * b_sign;
+            b[t] = o.b[t] * v2f{b_sign, b_sign};        // one v_pk_mul_f32
 #pragma unroll
             for (int p = 0; p < P; p++)
                 a[p][t] = fmaf(o.c[p][t].x, o.kv[t].x, o.c[p][t].y * o.kv[t].y);
@@ -592,8 +609,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         for (int t = 0; t < SUB; t++)
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b0[t], acc.t0[p], 0, 0, 0);
-                acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b1[t], acc.t1[p], 0, 0, 0);
+                acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b[t].x, acc.t0[p], 0, 0, 0);
+                acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][t], b[t].y, acc.t1[p], 0, 0, 0);
             }
         }
     };
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
 
     for (int64_t b = start; b < end; b += 64) {
         // ---- stage batch b (lane i <-> visibility b + i) and its per-group bounds ----------
-        int gmin_u, gmax_u, gmin_v, gmax_v;
+        int gb_u, gb_v;         // per group of 8 lanes: min | max << 16 of the first-tap coordinates
         {
             const bool ok = coords_ok(b, r0);
             const int u = (short) (r0.uv.x & 0xffff), v = (short) (r0.uv.x >> 16);
@@ -710,10 +727,13 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 live |= (sp[p].x != 0.0f) | (sp[p].y != 0.0f);
             }
             // bounds over each aligned group of 8 lanes; dead visibilities do not constrain
-            gmin_u = group8_min(live ? mu : INT_MAX);
-            gmax_u = group8_max(live ? mu : INT_MIN);
-            gmin_v = group8_min(live ? mv : INT_MAX);
-            gmax_v = group8_max(live ? mv : INT_MIN);
+            // (first-tap coordinates fit 16 bits: |u| < 32768 and the kernel is at most 64 wide)
+            const int gmin_u = group8_min(live ? mu : SHRT_MAX);
+            const int gmax_u = group8_max(live ? mu : SHRT_MIN);
+            const int gmin_v = group8_min(live ? mv : SHRT_MAX);
+            const int gmax_v = group8_max(live ? mv : SHRT_MIN);
+            gb_u = (gmax_u << 16) | (gmin_u & 0xffff);
+            gb_v = (gmax_v << 16) | (gmin_v & 0xffff);
         }
         // advance the global prefetch pipeline: b+64 gets its (dependent) weight gather,
         // b+128 its raw loads
@@ -735,54 +755,66 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         // window moves and cells are flushed).  Inner loop: the hot path, free of any flush
         // code so that the accumulators stay put in their registers; it runs on through the
         // following groups for as long as they fit the current window.
+        // (the decision is a plain scalar branch: each arm has its own copy of the pipeline step, so
+        // that no loop-carried flag has to live in a vector register)
+        auto group_bounds = [&](int first, int &lo_u, int &hi_u, int &lo_v, int &hi_v)
+            __attribute__((always_inline)) {
+            // (min | max << 16) per axis: two v_readlane instead of four
+            const int bu = __builtin_amdgcn_readlane(gb_u, first);
+            const int bv = __builtin_amdgcn_readlane(gb_v, first);
+            lo_u = (short) (bu & 0xffff);
+            hi_u = bu >> 16;
+            lo_v = (short) (bv & 0xffff);
+            hi_v = bv >> 16;
+        };
+        auto step = [&](int q, auto live_tag) __attribute__((always_inline)) {
+            constexpr bool LIVE = decltype(live_tag)::value;
+            const int first = q * 2 * SUB;
+            // clamp look-ahead indices at the end of the batch (those operands are unused)
+            const int next = q + 1 < npairs ? first + 2 * SUB : first;
+            stage_b(Y, first + SUB);
+            stage_a(next);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE)
+                stage_c(X);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_b(X, next);
+            stage_a(next + SUB);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE)
+                stage_c(Y);
+            __builtin_amdgcn_sched_barrier(0);
+        };
         int q = 0;
         while (q < npairs) {
-            bool live;
-            {
-                const int first = q * 2 * SUB;
-                const int lo_u = __builtin_amdgcn_readlane(gmin_u, first);
-                const int hi_u = __builtin_amdgcn_readlane(gmax_u, first);
-                const int lo_v = __builtin_amdgcn_readlane(gmin_v, first);
-                const int hi_v = __builtin_amdgcn_readlane(gmax_v, first);
-                const bool any = lo_u <= hi_u;
-                const bool jump = hi_u - lo_u > Su || hi_v - lo_v > Sv;
-                live = any && !jump;
-                if (live)
-                    fit_window(lo_u, hi_u, lo_v, hi_v);     // whole group shares one window
-                else if (any)
-                    slow_group(first);
-            }
-            for (;;) {
-                const int first = q * 2 * SUB;
-                // clamp look-ahead indices at the end of the batch (those operands are unused)
-                const int next = q + 1 < npairs ? first + 2 * SUB : first;
-                stage_b(Y, first + SUB);
-                stage_a(next);
-                __builtin_amdgcn_sched_barrier(0);
-                if (live)
-                    stage_c(X);
-                __builtin_amdgcn_sched_barrier(0);
-                stage_b(X, next);
-                stage_a(next + SUB);
-                __builtin_amdgcn_sched_barrier(0);
-                if (live)
-                    stage_c(Y);
-                __builtin_amdgcn_sched_barrier(0);
-                q++;
-                if (q >= npairs)
-                    break;
-                if ((q * 2 * SUB) % GROUP == 0) {
-                    // peek at the next group: stay in the hot loop only if it needs no flush
-                    const int lo_u = __builtin_amdgcn_readlane(gmin_u, next);
-                    const int hi_u = __builtin_amdgcn_readlane(gmax_u, next);
-                    const int lo_v = __builtin_amdgcn_readlane(gmin_v, next);
-                    const int hi_v = __builtin_amdgcn_readlane(gmax_v, next);
-                    const bool fits = have && lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + Su
-                                      && lo_v >= Wv && hi_v <= Wv + Sv;
-                    if (!fits)
+            int lo_u, hi_u, lo_v, hi_v;
+            group_bounds(q * 2 * SUB, lo_u, hi_u, lo_v, hi_v);
+            const bool any = lo_u <= hi_u;
+            const bool jump = hi_u - lo_u > Su || hi_v - lo_v > Sv;
+            if (any && !jump) {
+                fit_window(lo_u, hi_u, lo_v, hi_v);     // whole group shares one window
+                for (;;) {
+                    step(q, std::true_type());
+                    q++;
+                    if (q >= npairs)
                         break;
-                    live = true;
+                    if ((q * 2 * SUB) % GROUP == 0) {
+                        // peek at the next group: stay in the hot loop only if it needs no flush
+                        group_bounds(q * 2 * SUB, lo_u, hi_u, lo_v, hi_v);
+                        const bool fits = lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + Su
+                                          && lo_v >= Wv && hi_v <= Wv + Sv;
+                        if (!fits)
+                            break;
+                    }
                 }
+            } else {
+                if (any)
+                    slow_group(q * 2 * SUB);
+                // the group's operands still pass through the pipeline (unused)
+                do {
+                    step(q, std::false_type());
+                    q++;
+                } while (q < npairs && (q * 2 * SUB) % GROUP != 0);
             }
         }
         // the next batch overwrites this wave's staging area

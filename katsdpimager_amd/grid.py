@@ -362,6 +362,13 @@ class Gridder(GridDegrid):
                                     self._jumps.ptr, self.command_queue.handle), 'kimg_grid_jumps')
         return int(self._jumps.get(self.command_queue)[0]) / self.num_vis
 
+    def measure_locality(self):
+        """Set :attr:`locality_hint` from one measurement of the bound visibilities (what the
+        resident store does once per slice); returns the jump fraction."""
+        f = self.jump_fraction()
+        self.locality_hint = f <= AUTO_JUMP_FRACTION
+        return f
+
     def _choose_variant(self):
         variant = self.template.variant
         if variant != GRID_VARIANTS['auto'] or not self._binned_bytes:

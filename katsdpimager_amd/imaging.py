@@ -317,6 +317,9 @@ class Imaging(accel.OperationSequence):
         if len(data) != N:
             raise ValueError('Lengths do not match')
         self._ready()
+        if name == 'uv':
+            # new coordinates from the host: nothing is known about their order
+            (self._side.gridder if self._use_side() else self._gridder).locality_hint = None
         if name in ('uv', 'w_plane', 'vis', 'weights') and self._use_side():
             side = self._side
             if side.buffer(name) is not side.own[name]:
@@ -387,6 +390,7 @@ class Imaging(accel.OperationSequence):
         self._keep_own('uv', 'w_plane', 'vis', 'weights')
         self.num_vis = num_vis
         self.bind(uv=uv, w_plane=w_plane, vis=vis)
+        self._gridder.locality_hint = None
         if weights is not None:
             self.bind(weights=weights)
 
@@ -416,6 +420,7 @@ class Imaging(accel.OperationSequence):
             self.num_vis = n
             side.bind_chunk(uv=chunk.uv, w_plane=chunk.w_plane, weights=chunk.weights,
                             vis=side.own['vis'])
+            side.gridder.locality_hint = getattr(chunk, 'locality', None)
             if field == 'vis':
                 chunk.vis.copy_region(side.queue, side.own['vis'], np.s_[:n], np.s_[:n])
             else:
@@ -429,6 +434,7 @@ class Imaging(accel.OperationSequence):
         n = chunk.num_vis
         self.num_vis = n
         self.bind(uv=chunk.uv, w_plane=chunk.w_plane, weights=chunk.weights)
+        self._gridder.locality_hint = getattr(chunk, 'locality', None)
         own_vis = self.buffer('vis')
         if field == 'vis':
             chunk.vis.copy_region(self.command_queue, own_vis, np.s_[:n], np.s_[:n])

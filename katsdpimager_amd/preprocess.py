@@ -39,12 +39,16 @@ class DeviceChunk:
     """A block of one (channel, w_slice) in HBM.  The arrays are views of the store with
     ``block_size`` rows of which the first ``num_vis`` are valid."""
 
-    def __init__(self, num_vis, uv, w_plane, weights, vis):
+    def __init__(self, num_vis, uv, w_plane, weights, vis, locality=None):
         self.num_vis = num_vis
         self.uv = uv
         self.w_plane = w_plane
         self.weights = weights
         self.vis = vis
+        #: what the store knows about the order of these records, for ``Gridder.locality_hint``:
+        #: True = consecutive records stay close (window kernel as is), False = bin them first,
+        #: None = unknown (the gridder's `auto` variant measures on every call)
+        self.locality = locality
 
     def __len__(self):
         return self.num_vis
@@ -304,6 +308,7 @@ class VisibilityReaderDevice:
         self.collector = collector
         self._stores = collector._stores
         self.store_dtype = collector.store_dtype
+        self._locality_cache = {}
 
     @property
     def num_channels(self):
@@ -328,10 +333,30 @@ class VisibilityReaderDevice:
         if store.length == 0:
             return
         store.ensure_slack(block_size)
+        locality = self._locality(channel, w_slice)
         for start in range(0, store.length, block_size):
             v = store.view(start, block_size)
             yield DeviceChunk(min(block_size, store.length - start), v['uv'], v['w_plane'],
-                              v['weights'], v['vis'])
+                              v['weights'], v['vis'], locality)
+
+    def _locality(self, channel, w_slice):
+        """Measured once per stored slice (``kimg_grid_jumps`` + a 4-byte read-back): does the
+        slice's order suit the window gridder as it is (grid.AUTO_JUMP_FRACTION)?"""
+        key = (channel, w_slice)
+        if key not in self._locality_cache:
+            from . import grid
+            store = self._stores[channel][w_slice]
+            kernel_width = getattr(self.collector.grid_parameters[channel].fixed, 'kernel_width', None)
+            if kernel_width is None or store.length < grid.AUTO_MIN_VIS:
+                self._locality_cache[key] = None
+            else:
+                queue = self.collector.queue
+                count = accel.DeviceArray(queue.context, (1,), np.uint32, queue=queue)
+                check(lib().kimg_grid_jumps(store.arrays['uv'].ptr, store.length, int(kernel_width),
+                                            count.ptr, queue.handle), 'kimg_grid_jumps')
+                jumps = int(count.get(queue)[0])
+                self._locality_cache[key] = jumps <= grid.AUTO_JUMP_FRACTION * store.length
+        return self._locality_cache[key]
 
     def iter_slice(self, channel, w_slice, block_size=None):
         """Yield host record arrays (fields uv, sub_uv, w_plane, weights, vis) like

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Print the headline numbers of a bench.py JSON line (file argument)."""
+import json
+import sys
+
+d = json.load(open(sys.argv[1]))
+r = d['roofline']
+print('fp32  : %8.1f Mvis/s  %.3f ms/step  frac %.4f  launch %.1f us' % (
+    d['value'], d['ms_per_step'], r['frac'], r['avg_launch_us']))
+if 'split_fp16' in d:
+    s = d['split_fp16']
+    print('split : %8.1f Mvis/s  %.3f ms/step  frac %.4f (of fp32 peak %.4f)' % (
+        s['value'], s['ms_per_step'], s['roofline']['frac'],
+        s['roofline'].get('frac_of_fp32_mfma_peak', 0)))
+for k in ('max_norm_error_vs_fp64',):
+    if k in d:
+        print(k, d[k], d.get('split_fp16', {}).get(k))
+for k, v in d.get('secondary', {}).items():
+    print('  ', k, v)
+if 'major_cycle_loop' in d:
+    print('   major_cycle_loop', d['major_cycle_loop'])
+if 'cpu_baseline' in d:
+    print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('all_cores'))
