@@ -78,7 +78,7 @@ __device__ inline uint32_t changed_mask(int W, int nW)
 template <int P>
 __device__ __attribute__((always_inline)) inline void flush_window(
     window_acc<P> &acc, float *__restrict__ grid, int64_t row_stride, int64_t pol_stride,
-    int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane, float scale = 1.0f)
+    int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane, const float (&scale)[P])
 {
     const uint32_t row_mask = full ? 0xffffffffu : changed_mask(Wv, nWv);
     const uint32_t col_mask = full ? 0xffffffffu : changed_mask(Wu, nWu);
@@ -113,7 +113,7 @@ __device__ __attribute__((always_inline)) inline void flush_window(
                 for (int p = 0; p < P; p++) {
                     const float v = t ? acc.t1[p][k] : acc.t0[p][k];
                     if (x_ok[t] && y_ok && v != 0.0f)
-                        atomicAdd(cell + 2 * p * pol_stride, v * scale);
+                        atomicAdd(cell + 2 * p * pol_stride, v * scale[p]);
                     if (t)
                         acc.t1[p][k] = 0.0f;
                     else
@@ -135,6 +135,7 @@ struct vis_raw {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int GROUP = 8;        // visibilities sharing one window check
+constexpr int GROUP_COUNT = 64 / GROUP;
 // LDS kernel-table rows hold 32 zero-padded taps.  When the LDS budget allows, each row is
 // stored twice (ROW = 64) so that tap (lane - first_tap) mod 32 is a plain "lane + offset"
 // address; otherwise (ROW = 32) the wrap costs two more VALU operations per address.
@@ -434,8 +435,38 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int lane_u16 = ((lane & 31) >> 1) * 8;
     const unsigned sel = part ? 0x01000302u : 0x03020100u;      // odd columns swap (re, im)
     const unsigned flip = part ? 0x00008000u : 0u;              // ... and negate im
-    float T_scale = 0.0f;           // sample scale of this wave (0: not chosen yet)
-    float out_scale = 1.0f;         // 1 / (S * S * T)
+    // fp16 form: per-polarization sample scale T = 2^-E, kept as the integer E so that every decision
+    // about it is scalar integer work (gfx950 has no scalar float compare).  E_cur = scale of what
+    // the accumulators hold, E_stage = the scale the staging code last gave to a group,
+    // out_scale = 1 / (S S T) = 2^E / S^2.
+    constexpr int E_NONE = 0x7fff;      // no sample seen yet
+    constexpr int E_WIDE = 0x7ffe;      // (per group) staged unscaled: one visibility at a time
+    int E_cur[P], E_stage[P];
+    float out_scale[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        E_cur[p] = E_stage[p] = E_NONE;
+        out_scale[p] = 1.0f;
+    }
+    // A group (8 visibilities) keeps the scale of its predecessor while its largest sample, times
+    // that scale, stays within [2^-6, 2) (density weights that differ by an order of magnitude
+    // between neighbouring cells must not cost a flush per cell); otherwise the window is flushed and a new scale chosen
+    // (both ways: a run of small samples after a large one gets its own scale).  A group whose own
+    // samples spread over more than 2^11 is handled one visibility at a time; such a visibility
+    // keeps the current scale while it stays within [2^-14, 2) of it (the same lower end as the
+    // smallest member of an ordinary group: its row operand still has 17 good bits on the weakest
+    // tap that matters), so that an occasional tiny sample costs no flush.
+#ifndef KIMG_T_SPREAD
+#define KIMG_T_SPREAD 11
+#endif
+    constexpr int T_SPREAD = KIMG_T_SPREAD;
+    auto sample_exponent = [](unsigned bits) {      // |x| in [2^e, 2^(e+1)) -> e, clamped
+        const int e = (int) (bits >> 23) - 127;
+        return e < -100 ? -100 : (e > 100 ? 100 : e);
+    };
+    auto keeps_scale = [&](int e, int E, int low = -6) {    // 2^e * 2^-E within [2^low, 2)
+        return E != E_NONE && e - E <= 0 && e - E >= low;
+    };
 
     window_acc<P> acc;
 #pragma unroll
@@ -616,7 +647,26 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     };
     // A group whose visibilities do not share one window position (a jump inside the group):
     // rolled loop, window positioned per visibility, operands re-read from LDS.  Rare.
-    auto slow_group = [&](int first) __attribute__((always_inline)) {
+    auto switch_scale = [&](const int (&E_new)[P]) __attribute__((always_inline)) {
+        // the accumulators hold sums in units of the old scale: write them out, then go on
+        // in the new one
+        bool held = false;
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            held |= E_cur[p] != E_NONE;
+        if (have && held)
+            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane,
+                            out_scale);
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            if (E_new[p] != E_NONE && E_new[p] != E_WIDE) {
+                E_cur[p] = E_new[p];
+                out_scale[p] = ldexpf(1.0f / (S_scale * S_scale), E_new[p]);
+            }
+    };
+    // `unscaled` (fp16 form): the group's samples were staged as they are because they spread over
+    // too many binades for one scale; every visibility then checks the accumulators' scale itself.
+    auto slow_group = [&](int first, bool unscaled) __attribute__((always_inline)) {
         for (int t = 0; t < GROUP; t++) {
             const int idx = first + t;
             const int2 org = origins[idx];
@@ -634,6 +684,32 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                        __builtin_amdgcn_readfirstlane(org.y), __builtin_amdgcn_readfirstlane(org.y));
             const int2 r = recs[idx];
             if constexpr (F16) {
+                int vis_shift[P];
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    vis_shift[p] = 0;
+                if (unscaled) {
+                    int E_new[P];
+                    bool change = false;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        unsigned m = max(__float_as_uint(c[p].x) & 0x7fffffffu,
+                                         __float_as_uint(c[p].y) & 0x7fffffffu);
+                        m = (unsigned) __builtin_amdgcn_readfirstlane((int) m);
+                        if (m >= 0x7f800000u)
+                            m = 0;
+                        E_new[p] = E_NONE;
+                        if (m != 0 && !keeps_scale(sample_exponent(m), E_cur[p], -14)) {
+                            E_new[p] = sample_exponent(m);
+                            change = true;
+                        }
+                    }
+                    if (change)
+                        switch_scale(E_new);     // (fit_window above has already placed the window)
+#pragma unroll
+                    for (int p = 0; p < P; p++)
+                        vis_shift[p] = E_cur[p] != E_NONE ? -E_cur[p] : 0;
+                }
                 // one visibility, carried by the first member of a pair; the second contributes 0
                 const unsigned au16 = addr_u16(r.x);
                 const uint2 kvp = *reinterpret_cast<const uint2 *>(tbytes + addr_v(r.y));
@@ -644,7 +720,12 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 const u32x4 B0 = col_operand(tp0), B1 = col_operand(tp1);
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    const u32x4 A = row_operand(samples[p * 64 + idx], kvj, member != 0);
+                    float4 cs = samples[p * 64 + idx];
+                    cs.x = ldexpf(cs.x, vis_shift[p]);
+                    cs.y = ldexpf(cs.y, vis_shift[p]);
+                    cs.z = ldexpf(cs.z, vis_shift[p]);
+                    cs.w = ldexpf(cs.w, vis_shift[p]);
+                    const u32x4 A = row_operand(cs, kvj, member != 0);
                     acc.t0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                         __builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B0), acc.t0[p], 0, 0, 0);
                     acc.t1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -669,6 +750,9 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     for (int64_t b = start; b < end; b += 64) {
         // ---- stage batch b (lane i <-> visibility b + i) and its per-group bounds ----------
         int gb_u, gb_v;         // per group of 8 lanes: min | max << 16 of the first-tap coordinates
+        int gmax_bits[P];       // fp16 form: bits of the group's largest sample | (spread too wide)
+        int Evec[P];            // fp16 form: the scale (exponent) this lane's group was staged with,
+                                // E_WIDE (staged unscaled) or E_NONE (no sample yet)
         {
             const bool ok = coords_ok(b, r0);
             const int u = (short) (r0.uv.x & 0xffff), v = (short) (r0.uv.x >> 16);
@@ -687,38 +771,49 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 sp[p] = ok ? make_float2(r0.v[p].x * r0.w[p], r0.v[p].y * r0.w[p])
                            : make_float2(0.0f, 0.0f);                       // grid.py:1046
             if constexpr (F16) {
-                // keep the wave's samples in fp16 range: T = 2^-e for the largest one in
-                // [2^e, 2^(e+1)); a larger sample later on flushes the window (its cells are
-                // in units of the old T) and picks a new T
-                unsigned mb = 0;
-#pragma unroll
-                for (int p = 0; p < P; p++)
-                    mb = max(mb, max(__float_as_uint(sp[p].x) & 0x7fffffffu,
-                                     __float_as_uint(sp[p].y) & 0x7fffffffu));
-                if (mb >= 0x7f800000u)
-                    mb = 0;         // NaN / Inf samples poison their own footprint, not the scale
-                // wave maximum: DPP butterflies inside the 16-lane rows, then the four rows
-                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0xB1, 0xf, 0xf, true));
-                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x4E, 0xf, 0xf, true));
-                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x141, 0xf, 0xf, true));
-                mb = max(mb, (unsigned) __builtin_amdgcn_mov_dpp((int) mb, 0x140, 0xf, 0xf, true));
-                mb = max(max((unsigned) __builtin_amdgcn_readlane((int) mb, 0),
-                             (unsigned) __builtin_amdgcn_readlane((int) mb, 16)),
-                         max((unsigned) __builtin_amdgcn_readlane((int) mb, 32),
-                             (unsigned) __builtin_amdgcn_readlane((int) mb, 48)));
-                if (mb != 0 && (T_scale == 0.0f || __uint_as_float(mb) * T_scale > 2.0f)) {
-                    if (have && T_scale != 0.0f)
-                        flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv,
-                                        true, lane, out_scale);
-                    int e = (int) (mb >> 23) - 127;
-                    e = e < -100 ? -100 : (e > 100 ? 100 : e);
-                    T_scale = __uint_as_float((unsigned) (127 - e) << 23);
-                    out_scale = 1.0f / (S_scale * S_scale * T_scale);
-                }
+                // keep the samples in fp16 range: a scale T = 2^-E per group of 8 visibilities and
+                // polarization (see keeps_scale / T_SPREAD above), chosen group after group so that
+                // it changes only when it must
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    sp[p].x *= T_scale;
-                    sp[p].y *= T_scale;
+                    unsigned m = max(__float_as_uint(sp[p].x) & 0x7fffffffu,
+                                     __float_as_uint(sp[p].y) & 0x7fffffffu);
+                    if (m >= 0x7f800000u)
+                        m = 0;      // NaN / Inf samples poison their own footprint, not the scale
+                    const int gmax = group8_max((int) m);
+                    const int gmin = group8_min(m ? (int) m : INT_MAX);
+                    // low bit of the group maximum := "spread too wide" (the mantissa's last bit
+                    // does not matter to the choice of scale)
+                    const bool wide = gmax != 0 && (gmax >> 23) - (gmin >> 23) > T_SPREAD;
+                    gmax_bits[p] = (gmax & ~1) | (wide ? 1 : 0);
+                }
+                int Eg[GROUP_COUNT][P];
+#pragma unroll
+                for (int g = 0; g < GROUP_COUNT; g++) {
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const unsigned gm = (unsigned) __builtin_amdgcn_readlane(gmax_bits[p], g * GROUP);
+                        if ((gm & ~1u) != 0 && !(gm & 1u)
+                            && !keeps_scale(sample_exponent(gm), E_stage[p]))
+                            E_stage[p] = sample_exponent(gm);
+                        Eg[g][p] = E_stage[p];
+                    }
+                }
+                // a group with a wide spread in ANY polarization is staged unscaled in all of them
+                bool wide_lane = false;
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    wide_lane |= (gmax_bits[p] & 1) != 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    int e = E_NONE;     // (no sample of this polarization so far: nothing to scale)
+#pragma unroll
+                    for (int g = 0; g < GROUP_COUNT; g++)
+                        e = (lane >> 3) == g ? Eg[g][p] : e;
+                    Evec[p] = wide_lane ? E_WIDE : e;
+                    const int shift = (wide_lane || e == E_NONE) ? 0 : -e;
+                    sp[p].x = ldexpf(sp[p].x, shift);
+                    sp[p].y = ldexpf(sp[p].y, shift);
                 }
             }
 #pragma unroll
@@ -785,13 +880,34 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                 stage_c(Y);
             __builtin_amdgcn_sched_barrier(0);
         };
+        // fp16 form: the scale group `first` was staged with, against the accumulators' scale:
+        // 0 = the same (or nothing staged), 1 = another one (flush, then switch), 2 = staged
+        // unscaled (one visibility at a time)
+        int group_E[P];
+        auto group_scale = [&](int first) __attribute__((always_inline)) {
+            int verdict = 0;
+            if constexpr (F16) {
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    group_E[p] = __builtin_amdgcn_readlane(Evec[p], first);
+                    if (group_E[p] == E_WIDE)
+                        verdict = 2;
+                    else if (group_E[p] != E_NONE && group_E[p] != E_cur[p] && verdict == 0)
+                        verdict = 1;
+                }
+            }
+            return verdict;
+        };
         int q = 0;
         while (q < npairs) {
             int lo_u, hi_u, lo_v, hi_v;
             group_bounds(q * 2 * SUB, lo_u, hi_u, lo_v, hi_v);
             const bool any = lo_u <= hi_u;
             const bool jump = hi_u - lo_u > Su || hi_v - lo_v > Sv;
-            if (any && !jump) {
+            const int scale_verdict = any ? group_scale(q * 2 * SUB) : 0;
+            if (scale_verdict == 1)
+                switch_scale(group_E);
+            if (any && !jump && scale_verdict != 2) {
                 fit_window(lo_u, hi_u, lo_v, hi_v);     // whole group shares one window
                 for (;;) {
                     step(q, std::true_type());
@@ -802,14 +918,15 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
                         // peek at the next group: stay in the hot loop only if it needs no flush
                         group_bounds(q * 2 * SUB, lo_u, hi_u, lo_v, hi_v);
                         const bool fits = lo_u <= hi_u && lo_u >= Wu && hi_u <= Wu + Su
-                                          && lo_v >= Wv && hi_v <= Wv + Sv;
+                                          && lo_v >= Wv && hi_v <= Wv + Sv
+                                          && group_scale(q * 2 * SUB) == 0;
                         if (!fits)
                             break;
                     }
                 }
             } else {
                 if (any)
-                    slow_group(q * 2 * SUB);
+                    slow_group(q * 2 * SUB, scale_verdict == 2);
                 // the group's operands still pass through the pipeline (unused)
                 do {
                     step(q, std::false_type());

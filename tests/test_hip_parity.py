@@ -1556,3 +1556,73 @@ def test_gridder_auto_variant_follows_the_stream():
     assert fn.last_variant == 'mfma'
     with pytest.raises(ValueError):
         grid.GridderTemplate(None, fn.image_parameters.fixed, fn.grid_parameters.fixed, {'variant': 'fast'})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('P,K,W', [(1, 28, 32), (2, 28, 32), (1, 28, 160), (1, 60, 16)])
+@pytest.mark.parametrize('pattern', ['jump_down', 'jump_up', 'spikes', 'ramp', 'pol_ratio'])
+def test_gridder_f16_form_small_samples_per_cell(pattern, P, K, W):
+    """ADVICE r1 (grid_mfma.hip sample scale): small samples must not be judged against the peak of
+    large ones gridded by the same wave.  The grid of the SMALL samples alone (exact form) is the
+    reference: on the cells that no large sample touches, the split form of the full input must
+    reproduce it to 2e-5 of ITS OWN largest value -- after a 10^12 drop, before a 10^12 rise,
+    between isolated 10^9 spikes, along a smooth ramp over 12 decades (every cell against its own
+    neighbourhood), and (two polarizations per launch) with one polarization 10^-7 of the other.
+    (What the form cannot do: a sample's error floor is 2^-40 of its OWN peak contribution, so the
+    far corners of a strong sample's footprint can disturb a 10^8 times weaker neighbour.)"""
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=1500)
+    t = dict(gi.grid_track(c))
+    n = len(t['uv'])
+    rs = np.random.RandomState(11)
+    scale = np.ones((n, P), np.float32)
+    large = np.zeros(n, bool)
+    if pattern == 'jump_down':
+        large[:n // 3 + 5] = True
+    elif pattern == 'jump_up':
+        large[n // 2 + 13:] = True
+    elif pattern == 'spikes':
+        large[rs.choice(n, 12, replace=False)] = True
+    elif pattern == 'ramp':
+        # magnitudes falling smoothly by 12 decades along the track: every cell is compared
+        # with its own neighbourhood (below), not with the start of the track
+        scale *= (10.0 ** np.linspace(6, -6, n))[:, None].astype(np.float32)
+    if pattern == 'pol_ratio':
+        if P == 1:
+            pytest.skip('needs two polarizations in one launch')
+        scale[:, 1] = 1e-7          # the weak polarization is "small" everywhere: checked below
+    elif pattern != 'ramp':
+        scale[large] = 1e6 if pattern != 'spikes' else 1e9
+        scale[~large] = 1e-6 if pattern != 'spikes' else 1.0
+    vis = (t['vis'] * scale).astype(np.complex64)
+
+    def run(arith, v):
+        fn, q = _gridder(c, 'mfma:' + arith, max_vis=2048)
+        return _run_gridder(fn, q, dict(t, vis=v))
+    split = run('split_fp16', vis)
+    if pattern == 'pol_ratio':
+        exact = run('fp32', vis)
+        for p in range(P):
+            peak = np.abs(exact[p]).max()
+            assert np.abs(split[p] - exact[p]).max() <= 2e-6 * peak, p
+        return
+    if pattern == 'ramp':
+        from scipy import ndimage
+        exact = run('fp32', vis)
+        local = ndimage.maximum_filter(np.abs(exact), size=(1, 2 * K + 1, 2 * K + 1))
+        touched = local > 0
+        assert np.all(np.abs(split - exact)[touched] <= 2e-5 * local[touched])
+        assert local[touched].min() < 1e-9 * local.max()        # the ramp really spans the decades
+        return
+    small_only = vis.copy()
+    small_only[large] = 0
+    large_only = vis.copy()
+    large_only[~large] = 0
+    ref_small = run('fp32', small_only)
+    touched_by_large = run('fp32', large_only) != 0
+    cells = (~touched_by_large) & (ref_small != 0)
+    assert cells.sum() > 200            # (the track moves on: cells that see only small samples)
+    local_peak = np.abs(ref_small[cells]).max()
+    assert np.abs(split[cells] - ref_small[cells]).max() <= 2e-5 * local_peak
+    # and the whole grid still meets the global gate
+    exact = run('fp32', vis)
+    assert np.abs(split - exact).max() <= 2e-6 * np.abs(exact).max()
