@@ -56,3 +56,44 @@ def kernel_taper(c):
     from oracle import kimg_oracle as orc
     return orc.taper(c['pixels'], c['antialias_width'], orc.kernel_beta(c['antialias_width']),
                      c['oversample'])
+
+
+def grid_to_image_truth(grid, kernel1d, lm_scale, lm_bias, w):
+    """float64 evaluation of GridToImageHost (image.py:781-799) for a [P][G][G] grid: the
+    oracle's formulas, which are dtype-generic, run on complex128 / float64 copies."""
+    from oracle import kimg_oracle as orc
+    grid = np.asarray(grid, np.complex128)
+    image = np.zeros(grid.shape, np.float64)
+    orc.grid_to_image(grid, image, np.asarray(kernel1d, np.float64), float(lm_scale), float(lm_bias),
+                      float(w))
+    return image
+
+
+def grid_truth_numpy(kernel, uv, sub_uv, w_plane, vis, weights_grid):
+    """float64 evaluation of the gridding sum (grid.py:1032-1052) with numpy (small inputs)."""
+    kern = np.asarray(kernel, np.complex128)
+    P, G = weights_grid.shape[0], weights_grid.shape[-1]
+    K = kern.shape[-1]
+    half = G // 2
+    bias = (K - 1) // 2 - half
+    out = np.zeros((P, G * G), np.complex128)
+    u = uv[:, 0].astype(np.int64)
+    v = uv[:, 1].astype(np.int64)
+    taps = np.arange(K)
+    kv = np.conj(kern[w_plane, sub_uv[:, 1]])
+    ku = np.conj(kern[w_plane, sub_uv[:, 0]])
+    idx = ((v - bias)[:, None, None] + taps[None, :, None]) * G + ((u - bias)[:, None, None] + taps[None, None, :])
+    for p in range(P):
+        smp = vis[:, p].astype(np.complex128) * weights_grid[p][v + half, u + half].astype(np.float64)
+        vals = smp[:, None, None] * kv[:, :, None] * ku[:, None, :]
+        np.add.at(out[p], idx.reshape(-1), vals.reshape(-1))
+    return out.reshape(P, G, G)
+
+
+def taper_zones(taper1d, threshold=1e-2):
+    """(well-conditioned zone, the rest) of an image divided by outer(taper, taper): where the
+    product is at least `threshold` of its peak the division amplifies a float32 FFT's rounding by
+    at most 1 / threshold."""
+    t2 = np.outer(taper1d, taper1d).astype(np.float64)
+    good = t2 >= threshold * t2.max()
+    return good, ~good, t2
