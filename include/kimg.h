@@ -34,6 +34,9 @@ extern "C" {
 #define KIMG_EINVAL (-10001)      /* bad argument (null pointer, negative size ...) */
 #define KIMG_EUNSUPPORTED (-10002) /* parameter combination not supported by this build */
 #define KIMG_EWORKSPACE (-10003)   /* workspace too small */
+#define KIMG_ETIMEOUT (-10004)     /* workgroups of a persistent kernel did not see each other in time
+                                    * (reported after the stream was synchronised by the caller: see
+                                    * kimg_clean_cycles) */
 
 /* Arithmetic of the gridder / degridder matrix instructions (argument `arith`):
  *   KIMG_ARITH_FP32        v_mfma_f32_32x32x2_f32 -- every product and sum in float32, bit-identical
@@ -59,6 +62,11 @@ extern "C" {
 #define KIMG_CLEAN_FORM_AUTO 0      /* one launch per cycle when the patch's lattice blocks fit the CUs */
 #define KIMG_CLEAN_FORM_TWO_LAUNCH 1
 #define KIMG_CLEAN_FORM_ONE_LAUNCH 2    /* falls back to two launches when the patch is too large */
+#define KIMG_CLEAN_FORM_PERSISTENT 3    /* the whole loop in one launch of resident workgroups (small
+                                         * patches: at most 64 lattice blocks, tile maxima in LDS);
+                                         * falls back to ONE_LAUNCH otherwise.  Measured slower than
+                                         * ONE_LAUNCH (agent-scope hand-offs cost what the kernel
+                                         * boundary costs): AUTO does not take it. */
 
 #define KIMG_CLEAN_I 0      /* clean.py:29 */
 #define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */
@@ -326,7 +334,9 @@ int kimg_noise_est(const float *image, int64_t row_stride, int64_t pol_stride,
  *   log    device float32 [max_cycles][3 + P]: (metric, y, x as float bits, loop_gain*pixel[p])
  *   form   KIMG_CLEAN_FORM_*
  *   After the stream is synchronised, ((int32*)state)[0] holds the number of cycles done
- *   (stops early when the peak metric < threshold, clean.py:879-880).
+ *   (stops early when the peak metric < threshold, clean.py:879-880); ((int32*)state)[1] is 2 if
+ *   the persistent form gave up waiting (KIMG_ETIMEOUT for the caller to raise; the images are
+ *   then undefined).
  */
 size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int tiles_y);
 int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,

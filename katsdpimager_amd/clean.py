@@ -337,12 +337,13 @@ class _SubtractPsf(accel.Operation):
         check(rc, 'kimg_subtract_psf')
 
 
-CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2}     # KIMG_CLEAN_FORM_*
+CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2, 'persistent': 3}     # KIMG_CLEAN_FORM_*
 
 
 class CleanTemplate:
-    """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'}``, the
-    form of the device-resident loop of :meth:`Clean.run_cycles` (results are identical)."""
+    """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'|
+    'persistent'}``, the form of the device-resident loop of :meth:`Clean.run_cycles` (results are
+    identical; ``auto`` takes the fastest one the PSF patch allows)."""
     def __init__(self, context, clean_parameters, dtype, num_polarizations, tuning=None):
         types.require_float32(dtype, 'CleanTemplate')
         tuning = tuning or {}
@@ -447,7 +448,10 @@ class Clean(accel.OperationSequence):
             tile_max.shape[1], tile_max.shape[0], max_cycles, self.template.form,
             self._state.ptr, self._log.ptr, self.command_queue.handle)
         check(rc, 'kimg_clean_cycles')
-        count = int(self._state.get(self.command_queue)[0])
+        state = self._state.get(self.command_queue)
+        if int(state[1]) == 2:
+            check(-10004, 'kimg_clean_cycles')       # KIMG_ETIMEOUT: the persistent loop gave up
+        count = int(state[0])
         log = self._log.get(self.command_queue)[:count]
         pos = log[:, 1:3].copy().view(np.int32)
         return [(log[i, 0], (int(pos[i, 0]), int(pos[i, 1])), log[i, 3:].copy())

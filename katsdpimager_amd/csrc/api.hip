@@ -10,6 +10,7 @@ extern "C" const char *kimg_error_string(int code)
     case KIMG_EINVAL: return "invalid argument";
     case KIMG_EUNSUPPORTED: return "unsupported parameter combination";
     case KIMG_EWORKSPACE: return "workspace too small";
+    case KIMG_ETIMEOUT: return "persistent kernel timed out waiting for its peer workgroups";
     default:
         if (code < 0 && code > -10000)
             return hipGetErrorString((hipError_t) (-code));

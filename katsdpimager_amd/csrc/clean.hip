@@ -109,6 +109,28 @@ __device__ inline key_t block_max_key(key_t k, key_t *s_keys)
     return read_lane_key(k, 0);
 }
 
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global
+// store of the wave (its release semantics), which puts the latency of stores nobody is waiting
+// for on a latency-critical chain.
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// block_max_key with that barrier
+__device__ inline key_t block_max_key_lds(key_t k, key_t *s_keys)
+{
+    k = row_max_key(k);
+    const key_t w = key_max(key_max(read_lane_key(k, 0), read_lane_key(k, 16)),
+                            key_max(read_lane_key(k, 32), read_lane_key(k, 48)));
+    if ((threadIdx.x & 63) == 0)
+        s_keys[threadIdx.x >> 6] = w;
+    lds_barrier();
+    const int nw = blockDim.x >> 6, e = threadIdx.x & 15;
+    k = row_max_key(e < nw ? s_keys[e] : 0);
+    return read_lane_key(k, 0);
+}
+
 template <int MODE>
 __device__ inline float clean_metric(const float *__restrict__ dirty, int64_t addr,
                                      int64_t pol_stride, int P)
@@ -741,6 +763,365 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     }
 }
 
+// ---- the whole minor-cycle loop in ONE launch ----------------------------------------------
+// The one-launch-per-cycle form above still pays a kernel boundary per cycle (2.1 us between
+// dependent graph nodes + a cold first load).  Here the lattice workgroups of a small PSF patch
+// (at most PERSIST_MAX_WGS, all resident at once, one per CU) stay alive for the whole call and
+// hand their results to each other through memory:
+//   * after its subtraction a workgroup drains its pixel stores (every wave s_waitcnt vmcnt(0),
+//     barrier) and publishes ONE record -- the rewritten tile, or "no tile" -- as eight 8-byte
+//     {word, tag} granules, each written by a single write-through (sc1) store: a reader that sees
+//     all eight tags of cycle c has a consistent record and, because the pixel stores were
+//     write-through and drained first, may read those pixels (MI355X_MICROARCH.md, hand-offs with
+//     sc1 stores / loads and data-tagged granules);
+//   * at the top of a cycle the first waves poll the records of all workgroups (sc1 loads), route
+//     them through LDS to the threads that own the tiles, and every workgroup then finds the peak
+//     itself exactly as in the one-launch form -- so all agree on it without further exchange;
+//   * pixels are read and written with sc1 (L1-bypassing, write-through) accesses, since another
+//     workgroup's CU may have written them a cycle earlier;
+//   * everything a workgroup needs besides is PRIVATE to it: the tile maxima live in its LDS, the
+//     owners' best-two in registers, tile positions / peak pixels in a replica of its own in the
+//     scratch buffer (workgroup 0 uses the real arrays), all updated from the same records;
+//   * records are double-buffered by cycle parity: a workgroup can only be one cycle ahead of the
+//     slowest one.
+// Selection and arithmetic are those of the other forms, bit for bit.  Every wait is bounded: a
+// workgroup that does not see its peers within PERSIST_SPIN_LIMIT polls raises `error` and
+// everybody leaves (kimg_clean_cycles then reports KIMG_ETIMEOUT).
+//
+// MEASURED (MI355X, 4096^2, 111 x 133 patch = 30 workgroups; wall_clock64 stamps of workgroup 0,
+// build flag -DKIMG_CLEAN_STAMPS): 10.3-11.0 us per cycle against 6.2 for the one-launch-per-cycle
+// form, so KIMG_CLEAN_FORM_AUTO does NOT take this form; it stays selectable and tested.  Per cycle:
+// 2.6-3.0 us until the records of all peers are visible (an agent-scope hand-off is a fabric write
+// plus a fabric read, and the poll itself is a 1-us round trip), 0.4 routing / applying, 2.4-2.9
+// until the peak is known (the waves whose owners got a record rescan their tiles and fetch a
+// record before they reach the reduction's barrier -- work the one-launch form leaves to its
+// keeper workgroup, off the critical path), 1.05 for the block's pixels (sc1 loads are served from
+// the memory side), 1.0 subtract + rescan + stores, 0.1 drain.  Moving the rescan behind the
+// publication would bring it to about 5.7 us: the hand-off alone costs what the kernel boundary
+// cost, which is why none of the in-launch exchanges tried so far beat one launch per cycle.
+constexpr int PERSIST_MAX_WGS = 64;
+constexpr int PERSIST_SPIN_LIMIT = 1 << 21;
+constexpr size_t PERSIST_LDS_LIMIT = 160 * 1024 - 2048;
+
+struct persist_header {
+    unsigned long long records[2][PERSIST_MAX_WGS][8];      // {word | tag << 32}
+    int error;
+    int pad[15];
+    // replicas follow: [wgs - 1][tiles] x { int y, x; float pix[4] }
+};
+
+struct replica_t {
+    int y, x;
+    float pix[4];
+};
+
+__device__ inline float load_sc1(const float *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline void store_sc1(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_persistent_kernel(
+    float *dirty, float *model, int64_t row_stride, int64_t pol_stride, int width, int height,
+    int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+    int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
+    int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain, float threshold, int limit,
+    fused_scratch *scratch, persist_header *hdr, replica_t *replicas, float *log)
+{
+    extern __shared__ __align__(16) unsigned char persist_smem[];
+    __shared__ key_t s_keys[16];
+    __shared__ int s_pos[2];
+    __shared__ float s_pix[4];
+    __shared__ int s_abort;
+    const int tiles = tiles_x * tiles_y;
+    float *s_tile_max = reinterpret_cast<float *>(persist_smem);
+    delta_t *s_delta = reinterpret_cast<delta_t *>(persist_smem + (((size_t) tiles * 4 + 15) & ~(size_t) 15));
+    float *tile_pix = reinterpret_cast<float *>(scratch + 1);
+    const int tid = threadIdx.x;
+    const int nwgs = gridDim.x * gridDim.y;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    // this workgroup's own copy of (tile position, peak pixels): workgroup 0 keeps the real arrays
+    replica_t *mine = wg ? replicas + (size_t) (wg - 1) * tiles : nullptr;
+
+    for (int i = tid; i < tiles; i += 1024) {
+        s_tile_max[i] = tile_max[i];
+        if (wg) {
+            replica_t r;
+            r.y = tile_pos[2 * i];
+            r.x = tile_pos[2 * i + 1];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                r.pix[p] = tile_pix[4 * i + p];
+            mine[i] = r;
+        }
+    }
+    s_delta[tid].tag = 0;
+    if (tid == 0)
+        s_abort = 0;
+    __syncthreads();
+    owner_best_t ob;
+    {
+        owned_tiles walk(tid, tiles_x, tiles_y);
+        ob = walk.best(s_tile_max, -1, 0.0f);
+    }
+    // (position, peak pixels) of this owner's best tile, kept in registers: the peak search then
+    // needs no memory access at all
+    auto load_record = [&](int t) {
+        replica_t r;
+        if (wg) {
+            r = mine[t];
+        } else {
+            r.y = tile_pos[2 * t];
+            r.x = tile_pos[2 * t + 1];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                r.pix[p] = tile_pix[4 * t + p];
+        }
+        return r;
+    };
+    replica_t best_rec = {0, 0, {0.0f, 0.0f, 0.0f, 0.0f}};
+    if (ob.v1 >= 0.0f)
+        best_rec = load_record(ob.t1);
+
+#ifdef KIMG_CLEAN_STAMPS
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = wall_clock64();
+#define PSTAMP(i) do { if (wg == 0 && tid == 0) { const long long n_ = wall_clock64(); pacc[i] += n_ - pt; pt = n_; } } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+    int count = 0;
+    for (;;) {
+        PSTAMP(0);
+        // ---- the records of the previous cycle ------------------------------------------------
+        delta_t d;
+        d.tag = 0;
+        if (count > 0) {
+            if (tid < nwgs) {
+                const unsigned long long *rec = hdr->records[(count - 1) & 1][tid];
+                const unsigned tag = (unsigned) count + 1;
+                unsigned long long g[8];
+                int spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        g[k] = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned) (g[k] >> 32) == tag;
+                    }
+                    if (ok)
+                        break;
+                    if (++spins > PERSIST_SPIN_LIMIT
+                        || __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(&hdr->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_abort = 1;
+                        break;
+                    }
+                }
+                const int tile = (int) (unsigned) g[0];
+                if (!s_abort && tile >= 0) {
+                    // route the record to the thread that owns the tile
+                    delta_t o;
+                    o.tag = (int) tag;
+                    o.tile = tile;
+                    o.value = __uint_as_float((unsigned) g[1]);
+                    o.y = (int) (unsigned) g[2];
+                    o.x = (int) (unsigned) g[3];
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        o.pix[p] = __uint_as_float((unsigned) g[4 + p]);
+                    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                    s_delta[(ty & 31) * 32 + (tx & 31)] = o;
+                }
+            }
+            PSTAMP(1);
+            __syncthreads();
+            if (s_abort)
+                return;
+            d = s_delta[tid];
+            if (d.tag == count + 1) {
+                s_tile_max[d.tile] = d.value;           // (only ever read by this thread: it owns the tile)
+                if (wg) {
+                    replica_t r;
+                    r.y = d.y;
+                    r.x = d.x;
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        r.pix[p] = d.pix[p];
+                    mine[d.tile] = r;
+                } else {
+                    tile_pos[2 * d.tile] = d.y;
+                    tile_pos[2 * d.tile + 1] = d.x;
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        tile_pix[4 * d.tile + p] = d.pix[p];
+                }
+                owned_tiles walk(tid, tiles_x, tiles_y);
+                ob = walk.best(s_tile_max, -1, 0.0f);
+                if (ob.v1 >= 0.0f) {
+                    if (ob.t1 == d.tile) {
+                        best_rec.y = d.y;
+                        best_rec.x = d.x;
+#pragma unroll
+                        for (int p = 0; p < 4; p++)
+                            best_rec.pix[p] = d.pix[p];
+                    } else {
+                        best_rec = load_record(ob.t1);
+                    }
+                }
+            }
+        }
+        if (count >= limit)
+            break;
+        PSTAMP(2);
+
+        // ---- the peak: every workgroup for itself ----------------------------------------------
+        const float bv = ob.v1;
+        const int bi = ob.t1;
+        const int2 cpos = make_int2(best_rec.y, best_rec.x);
+        const float4 cpix = make_float4(best_rec.pix[0], best_rec.pix[1], best_rec.pix[2], best_rec.pix[3]);
+        const key_t mykey = bv < 0.0f ? 0 : make_key(bv, bi);
+        const key_t best = block_max_key_lds(mykey, s_keys);
+        const float value = __uint_as_float((unsigned) (best >> 32));
+        PSTAMP(3);
+        if (best == 0 || value < threshold)                         // clean.py:1065-1066
+            break;
+        if (mykey == best) {        // exactly one thread: every tile has one owner
+            s_pos[0] = cpos.x;
+            s_pos[1] = cpos.y;
+            s_pix[0] = cpix.x;
+            s_pix[1] = cpix.y;
+            s_pix[2] = cpix.z;
+            s_pix[3] = cpix.w;
+        }
+        lds_barrier();
+        const int py = s_pos[0], px = s_pos[1];
+        if (value == 0.0f) {
+            // a tile without any positive metric won: its record holds the (x0, y0) start position
+            // of clean.py:950, whose pixel is read now, as the other forms do
+            __syncthreads();
+            if (tid < 4) {
+                const bool ok = py >= 0 && py < height && px >= 0 && px < width && tid < P;
+                s_pix[tid] = ok ? load_sc1(dirty + tid * pol_stride + (int64_t) py * row_stride + px) : 0.0f;
+            }
+            __syncthreads();
+        }
+        float scale[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            scale[p] = loop_gain * s_pix[p];                            // clean.py:1044
+        if (wg == 0 && tid < P) {
+            float *entry = log + (int64_t) count * (3 + P);
+            float *mp = model + tid * pol_stride + (int64_t) py * row_stride + px;
+            if (tid == 0) {
+                entry[0] = value;
+                entry[1] = __int_as_float(py);
+                entry[2] = __int_as_float(px);
+            }
+            entry[3 + tid] = scale[tid];
+            *mp = *mp + scale[tid];                                     // clean.py:1047
+        }
+
+        // ---- this workgroup's lattice block ----------------------------------------------------
+        const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
+        const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
+        const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
+        const int tx = bx0 + (int) blockIdx.x, ty = by0 + (int) blockIdx.y;
+        const int ox = tx * TILE + border, oy = ty * TILE + border;
+        const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;
+        const bool is_tile = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;
+        const int x = ox + (tid & 31), y = oy + (tid >> 5);
+        const bool inside = x >= 0 && x < width && y >= 0 && y < height;
+        const int64_t ia = (int64_t) y * row_stride + x;
+        const bool in_patch = inside && x >= x0 && x < x0 + patch_w && y >= y0 && y < y0 + patch_h;
+        const bool in_tile = inside && is_tile && x < width - border && y < height - border;
+        float dv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (inside)
+            for (int p = 0; p < P; p++)
+                dv[p] = load_sc1(dirty + p * pol_stride + ia);
+        if (in_patch)
+            for (int p = 0; p < P; p++)
+                pv[p] = psf[p * psf_pol_stride + (int64_t) (y + psf_dy) * psf_row_stride + (x + psf_dx)];
+        float metric = 0.0f;
+#ifdef KIMG_CLEAN_STAMPS
+        if (dv[0] + pv[0] == 12345.678f)
+            pacc[7] = 1;
+        PSTAMP(4);
+#endif
+        for (int p = 0; p < P; p++) {
+            if (in_patch) {
+                const float tp = scale[p] * pv[p];
+                dv[p] -= tp;
+                store_sc1(dirty + p * pol_stride + ia, dv[p]);
+            }
+            if (MODE == KIMG_CLEAN_I) {
+                if (p == 0)
+                    metric = fabsf(dv[0]);
+            } else {
+                metric += dv[p] * dv[p];
+            }
+        }
+        // first strict maximum in row-major order; only positive metrics count (clean.py:953-958)
+        // (the barrier inside also orders s_pos / s_pix against the next cycle's writes)
+        const key_t tb = block_max_key((in_tile && metric > 0.0f) ? make_key(metric, tid) : 0, s_keys);
+        const int widx = ~(int) (unsigned) tb;
+        PSTAMP(5);
+        // every wave's pixel stores have left the CU before the record says so
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        PSTAMP(6);
+        if (tb == 0 ? tid == 0 : tid == widx) {
+            unsigned w[8];
+            w[0] = (unsigned) (is_tile ? ty * tiles_x + tx : -1);
+            if (tb == 0) {
+                // no positive metric: value 0 and the (x0, y0) initial position of clean.py:950
+                w[1] = __float_as_uint(0.0f);
+                w[2] = (unsigned) ox;
+                w[3] = (unsigned) oy;
+                w[4] = w[5] = w[6] = w[7] = 0u;
+            } else {
+                w[1] = __float_as_uint(metric);
+                w[2] = (unsigned) y;
+                w[3] = (unsigned) x;
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    w[4 + p] = __float_as_uint(dv[p]);
+            }
+            unsigned long long *rec = hdr->records[count & 1][wg];
+            const unsigned long long tag = (unsigned long long) (unsigned) (count + 2) << 32;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                __hip_atomic_store(rec + k, tag | w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        count++;
+    }
+    __syncthreads();        // (the owners' last updates of the LDS tile maxima, read by other threads below)
+    if (wg == 0) {
+        // the tile maxima go back to the caller's array; positions / peak pixels are already there
+        for (int i = tid; i < tiles; i += 1024)
+            tile_max[i] = s_tile_max[i];
+        if (tid == 0) {
+            scratch->st[0].count = count;
+            scratch->st[0].done = 1;
+#ifdef KIMG_CLEAN_STAMPS
+            for (int i = 0; i < 8; i++)
+                scratch->st[0].pad[i] = (int) (pacc[i] / (count > 0 ? count : 1));
+#endif
+        }
+    }
+}
+
+// state[1] := 2 when the persistent loop gave up (see kimg.h)
+__global__ void persist_status_kernel(fused_scratch *scratch, const persist_header *hdr)
+{
+    if (hdr->error)
+        scratch->st[0].done = 2;
+}
+
 // Pixel values at every tile's peak position (the part of a tile record the tile scan of
 // kimg_update_tiles does not produce); once per kimg_clean_cycles call.
 __global__ __launch_bounds__(256) void tile_pix_kernel(
@@ -989,13 +1370,21 @@ extern "C" int kimg_subtract_psf(float *dirty, float *model, int64_t row_stride,
     return kimg_launch_status();
 }
 
+// byte offset of the persistent form's header in the state buffer (behind fused_scratch + tile_pix)
+static size_t persist_offset(int tiles_x, int tiles_y)
+{
+    const size_t n = sizeof(fused_scratch) + (size_t) tiles_x * tiles_y * 4 * sizeof(float);
+    return (n + 255) / 256 * 256;
+}
+
 extern "C" size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int tiles_y)
 {
     (void) num_polarizations;
     static_assert(sizeof(fused_scratch) >= sizeof(clean_state), "the two forms share the scratch");
     if (tiles_x <= 0 || tiles_y <= 0)
         return 0;
-    return sizeof(fused_scratch) + (size_t) tiles_x * tiles_y * 4 * sizeof(float);
+    return persist_offset(tiles_x, tiles_y) + sizeof(persist_header)
+           + (size_t) (PERSIST_MAX_WGS - 1) * tiles_x * tiles_y * sizeof(replica_t);
 }
 
 namespace {
@@ -1153,7 +1542,7 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
     KIMG_CHECK_ARG(form == KIMG_CLEAN_FORM_AUTO || form == KIMG_CLEAN_FORM_TWO_LAUNCH
-                   || form == KIMG_CLEAN_FORM_ONE_LAUNCH);
+                   || form == KIMG_CLEAN_FORM_ONE_LAUNCH || form == KIMG_CLEAN_FORM_PERSISTENT);
     hipStream_t s = (hipStream_t) stream;
     // one launch per cycle when the patch touches few lattice blocks (every workgroup then
     // repeats the global peak search)
@@ -1167,6 +1556,39 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
         tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
             dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
             tiles_x * tiles_y, static_cast<fused_scratch *>(state));
+    // the whole loop in one launch when the patch's lattice blocks can all be resident and the
+    // tile maxima fit LDS
+    const size_t persist_lds = (((size_t) tiles_x * tiles_y * 4 + 15) & ~(size_t) 15)
+                               + 1024 * sizeof(delta_t);
+    const bool persistent = fused && bx * by <= PERSIST_MAX_WGS && persist_lds <= PERSIST_LDS_LIMIT
+                            && form == KIMG_CLEAN_FORM_PERSISTENT && max_cycles > 0;
+    if (persistent) {
+        unsigned char *base = static_cast<unsigned char *>(state) + persist_offset(tiles_x, tiles_y);
+        persist_header *hdr = reinterpret_cast<persist_header *>(base);
+        replica_t *replicas = reinterpret_cast<replica_t *>(base + sizeof(persist_header));
+        KIMG_HIP(hipMemsetAsync(hdr, 0, sizeof(persist_header), s));
+        const dim3 g(bx, by);
+#define PERSIST(MODE) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+            KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cycle_persistent_kernel<MODE>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int) PERSIST_LDS_LIMIT)); \
+            attr_set = true; \
+        } \
+        cycle_persistent_kernel<MODE><<<g, 1024, persist_lds, s>>>( \
+            dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf, \
+            psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height, border, \
+            tile_max, tile_pos, tiles_x, tiles_y, loop_gain, threshold, max_cycles, \
+            static_cast<fused_scratch *>(state), hdr, replicas, log); } while (0)
+        if (mode == KIMG_CLEAN_I)
+            PERSIST(KIMG_CLEAN_I);
+        else
+            PERSIST(KIMG_CLEAN_SUMSQ);
+#undef PERSIST
+        persist_status_kernel<<<1, 1, 0, s>>>(static_cast<fused_scratch *>(state), hdr);
+        return kimg_launch_status();
+    }
     if (fused)
         owner_best_kernel<<<1, 1024, 0, s>>>(tile_max, tiles_x, tiles_y,
                                              static_cast<fused_scratch *>(state));

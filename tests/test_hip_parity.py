@@ -1303,8 +1303,7 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
     cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, mode, 0.01, 0.5, border)
     full_patch = (P,) + patch
 
-    def run(fused):
-        form = 'one_launch' if fused else 'two_launch'
+    def run(form):
         fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form}).instantiate(q, ip)
         fn.ensure_all_bound()
         fn.buffer('dirty').set(q, dirty)
@@ -1321,14 +1320,16 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
         log += fn.run_cycles(full_patch, 0.5 * first, 500)
         return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
                 fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
-    a, b = run(True), run(False)
-    assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 1188
-    for u, w in zip(a[0], b[0]):
-        assert u[0] == w[0] and tuple(u[1]) == tuple(w[1])
-        np.testing.assert_array_equal(u[2], w[2])
-    for u, w in zip(a[1:], b[1:]):
-        np.testing.assert_array_equal(u, w)
-    assert border == 0.0 or (3, 5) not in [tuple(e[1]) for e in a[0]]
+    b = run('two_launch')
+    for form in ('one_launch', 'persistent'):
+        a = run(form)
+        assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 1188
+        for u, w in zip(a[0], b[0]):
+            assert u[0] == w[0] and tuple(u[1]) == tuple(w[1])
+            np.testing.assert_array_equal(u[2], w[2])
+        for u, w in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(u, w)
+        assert border == 0.0 or (3, 5) not in [tuple(e[1]) for e in a[0]]
 
 
 @pytest.mark.gpu
