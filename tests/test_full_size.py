@@ -268,20 +268,24 @@ def test_full_size_noise_estimate_and_clean_rate_invariants(G, P):
                                rtol=1e-3)
 
 
-def test_c2_f16_form_vs_exact_and_repeatable():
-    """Config 2 geometry, 2.2 M visibilities: the fp16 hi/lo form of the gridder (tuning arith =
-    'split_fp16') against the exact-fp32 form and against itself (the only run-to-run difference
-    allowed is the order of the float atomics)."""
-    ctx, q, obs, fn, wg = _setup(4096, 2_200_000, 32, 1)
-    _, _, _, fn_split, _ = _setup(4096, 2_200_000, 32, 1, arith='split_fp16')
+def test_c2_forms_repeatable_at_scale():
+    """A/B harness at config-2 scale (the round-1 packed-math variant differed by 7e-3 of
+    the peak between two runs at this scale while every small test passed): 8.4 M visibilities,
+    each arithmetic form gridded three times.  The only run-to-run difference allowed is the order
+    of the float atomics (5e-7 of the peak); the split form stays within 2e-6 of the float32 form;
+    both touch exactly the same cells."""
+    n = 8 << 20
+    ctx, q, obs, fn, wg = _setup(4096, n, 32, 1)
+    _, _, _, fn_split, _ = _setup(4096, n, 32, 1, arith='split_fp16')
     fn_split.bind(weights_grid=wg)
-    exact = _grid_all(ctx, q, obs, fn).clone()
-    split = _grid_all(ctx, q, obs, fn_split).clone()
-    again = _grid_all(ctx, q, obs, fn_split).clone()
-    peak = float(exact.abs().max())
-    assert float((split - exact).abs().max()) <= 2e-6 * peak
-    assert float((split - again).abs().max()) <= 5e-7 * peak
-    assert int((split != 0).sum()) == int((exact != 0).sum())
+    exact = [_grid_all(ctx, q, obs, fn).clone() for _ in range(3)]
+    split = [_grid_all(ctx, q, obs, fn_split).clone() for _ in range(3)]
+    peak = float(exact[0].abs().max())
+    for runs in (exact, split):
+        for other in runs[1:]:
+            assert float((runs[0] - other).abs().max()) <= 5e-7 * peak
+    assert float((split[0] - exact[0]).abs().max()) <= 2e-6 * peak
+    assert int((split[0] != 0).sum()) == int((exact[0] != 0).sum())
 
 
 # ---- BASELINE config 5: the major-cycle loop at full size -------------------------------------
