@@ -282,8 +282,10 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
     if (num_vis == 0)
         return 0;                                               // grid.py:810-811
     hipStream_t s = (hipStream_t) stream;
-    // (the window kernel packs first-tap coordinates into 16 bits)
+    // (the window kernel packs first-tap coordinates into 16 bits and addresses a polarization's
+    // plane with 32-bit byte offsets)
     const bool mfma_ok = grid_size <= 32000
+                         && (int64_t) grid_size * grid_row_stride * 8 < ((int64_t) 1 << 32)
                          && kimg_grid_mfma_supported(num_polarizations, w_planes, oversample,
                                                      kernel_width);
     if ((variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED) && !mfma_ok)

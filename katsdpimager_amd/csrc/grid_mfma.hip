@@ -75,53 +75,88 @@ __device__ inline uint32_t changed_mask(int W, int nW)
 // instruction covers two grid rows x 128 contiguous bytes (16 complex cells), the shape
 // global float atomics run at full rate for.  Registers whose rows and columns are all
 // unaffected are skipped with a scalar test.
-template <int P>
+//
+// Window moves are frequent on fast tracks (every few visibilities for the 30-tap blocks of a wide
+// kernel, whose slack is 2 cells), and a wave issues at most one instruction every few cycles, so
+// the flush is built for a short INSTRUCTION STREAM: 32-bit byte offsets on a scalar base
+// (global_atomic ... s[base]), the grid row of register k as two vector instructions plus one
+// multiply-add per tile, and no per-cell test that the kind of move makes unnecessary --
+// ROWS says whether row predicates are needed at all (false for the common pure column move),
+// and windows that lie wholly inside the grid (nearly all) skip the bounds tests.
+// SCALED: multiply by scale[p] on the way out (fp16 form); the float32 form's scale is 1.
+template <int P, bool SCALED, bool ROWS, bool COLS, bool BOUNDS>
+__device__ __attribute__((always_inline)) inline void flush_cells(
+    window_acc<P> &acc, float *__restrict__ grid, unsigned row_bytes, int64_t pol_stride, int Gg,
+    int Wu, int Wv, uint32_t row_mask, uint32_t col_mask, int lane, const float (&scale)[P])
+{
+    const int part = lane & 1;
+    const int cx0 = (lane & 31) >> 1;
+    const int c = (lane >> 5) * 4 - Wv;             // window row of register k = (rk + c) & 31
+    const uint32_t lane_rows = row_mask >> ((lane >> 5) * 4);   // bit rk <-> this lane's row of register k
+    unsigned base[2];
+    bool col_sel[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int cx = cx0 + 16 * t;
+        const int xold = Wu + ((cx - Wu) & 31);
+        base[t] = (unsigned) Wv * row_bytes + (unsigned) (2 * xold + part) * 4u;   // (wraps like the sum)
+        col_sel[t] = COLS ? ((col_mask >> cx) & 1u) != 0 : false;
+        if (BOUNDS && (unsigned) xold >= (unsigned) Gg)
+            base[t] = 0xffffffffu;                  // marks a column outside the grid
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        constexpr uint32_t one = 1u;
+        const int rk = (k & 3) + 8 * (k >> 2);          // MFMA 32x32 C/D row of register k (lower half)
+        if (ROWS && !COLS && (row_mask & ((one << rk) | (one << (rk + 4)))) == 0)
+            continue;                                   // uniform: nothing of register k moves
+        const unsigned rr = (unsigned) (rk + c) & 31u;
+        const bool row_sel = ROWS ? ((lane_rows >> rk) & 1u) != 0 : false;
+        const bool y_ok = BOUNDS ? (unsigned) (Wv + (int) rr) < (unsigned) Gg : true;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const bool sel = (ROWS || COLS) ? (row_sel || col_sel[t]) : true;
+            const unsigned off = rr * row_bytes + base[t];      // v_mad_u32_u24
+            const bool inside = BOUNDS ? (y_ok && base[t] != 0xffffffffu) : true;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const float v = t ? acc.t1[p][k] : acc.t0[p][k];
+                if (sel && inside && v != 0.0f) {
+                    float *cell = reinterpret_cast<float *>(
+                        reinterpret_cast<char *>(grid + 2 * p * pol_stride) + off);
+                    atomicAdd(cell, SCALED ? v * scale[p] : v);
+                }
+                if (t)
+                    acc.t1[p][k] = sel ? 0.0f : v;
+                else
+                    acc.t0[p][k] = sel ? 0.0f : v;
+            }
+        }
+    }
+}
+
+template <int P, bool SCALED>
 __device__ __attribute__((always_inline)) inline void flush_window(
     window_acc<P> &acc, float *__restrict__ grid, int64_t row_stride, int64_t pol_stride,
     int Gg, int Wu, int Wv, int nWu, int nWv, bool full, int lane, const float (&scale)[P])
 {
     const uint32_t row_mask = full ? 0xffffffffu : changed_mask(Wv, nWv);
     const uint32_t col_mask = full ? 0xffffffffu : changed_mask(Wu, nWu);
-    const int part = lane & 1;
-    const int cx0 = (lane & 31) >> 1;
-    const int h4 = (lane >> 5) * 4;
-    const uint32_t lane_rows = row_mask >> h4;      // bit rk <-> this lane's row of register k
-    int xold[2];
-    bool col_changed[2], x_ok[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int cx = cx0 + 16 * t;
-        xold[t] = Wu + ((cx - Wu) & 31);
-        col_changed[t] = (col_mask >> cx) & 1u;
-        x_ok[t] = (unsigned) xold[t] < (unsigned) Gg;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        constexpr uint32_t one = 1u;
-        const int rk = (k & 3) + 8 * (k >> 2);          // MFMA 32x32 C/D row of register k
-        if (col_mask == 0 && (row_mask & ((one << rk) | (one << (rk + 4)))) == 0)
-            continue;                                   // uniform: nothing of register k moves
-        const int r = rk + h4;
-        const int yold = Wv + ((r - Wv) & 31);
-        const bool row_changed = (lane_rows >> rk) & 1u;
-        const bool y_ok = (unsigned) yold < (unsigned) Gg;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            if (col_changed[t] || row_changed) {
-                float *cell = grid + 2 * ((int64_t) yold * row_stride + xold[t]) + part;
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const float v = t ? acc.t1[p][k] : acc.t0[p][k];
-                    if (x_ok[t] && y_ok && v != 0.0f)
-                        atomicAdd(cell + 2 * p * pol_stride, v * scale[p]);
-                    if (t)
-                        acc.t1[p][k] = 0.0f;
-                    else
-                        acc.t0[p][k] = 0.0f;
-                }
-            }
-        }
-    }
+    if ((row_mask | col_mask) == 0)
+        return;
+    const unsigned row_bytes = (unsigned) row_stride * 8u;  // (grid_size * row_bytes < 2^32: checked on the host)
+    const bool inside = Wu >= 0 && Wv >= 0 && Wu + WIN <= Gg && Wv + WIN <= Gg;
+#define KIMG_FLUSH(ROWS, COLS, BOUNDS) flush_cells<P, SCALED, ROWS, COLS, BOUNDS>( \
+        acc, grid, row_bytes, pol_stride, Gg, Wu, Wv, row_mask, col_mask, lane, scale)
+    // the two common moves of a window inside the grid get their own short code; everything else
+    // (both axes at once, jumps and other full flushes, windows at the grid's rim) the general form
+    if (inside && !full && row_mask == 0)
+        KIMG_FLUSH(false, true, false);         // along u only
+    else if (inside && !full && col_mask == 0)
+        KIMG_FLUSH(true, false, false);         // along v only
+    else
+        KIMG_FLUSH(true, true, true);
+#undef KIMG_FLUSH
 }
 
 template <int P>
@@ -495,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         const int nWv = !bad_v ? Wv : (hi_v > Wv + Sv ? lo_v : hi_v - Sv);
         const bool full = nWu - Wu >= WIN || Wu - nWu >= WIN || nWv - Wv >= WIN || Wv - nWv >= WIN;
         if (!(dbg & 2))
-            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane,
+            flush_window<P, F16>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, nWu, nWv, full, lane,
                             out_scale);
         Wu = nWu;
         Wv = nWv;
@@ -655,7 +690,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         for (int p = 0; p < P; p++)
             held |= E_cur[p] != E_NONE;
         if (have && held)
-            flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane,
+            flush_window<P, F16>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane,
                             out_scale);
 #pragma unroll
         for (int p = 0; p < P; p++)
@@ -938,7 +973,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     if (have && !(dbg & 1))
-        flush_window<P>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane, out_scale);
+        flush_window<P, F16>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane, out_scale);
 }
 
 template <int P>
