@@ -171,148 +171,6 @@ __global__ __launch_bounds__(256) void pp_convert_kernel(
 
 // ---- compress ---------------------------------------------------------------------------
 
-// valid[i] = record survives the flag test of compress (weights[0] != 0, :339,:352); also
-// primes the sort arrays and zeroes the per-slice counters.
-template <int P>
-__global__ __launch_bounds__(256) void pp_valid_kernel(
-    int64_t n, const float *__restrict__ w, int *__restrict__ valid,
-    unsigned short *__restrict__ skey, int *__restrict__ sval, int w_slices,
-    unsigned long long *__restrict__ counts)
-{
-    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < w_slices)
-        counts[i] = 0;
-    if (i >= n)
-        return;
-    valid[i] = (w[i * P] != 0.0f) ? 1 : 0;
-    skey[i] = (unsigned short) w_slices;      // sentinel: sorts behind every real slice
-    sval[i] = (int) i;
-}
-
-__global__ __launch_bounds__(256) void pp_compact_kernel(
-    int64_t n, const int *__restrict__ valid, const int *__restrict__ pos, int *__restrict__ cidx)
-{
-    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && valid[i])
-        cidx[pos[i]] = (int) i;
-}
-
-// head[k] = compacted record k starts a new output visibility (:354 memcmp of the key prefix)
-__global__ __launch_bounds__(256) void pp_head_kernel(
-    int64_t n, const int *__restrict__ valid, const int *__restrict__ pos,
-    const int *__restrict__ cidx, const short *__restrict__ key, int *__restrict__ head)
-{
-    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
-        return;
-    int nv = pos[n - 1] + valid[n - 1];
-    int h = 0;
-    if (k < nv) {
-        if (k == 0)
-            h = 1;
-        else {
-            const int *a = reinterpret_cast<const int *>(key + 6 * (int64_t) cidx[k]);
-            const int *b = reinterpret_cast<const int *>(key + 6 * (int64_t) cidx[k - 1]);
-            h = (a[0] != b[0]) | (a[1] != b[1]) | (a[2] != b[2]);
-        }
-    }
-    head[k] = h;
-}
-
-// hidx[o] = compacted index of the head of output run o.
-__global__ __launch_bounds__(256) void pp_headidx_kernel(
-    int64_t n, const int *__restrict__ head, const int *__restrict__ opos, int *__restrict__ hidx)
-{
-    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n && head[k])
-        hidx[opos[k]] = (int) k;
-}
-
-// One thread per OUTPUT record: it sums its run of adjacent equal keys in arrival order
-// (:356-360, bit-identical to the host loop) and writes the merged record.  With one w-slice
-// the record goes straight to its final place.
-template <int P>
-__global__ __launch_bounds__(256) void pp_merge_kernel(
-    int64_t n, const int *__restrict__ nv_valid, const int *__restrict__ nv_pos,
-    const int *__restrict__ cidx, const int *__restrict__ head, const int *__restrict__ opos,
-    const int *__restrict__ hidx,
-    const short *__restrict__ key, const float *__restrict__ w, const float2 *__restrict__ vis,
-    int single_slice,
-    short *__restrict__ m_uv, short *__restrict__ m_wplane, float *__restrict__ m_w,
-    float2 *__restrict__ m_vis, unsigned short *__restrict__ skey,
-    unsigned long long *__restrict__ counts)
-{
-    int64_t o = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n)
-        return;
-    const int nv = nv_pos[n - 1] + nv_valid[n - 1];
-    const int m = nv > 0 ? opos[n - 1] + head[n - 1] : 0;
-    if (single_slice && o == 0)
-        counts[0] = (unsigned long long) m;
-    if (o >= m)
-        return;
-    const int64_t k = hidx[o];
-    const int64_t k_end = (o + 1 < m) ? hidx[o + 1] : nv;
-    int64_t e = cidx[k];
-    const int *kp = reinterpret_cast<const int *>(key + 6 * e);
-    int k01 = kp[0], k23 = kp[1], k45 = kp[2];
-    float aw[P];
-    float2 av[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        aw[p] = w[e * P + p];
-        av[p] = vis[e * P + p];
-    }
-    // Long runs (slowly moving short baselines) are latency chains: fetch UNROLL elements
-    // ahead, then add them in arrival order.
-    constexpr int UNROLL = 8;
-    int64_t j = k + 1;
-    for (; j + UNROLL <= k_end; j += UNROLL) {
-        int64_t f[UNROLL];
-        float2 tv[UNROLL][P];
-        float tw[UNROLL][P];
-#pragma unroll
-        for (int i = 0; i < UNROLL; i++)
-            f[i] = cidx[j + i];
-#pragma unroll
-        for (int i = 0; i < UNROLL; i++)
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                tv[i][p] = vis[f[i] * P + p];
-                tw[i][p] = w[f[i] * P + p];
-            }
-#pragma unroll
-        for (int i = 0; i < UNROLL; i++)
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                av[p].x += tv[i][p].x;
-                av[p].y += tv[i][p].y;
-                aw[p] += tw[i][p];
-            }
-    }
-    for (; j < k_end; j++) {
-        int64_t f = cidx[j];
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            float2 t = vis[f * P + p];
-            av[p].x += t.x;
-            av[p].y += t.y;
-            aw[p] += w[f * P + p];
-        }
-    }
-    int *uv32 = reinterpret_cast<int *>(m_uv + 4 * o);
-    uv32[0] = k01;
-    uv32[1] = k23;
-    m_wplane[o] = (short) (k45 & 0xffff);
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        m_w[o * P + p] = aw[p];
-        m_vis[o * P + p] = av[p];
-    }
-    if (!single_slice)
-        skey[o] = (unsigned short) (k45 >> 16);
-}
-
 // Run length per w-slice from the sorted slice ids (a same-address atomic per record would
 // serialise in L2): counts[s] = lower_bound(s + 1) - lower_bound(s).  Unused tail entries
 // carry the sentinel w_slices and sort behind everything.
@@ -339,9 +197,8 @@ __global__ void pp_slice_counts_kernel(
 
 // Apply the stable slice order: output t takes merged record perm[t].
 template <int P>
-__global__ __launch_bounds__(256) void pp_gather_kernel(
-    int64_t n, const int *__restrict__ head, const int *__restrict__ opos,
-    const int *__restrict__ perm,
+__global__ __launch_bounds__(256) void pp_gather_stream_kernel(
+    int64_t n, const int *__restrict__ ipos, const int *__restrict__ perm,
     const short *__restrict__ m_uv, const short *__restrict__ m_wplane,
     const float *__restrict__ m_w, const float2 *__restrict__ m_vis,
     short *__restrict__ out_uv, short *__restrict__ out_wplane, float *__restrict__ out_w,
@@ -350,7 +207,7 @@ __global__ __launch_bounds__(256) void pp_gather_kernel(
     int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n)
         return;
-    int m = opos[n - 1] + head[n - 1];
+    const int m = ipos[n - 1];
     if (t >= m)
         return;
     int64_t s = perm[t];
@@ -372,10 +229,143 @@ __global__ __launch_bounds__(256) void pp_real_to_complex_kernel(
         dst[i] = make_float2(src[i], 0.0f);
 }
 
+// ---- compress, fused (round 2): two scans with the index kernels folded into their input
+// iterators, and a merge that walks the uncompacted stream -----------------------------------
+//   scan 1 (inclusive max): pv[i] = index of the last valid record at or before i (-1: none),
+//           input computed on the fly from the weights (the flag test of :339,:352);
+//   scan 2 (inclusive sum): ipos[i] = number of run heads at or before i, a head being a valid
+//           record whose key differs from the previous valid record's (:354), input computed on the
+//           fly from pv and the keys;
+//   merge:  the thread of a head sums its run in arrival order (skipping flagged records) and
+//           writes output record ipos[i] - 1.
+// Five launches per buffer instead of thirteen (each scan is two rocPRIM kernels).
+struct pp_valid_index {
+    const float *w;
+    int P;
+    __host__ __device__ int operator()(int i) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return w[(int64_t) i * P] != 0.0f ? i : -1;
+#else
+        return -1;
+#endif
+    }
+};
+
+struct pp_max_op {
+    __host__ __device__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+
+struct pp_head_flag {
+    const int *pv;
+    const short *key;
+    __host__ __device__ int operator()(int i) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (pv[i] != i)
+            return 0;                           // flagged record
+        const int prev = i > 0 ? pv[i - 1] : -1;
+        if (prev < 0)
+            return 1;
+        const int *a = reinterpret_cast<const int *>(key + 6 * (int64_t) i);
+        const int *b = reinterpret_cast<const int *>(key + 6 * (int64_t) prev);
+        return (a[0] != b[0]) | (a[1] != b[1]) | (a[2] != b[2]);
+#else
+        return 0;
+#endif
+    }
+};
+
+template <int P>
+__global__ __launch_bounds__(256) void pp_merge_stream_kernel(
+    int64_t n, const int *__restrict__ pv, const int *__restrict__ ipos,
+    const short *__restrict__ key, const float *__restrict__ w, const float2 *__restrict__ vis,
+    int single_slice,
+    short *__restrict__ m_uv, short *__restrict__ m_wplane, float *__restrict__ m_w,
+    float2 *__restrict__ m_vis, unsigned short *__restrict__ skey,
+    unsigned long long *__restrict__ counts)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int m = ipos[n - 1];
+    if (single_slice && i == n - 1)
+        counts[0] = (unsigned long long) m;
+    const int here = ipos[i];
+    if (pv[i] != i || here == (i > 0 ? ipos[i - 1] : 0))
+        return;                                 // flagged, or a later member of somebody's run
+    const int64_t o = here - 1;
+    const int *kp = reinterpret_cast<const int *>(key + 6 * i);
+    const int k01 = kp[0], k23 = kp[1], k45 = kp[2];
+    float aw[P];
+    float2 av[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        aw[p] = w[i * P + p];
+        av[p] = vis[i * P + p];
+    }
+    // Long runs (slowly moving short baselines) are latency chains: fetch UNROLL records ahead,
+    // then add the valid ones of this run in arrival order (bit-identical to the host loop).
+    constexpr int UNROLL = 8;
+    int64_t j = i + 1;
+    bool more = true;
+    while (more && j < n) {
+        int run[UNROLL];
+        float2 tv[UNROLL][P];
+        float tw[UNROLL][P];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t f = j + u < n ? j + u : n - 1;
+            run[u] = j + u < n ? ipos[f] : here + 1;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                tv[u][p] = vis[f * P + p];
+                tw[u][p] = w[f * P + p];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (run[u] != here)
+                more = false;                   // the next run has begun
+            if (more && tw[u][0] != 0.0f) {     // (flagged records inside the run are skipped)
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    av[p].x += tv[u][p].x;
+                    av[p].y += tv[u][p].y;
+                    aw[p] += tw[u][p];
+                }
+            }
+        }
+        j += UNROLL;
+    }
+    int *uv32 = reinterpret_cast<int *>(m_uv + 4 * o);
+    uv32[0] = k01;
+    uv32[1] = k23;
+    m_wplane[o] = (short) (k45 & 0xffff);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        m_w[o * P + p] = aw[p];
+        m_vis[o * P + p] = av[p];
+    }
+    if (!single_slice)
+        skey[o] = (unsigned short) (k45 >> 16);
+}
+
+// (several w-slices only) the sort arrays: sentinel keys, identity values
+__global__ __launch_bounds__(256) void pp_sort_init_kernel(
+    int64_t n, unsigned short *__restrict__ skey, int *__restrict__ sval, int w_slices)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    skey[i] = (unsigned short) w_slices;      // sorts behind every real slice
+    sval[i] = (int) i;
+}
+
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct pp_workspace {
-    int *valid, *pos, *cidx, *head, *opos, *hidx, *sval_in, *sval_out;
+    int *valid, *pos, *sval_in, *sval_out;      // valid = pv (last valid index), pos = ipos (heads so far)
     unsigned short *skey_in, *skey_out;
     short *m_uv, *m_wplane;
     float *m_w;
@@ -394,11 +384,17 @@ int slice_bits(int w_slices)
 
 hipError_t layout_workspace(int64_t n, int P, char *base, pp_workspace &ws)
 {
-    size_t scan_bytes = 0, sort_bytes = 0;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int *) nullptr,
+    size_t scan_bytes = 0, sort_bytes = 0, scan2_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (int *) nullptr,
                                                     (int *) nullptr, (int) n);
     if (e != hipSuccess)
         return e;
+    e = hipcub::DeviceScan::InclusiveScan(nullptr, scan2_bytes, (int *) nullptr, (int *) nullptr,
+                                          pp_max_op(), (int) n);
+    if (e != hipSuccess)
+        return e;
+    if (scan2_bytes > scan_bytes)
+        scan_bytes = scan2_bytes;
     e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned short *) nullptr,
                                            (unsigned short *) nullptr, (int *) nullptr,
                                            (int *) nullptr, (int) n, 0, 16);
@@ -413,10 +409,6 @@ hipError_t layout_workspace(int64_t n, int P, char *base, pp_workspace &ws)
     size_t ni = (size_t) n * sizeof(int);
     ws.valid = (int *) take(ni);
     ws.pos = (int *) take(ni);
-    ws.cidx = (int *) take(ni);
-    ws.head = (int *) take(ni);
-    ws.opos = (int *) take(ni);
-    ws.hidx = (int *) take(ni);
     ws.sval_in = (int *) take(ni);
     ws.sval_out = (int *) take(ni);
     ws.skey_in = (unsigned short *) take((size_t) n * 2);
@@ -462,17 +454,21 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
 {
     const int blocks = kimg_divup(n, 256);
     const int single = (w_slices == 1);
-    pp_valid_kernel<P><<<kimg_divup(n > w_slices ? n : w_slices, 256), 256, 0, stream>>>(
-        n, w, ws.valid, ws.skey_in, ws.sval_in, w_slices, counts);
+    int *pv = ws.valid, *ipos = ws.pos;         // (the arrays of the unfused pipeline, reused)
     size_t cb = ws.cub_bytes;
-    KIMG_HIP(hipcub::DeviceScan::ExclusiveSum(ws.cub, cb, ws.valid, ws.pos, (int) n, stream));
-    pp_compact_kernel<<<blocks, 256, 0, stream>>>(n, ws.valid, ws.pos, ws.cidx);
-    pp_head_kernel<<<blocks, 256, 0, stream>>>(n, ws.valid, ws.pos, ws.cidx, key, ws.head);
+    hipcub::CountingInputIterator<int> index(0);
+    hipcub::TransformInputIterator<int, pp_valid_index, hipcub::CountingInputIterator<int>>
+        valid_index(index, pp_valid_index{w, P});
+    KIMG_HIP(hipcub::DeviceScan::InclusiveScan(ws.cub, cb, valid_index, pv, pp_max_op(), (int) n,
+                                               stream));
+    hipcub::TransformInputIterator<int, pp_head_flag, hipcub::CountingInputIterator<int>>
+        head_flag(index, pp_head_flag{pv, key});
     cb = ws.cub_bytes;
-    KIMG_HIP(hipcub::DeviceScan::ExclusiveSum(ws.cub, cb, ws.head, ws.opos, (int) n, stream));
-    pp_headidx_kernel<<<blocks, 256, 0, stream>>>(n, ws.head, ws.opos, ws.hidx);
-    pp_merge_kernel<P><<<blocks, 256, 0, stream>>>(
-        n, ws.valid, ws.pos, ws.cidx, ws.head, ws.opos, ws.hidx, key, w, vis, single,
+    KIMG_HIP(hipcub::DeviceScan::InclusiveSum(ws.cub, cb, head_flag, ipos, (int) n, stream));
+    if (!single)
+        pp_sort_init_kernel<<<blocks, 256, 0, stream>>>(n, ws.skey_in, ws.sval_in, w_slices);
+    pp_merge_stream_kernel<P><<<blocks, 256, 0, stream>>>(
+        n, pv, ipos, key, w, vis, single,
         single ? out_uv : ws.m_uv, single ? out_wplane : ws.m_wplane, single ? out_w : ws.m_w,
         single ? out_vis : ws.m_vis, ws.skey_in, counts);
     if (!single) {
@@ -482,8 +478,8 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
                                                     stream));
         pp_slice_counts_kernel<<<kimg_divup(w_slices, 64), 64, 0, stream>>>(n, ws.skey_out, w_slices,
                                                                            counts);
-        pp_gather_kernel<P><<<blocks, 256, 0, stream>>>(
-            n, ws.head, ws.opos, ws.sval_out, ws.m_uv, ws.m_wplane, ws.m_w, ws.m_vis,
+        pp_gather_stream_kernel<P><<<blocks, 256, 0, stream>>>(
+            n, ipos, ws.sval_out, ws.m_uv, ws.m_wplane, ws.m_w, ws.m_vis,
             out_uv, out_wplane, out_w, out_vis);
     }
     return kimg_launch_status();
