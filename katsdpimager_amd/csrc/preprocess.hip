@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256) void pp_real_to_complex_kernel(
 //   scan 2 (inclusive sum): ipos[i] = number of run heads at or before i, a head being a valid
 //           record whose key differs from the previous valid record's (:354), input computed on the
 //           fly from pv and the keys;
-//   merge:  the thread of a head sums its run in arrival order (skipping flagged records) and
-//           writes output record ipos[i] - 1.
-// Five launches per buffer instead of thirteen (each scan is two rocPRIM kernels).
+//   head index: hidx[o] = input index of the head of run o;
+//   merge:  one thread per output run sums it in arrival order (skipping flagged records).
+// Seven launches per buffer instead of thirteen (each scan is a rocPRIM look-back scan with its
+// small state-initialisation kernel), no compaction pass and no index indirection in the merge.
 struct pp_valid_index {
     const float *w;
     int P;
@@ -276,25 +277,40 @@ struct pp_head_flag {
     }
 };
 
+// hidx[o] = input index of the head of output run o (one thread per input record)
+__global__ __launch_bounds__(256) void pp_headidx_stream_kernel(
+    int64_t n, const int *__restrict__ pv, const int *__restrict__ ipos, int *__restrict__ hidx)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int here = ipos[i];
+    if (pv[i] == i && here != (i > 0 ? ipos[i - 1] : 0))
+        hidx[here - 1] = (int) i;
+}
+
+// One thread per OUTPUT record (dense waves): it walks the input stream from its head to the next
+// run's head, adding the unflagged records in arrival order (:356-360, bit-identical to the host
+// loop), and writes the merged record.  With one w-slice the record goes straight to its final place.
 template <int P>
 __global__ __launch_bounds__(256) void pp_merge_stream_kernel(
-    int64_t n, const int *__restrict__ pv, const int *__restrict__ ipos,
+    int64_t n, const int *__restrict__ ipos, const int *__restrict__ hidx,
     const short *__restrict__ key, const float *__restrict__ w, const float2 *__restrict__ vis,
     int single_slice,
     short *__restrict__ m_uv, short *__restrict__ m_wplane, float *__restrict__ m_w,
     float2 *__restrict__ m_vis, unsigned short *__restrict__ skey,
     unsigned long long *__restrict__ counts)
 {
-    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    const int64_t o = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n)
         return;
     const int m = ipos[n - 1];
-    if (single_slice && i == n - 1)
+    if (single_slice && o == 0)
         counts[0] = (unsigned long long) m;
-    const int here = ipos[i];
-    if (pv[i] != i || here == (i > 0 ? ipos[i - 1] : 0))
-        return;                                 // flagged, or a later member of somebody's run
-    const int64_t o = here - 1;
+    if (o >= m)
+        return;
+    const int64_t i = hidx[o];
+    const int64_t i_end = (o + 1 < m) ? hidx[o + 1] : n;
     const int *kp = reinterpret_cast<const int *>(key + 6 * i);
     const int k01 = kp[0], k23 = kp[1], k45 = kp[2];
     float aw[P];
@@ -305,29 +321,22 @@ __global__ __launch_bounds__(256) void pp_merge_stream_kernel(
         av[p] = vis[i * P + p];
     }
     // Long runs (slowly moving short baselines) are latency chains: fetch UNROLL records ahead,
-    // then add the valid ones of this run in arrival order (bit-identical to the host loop).
+    // then add them in arrival order; flagged records (weight 0) inside the run are skipped.
     constexpr int UNROLL = 8;
     int64_t j = i + 1;
-    bool more = true;
-    while (more && j < n) {
-        int run[UNROLL];
+    for (; j + UNROLL <= i_end; j += UNROLL) {
         float2 tv[UNROLL][P];
         float tw[UNROLL][P];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const int64_t f = j + u < n ? j + u : n - 1;
-            run[u] = j + u < n ? ipos[f] : here + 1;
+        for (int u = 0; u < UNROLL; u++)
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                tv[u][p] = vis[f * P + p];
-                tw[u][p] = w[f * P + p];
+                tv[u][p] = vis[(j + u) * P + p];
+                tw[u][p] = w[(j + u) * P + p];
             }
-        }
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            if (run[u] != here)
-                more = false;                   // the next run has begun
-            if (more && tw[u][0] != 0.0f) {     // (flagged records inside the run are skipped)
+        for (int u = 0; u < UNROLL; u++)
+            if (tw[u][0] != 0.0f) {
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     av[p].x += tv[u][p].x;
@@ -335,8 +344,17 @@ __global__ __launch_bounds__(256) void pp_merge_stream_kernel(
                     aw[p] += tw[u][p];
                 }
             }
+    }
+    for (; j < i_end; j++) {
+        if (w[j * P] == 0.0f)
+            continue;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const float2 t = vis[j * P + p];
+            av[p].x += t.x;
+            av[p].y += t.y;
+            aw[p] += w[j * P + p];
         }
-        j += UNROLL;
     }
     int *uv32 = reinterpret_cast<int *>(m_uv + 4 * o);
     uv32[0] = k01;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(256) void pp_sort_init_kernel(
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct pp_workspace {
-    int *valid, *pos, *sval_in, *sval_out;      // valid = pv (last valid index), pos = ipos (heads so far)
+    int *valid, *pos, *hidx, *sval_in, *sval_out;   // valid = pv (last valid index), pos = ipos (heads so far)
     unsigned short *skey_in, *skey_out;
     short *m_uv, *m_wplane;
     float *m_w;
@@ -409,6 +427,7 @@ hipError_t layout_workspace(int64_t n, int P, char *base, pp_workspace &ws)
     size_t ni = (size_t) n * sizeof(int);
     ws.valid = (int *) take(ni);
     ws.pos = (int *) take(ni);
+    ws.hidx = (int *) take(ni);
     ws.sval_in = (int *) take(ni);
     ws.sval_out = (int *) take(ni);
     ws.skey_in = (unsigned short *) take((size_t) n * 2);
@@ -467,8 +486,9 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
     KIMG_HIP(hipcub::DeviceScan::InclusiveSum(ws.cub, cb, head_flag, ipos, (int) n, stream));
     if (!single)
         pp_sort_init_kernel<<<blocks, 256, 0, stream>>>(n, ws.skey_in, ws.sval_in, w_slices);
+    pp_headidx_stream_kernel<<<blocks, 256, 0, stream>>>(n, pv, ipos, ws.hidx);
     pp_merge_stream_kernel<P><<<blocks, 256, 0, stream>>>(
-        n, pv, ipos, key, w, vis, single,
+        n, ipos, ws.hidx, key, w, vis, single,
         single ? out_uv : ws.m_uv, single ? out_wplane : ws.m_wplane, single ? out_w : ws.m_w,
         single ? out_vis : ws.m_vis, ws.skey_in, counts);
     if (!single) {
