@@ -64,3 +64,22 @@ def gather_stats(values, device='cpu'):
     out = [torch.empty_like(t) for _ in range(size)]
     dist.all_gather(out, t)
     return torch.cat(out, dim=0)
+
+
+def image_assigned_channels(make_job, num_channels, workers=2, runner=None):
+    """Image this rank's share of `num_channels` channels: channel c belongs to rank c mod world_size
+    (:func:`assign_channels`); a rank with several channels keeps up to `workers` of them in flight
+    on its GPU (``frontend.process_channels``: one host thread and one HIP stream per channel).
+
+    ``make_job(channel)`` returns the keyword arguments of ``frontend.process_channel`` for one channel
+    (its own ``imager``, hence its own command queue).  Returns {channel: result} for this rank's
+    channels; no collective is involved (gather statistics with :func:`gather_stats` if needed).
+    ``runner`` replaces ``frontend.process_channels`` in tests."""
+    rank, size = world()
+    mine = assign_channels(num_channels, size, rank)
+    jobs = [make_job(c) for c in mine]
+    if runner is None:
+        from . import frontend
+        runner = frontend.process_channels
+    results = runner(jobs, workers=workers) if jobs else []
+    return dict(zip(mine, results))

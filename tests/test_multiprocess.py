@@ -43,6 +43,14 @@ def _worker(rank, world_size, port, result_dir):
         obs = synth.make_observation(256, 4096, 8, device='cpu', seed=2 + mine[0],
                                      channel_scale=parallel.channel_frequency_scale(mine[0], 5))
         checksum = float(obs.uv.to(torch.float64).abs().sum())
+        # 3b. a rank with several channels hands exactly its own to the per-GPU channel pool
+        seen = []
+
+        def runner(jobs, workers):
+            seen.append((tuple(j['channel'] for j in jobs), workers))
+            return [j['channel'] * 10 for j in jobs]
+        got = parallel.image_assigned_channels(lambda c: dict(channel=c), 5, workers=3, runner=runner)
+        assert got == {c: c * 10 for c in mine} and seen == [(tuple(mine), 3)]
         # 4. timing reduction and statistics gather
         slowest = parallel.max_over_ranks(1.0 + rank)
         stats = parallel.gather_stats([float(rank), checksum, float(len(mine))])
