@@ -364,6 +364,10 @@ def main():
     if rank == 0 and not args.no_major_loop and not args.no_secondary:
         del slice_ops, chunk_ops, chunks
         result['major_cycle_loop'] = major_cycle_loop(args, ctx, q, obs, extras=args.extras)
+        if args.variant != 'generic' and K <= 64:
+            # the same loop with the opt-in fp16 hi/lo form in the gridder and the degridder
+            result['major_cycle_loop_split_fp16'] = major_cycle_loop(
+                args, ctx, q, obs, arith='split_fp16', add_sources=False)
     barrier()
     if rank == 0:
         print(json.dumps(result))
@@ -613,7 +617,7 @@ def geometry_sweep(args, ctx, q, dev):
     return out
 
 
-def major_cycle_loop(args, ctx, q, obs, extras=False):
+def major_cycle_loop(args, ctx, q, obs, extras=False, arith='fp32', add_sources=True):
     """BASELINE config 5: the per-channel loop of frontend.process_channel (frontend.py:465-585)
     on the Imaging facade with the channel resident in HBM and one launch per W-slice: robust
     weights -> PSF -> 2 major cycles of { grid -> FFT -> noise estimate -> CLEAN minor cycles ->
@@ -626,13 +630,15 @@ def major_cycle_loop(args, ctx, q, obs, extras=False):
     ipd, gpd, apd = synth.make_parameters(obs, P, args.kernel_width, degrid=True)
     cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
     wparm = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
-    template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
+    tuning = {'gridder': {'arith': arith}, 'degridder': {'arith': arith}}
+    template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp, tuning)
     n = obs.n_vis
     im = template.instantiate(q, ipd, gpd, n, 0, 2)
     im.ensure_all_bound()
     # a sky with something to CLEAN: 200 point sources + noise (the gridder measurements above
     # used uniform random visibilities, as the reference's own tests do)
-    synth.add_point_sources(obs, 200, seed=4, noise=0.01)
+    if add_sources:
+        synth.add_point_sources(obs, 200, seed=4, noise=0.01)
     vis = obs.vis
     chunk = _pp.DeviceChunk(
         n, accel.DeviceArray(ctx, (n, 4), np.int16, tensor=obs.uv),
@@ -698,7 +704,7 @@ def major_cycle_loop(args, ctx, q, obs, extras=False):
     out['clean_cycles_per_s'] = round((minor - 2) / times['clean'], 1)
     out['psf_patch'] = list(patch)
     out['visibilities'] = n
-    out['arith'] = 'fp32'
+    out['arith'] = arith
     del im
     if extras:
         out['extras'] = major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm)

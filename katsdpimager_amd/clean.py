@@ -448,7 +448,10 @@ class Clean(accel.OperationSequence):
             tile_max.shape[1], tile_max.shape[0], max_cycles, self.template.form,
             self._state.ptr, self._log.ptr, self.command_queue.handle)
         check(rc, 'kimg_clean_cycles')
-        state = self._state.get(self.command_queue)
+        # (only the head of the state buffer: it also holds the persistent form's per-workgroup
+        # replicas, tens of megabytes)
+        state = np.empty((4,), np.int32)
+        self._state.get_region(self.command_queue, state, np.s_[:4], np.s_[:])
         if int(state[1]) == 2:
             check(-10004, 'kimg_clean_cycles')       # KIMG_ETIMEOUT: the persistent loop gave up
         count = int(state[0])

@@ -22,5 +22,5 @@ for form in ('persistent', 'one_launch'):
         fn.buffer('dirty').set(q, dirty); fn.buffer('model').zero(q); fn.reset(); q.finish()
         t0 = time.perf_counter(); n = len(fn.run_cycles((P,) + patch, 0.0, 1000)); q.finish()
         dt = time.perf_counter() - t0
-    st = fn._state.get(q)
+    st = fn._state.get(q)[:16]
     print(form, n, 'cycles', round(dt / n * 1e6, 2), 'us/cycle', 'stamps (100 MHz ticks per cycle):', st[4:12].tolist())
