@@ -52,11 +52,13 @@ extern "C" {
 #define KIMG_VARIANT_AUTO 0     /* MFMA window kernel when the parameters allow it */
 #define KIMG_VARIANT_GENERIC 1  /* one wave per visibility, any kernel width */
 #define KIMG_VARIANT_MFMA 2     /* MFMA window kernel or KIMG_EUNSUPPORTED */
-#define KIMG_VARIANT_BINNED 3   /* kimg_grid only: sort the visibilities by grid tile on the device
+#define KIMG_VARIANT_BINNED 3   /* sort the visibilities by grid tile on the device
                                  * (bins of window-slack cells, stable radix sort, gather), then the
                                  * MFMA window kernel over the sorted copies -- for streams without
                                  * locality (time order, shuffled); needs the scratch of
-                                 * kimg_grid_binned_workspace_bytes; KIMG_EUNSUPPORTED where MFMA is */
+                                 * kimg_grid_binned_workspace_bytes / kimg_degrid_binned_workspace_bytes
+                                 * (the degridder also sorts the weights and scatters its results
+                                 * back into the caller's order); KIMG_EUNSUPPORTED where MFMA is */
 
 /* Form of the device-resident CLEAN loop (argument `form` of kimg_clean_cycles) */
 #define KIMG_CLEAN_FORM_AUTO 0      /* one launch per cycle when the patch's lattice blocks fit the CUs */
@@ -145,6 +147,9 @@ int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stri
  * copy of it is built there on every call, as for kimg_grid). */
 size_t kimg_degrid_workspace_bytes(int num_polarizations, int w_planes, int oversample,
                                    int kernel_width);
+/* Scratch of kimg_degrid with KIMG_VARIANT_BINNED (includes the above). */
+size_t kimg_degrid_binned_workspace_bytes(int64_t max_vis, int num_polarizations, int w_planes,
+                                          int oversample, int kernel_width);
 
 /* ---- direct prediction: predict.py:386-416 Predict._run + predict.mako:10-87
  * vis[r][p] -= weights[r][p] * sum_s flux[s][p] * exp(-2 pi i (l u + m v + (n-1) w)),

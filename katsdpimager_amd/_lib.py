@@ -30,6 +30,7 @@ PROTOTYPES = {
     'kimg_grid': (c_int, [P, L, L, I, I, P, L, L, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
     'kimg_degrid': (c_int, [P, L, L, I, I, P, P, P, P, L, P, I, I, I, P, c_size_t, I, I, P]),
     'kimg_degrid_workspace_bytes': (c_size_t, [I, I, I, I]),
+    'kimg_degrid_binned_workspace_bytes': (c_size_t, [L, I, I, I, I]),
     'kimg_predict': (c_int, [P, P, P, P, P, P, L, I, I, I, F, F, F, P]),
     'kimg_grid_weights': (c_int, [P, L, L, I, I, I, P, P, L, P]),
     'kimg_mean_weight': (c_int, [P, P, L, I, I, P]),

@@ -24,6 +24,11 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                      const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
                      int w_planes, int oversample, int kernel_width, void *workspace,
                      size_t workspace_bytes, int arith, hipStream_t stream);
+int kimg_degrid_binned(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
+                       int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
+                       const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
+                       int w_planes, int oversample, int kernel_width, void *workspace,
+                       size_t workspace_bytes, int arith, hipStream_t stream);
 size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
 bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 
@@ -333,7 +338,7 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
     KIMG_CHECK_ARG(grid && uv && w_plane && weights && vis && convolve_kernel);
     KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
     KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
-                   || variant == KIMG_VARIANT_MFMA);
+                   || variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
                              kernel_width);
     if (rc)
@@ -343,8 +348,13 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
     hipStream_t s = (hipStream_t) stream;
     const bool mfma_ok = kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample,
                                                     kernel_width);
-    if (variant == KIMG_VARIANT_MFMA && !mfma_ok)
+    if ((variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED) && !mfma_ok)
         return KIMG_EUNSUPPORTED;
+    if (variant == KIMG_VARIANT_BINNED)
+        return kimg_degrid_binned(grid, grid_row_stride, grid_pol_stride, grid_size,
+                                  num_polarizations, uv, w_plane, weights, vis, num_vis,
+                                  convolve_kernel, w_planes, oversample, kernel_width, workspace,
+                                  workspace_bytes, arith, s);
     if (variant != KIMG_VARIANT_GENERIC && mfma_ok)
         return kimg_degrid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size,
                                 num_polarizations, uv, w_plane, weights, vis, num_vis,

@@ -25,6 +25,13 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                    void *workspace, size_t workspace_bytes, int arith, hipStream_t stream);
 bool kimg_grid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
+int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
+                     int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
+                     const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
+                     int w_planes, int oversample, int kernel_width, void *workspace,
+                     size_t workspace_bytes, int arith, hipStream_t stream);
+size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width);
+bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_width);
 
 namespace {
 
@@ -83,6 +90,42 @@ __global__ __launch_bounds__(256) void gather_kernel(
         vis_out[i * P + p] = vis[(int64_t) src * P + p];
 }
 
+// the degridder's inputs in tile order (it also needs the statistical weights) ...
+template <int P>
+__global__ __launch_bounds__(256) void gather_degrid_kernel(
+    const unsigned *__restrict__ index, int64_t n, const int2 *__restrict__ uv,
+    const int16_t *__restrict__ w_plane, const float *__restrict__ weights,
+    const float2 *__restrict__ vis, int2 *__restrict__ uv_out, int16_t *__restrict__ wp_out,
+    float *__restrict__ w_out, float2 *__restrict__ vis_out)
+{
+    const int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int64_t src = index[i];
+    uv_out[i] = uv[src];
+    wp_out[i] = w_plane[src];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        w_out[i * P + p] = weights[src * P + p];
+        vis_out[i * P + p] = vis[src * P + p];
+    }
+}
+
+// ... and its results back in the caller's order
+template <int P>
+__global__ __launch_bounds__(256) void scatter_vis_kernel(
+    const unsigned *__restrict__ index, int64_t n, const float2 *__restrict__ vis_sorted,
+    float2 *__restrict__ vis)
+{
+    const int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int64_t dst = index[i];
+#pragma unroll
+    for (int p = 0; p < P; p++)
+        vis[dst * P + p] = vis_sorted[i * P + p];
+}
+
 __global__ __launch_bounds__(256) void jump_count_kernel(
     const int2 *__restrict__ uv, int64_t n, int slack, unsigned *__restrict__ count)
 {
@@ -103,14 +146,15 @@ __global__ __launch_bounds__(256) void jump_count_kernel(
 
 struct binned_ws {
     size_t table;       // the window kernel's own scratch (padded table copy), first
-    size_t keys[2], index[2], uv, wp, vis, cub, cub_bytes, total;
+    size_t keys[2], index[2], uv, wp, vis, weights, cub, cub_bytes, total;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-hipError_t layout(int64_t n, int P, int W, int OV, int K, binned_ws &ws)
+hipError_t layout(int64_t n, int P, int W, int OV, int K, binned_ws &ws, bool degrid = false)
 {
-    size_t off = align256(kimg_grid_mfma_workspace_bytes(P, W, OV, K));
+    size_t off = align256(degrid ? kimg_degrid_mfma_workspace_bytes(P, W, OV, K)
+                                 : kimg_grid_mfma_workspace_bytes(P, W, OV, K));
     ws.table = 0;
     for (int i = 0; i < 2; i++) {
         ws.keys[i] = off;
@@ -124,6 +168,9 @@ hipError_t layout(int64_t n, int P, int W, int OV, int K, binned_ws &ws)
     off += align256((size_t) n * sizeof(int16_t));
     ws.vis = off;
     off += align256((size_t) n * P * sizeof(float2));
+    ws.weights = off;
+    if (degrid)
+        off += align256((size_t) n * P * sizeof(float));
     ws.cub_bytes = 0;
     hipcub::DoubleBuffer<unsigned> k(nullptr, nullptr), v(nullptr, nullptr);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, ws.cub_bytes, k, v, (int) n, 0, 32,
@@ -146,6 +193,87 @@ size_t kimg_grid_binned_workspace_bytes_impl(int64_t n, int P, int W, int OV, in
     return ws.total;
 }
 
+// keys of the footprint-origin bins, sorted; index.Current() = the caller's record of sorted place i
+static int sort_by_tile(const int16_t *uv, int64_t num_vis, int grid_size, int kernel_width,
+                        unsigned char *base, const binned_ws &ws,
+                        hipcub::DoubleBuffer<unsigned> &keys, hipcub::DoubleBuffer<unsigned> &index,
+                        hipStream_t stream)
+{
+    bin_geometry g;
+    g.half = grid_size / 2;
+    g.bin = window_slack(kernel_width) + 1;
+    g.nbu = (grid_size + g.bin - 1) / g.bin;
+    const int nbv = g.nbu;
+    g.last_key = (unsigned) g.nbu * (unsigned) nbv;
+    int bits = 1;
+    while (bits < 32 && (g.last_key >> bits) != 0)
+        bits++;
+    bin_key_kernel<<<kimg_divup(num_vis, 256), 256, 0, stream>>>(
+        reinterpret_cast<const int2 *>(uv), num_vis, g, grid_size, keys.Current(), index.Current());
+    size_t cub_bytes = ws.cub_bytes;
+    KIMG_HIP(hipcub::DeviceRadixSort::SortPairs(base + ws.cub, cub_bytes, keys, index, (int) num_vis,
+                                                0, bits, stream));
+    return kimg_launch_status();
+}
+
+int kimg_degrid_binned(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
+                       int grid_size, int P, const int16_t *uv, const int16_t *w_plane,
+                       const float *weights, void *vis, int64_t num_vis, const void *convolve_kernel,
+                       int w_planes, int oversample, int kernel_width, void *workspace,
+                       size_t workspace_bytes, int arith, hipStream_t stream)
+{
+    if (num_vis >= ((int64_t) 1 << 31))
+        return KIMG_EUNSUPPORTED;
+    binned_ws ws;
+    hipError_t e = layout(num_vis, P, w_planes, oversample, kernel_width, ws, true);
+    if (e != hipSuccess)
+        return -(int) e;
+    if (workspace == nullptr || workspace_bytes < ws.total)
+        return KIMG_EWORKSPACE;
+    unsigned char *base = static_cast<unsigned char *>(workspace);
+    hipcub::DoubleBuffer<unsigned> keys(reinterpret_cast<unsigned *>(base + ws.keys[0]),
+                                        reinterpret_cast<unsigned *>(base + ws.keys[1]));
+    hipcub::DoubleBuffer<unsigned> index(reinterpret_cast<unsigned *>(base + ws.index[0]),
+                                         reinterpret_cast<unsigned *>(base + ws.index[1]));
+    int rc = sort_by_tile(uv, num_vis, grid_size, kernel_width, base, ws, keys, index, stream);
+    if (rc)
+        return rc;
+    const int blocks = kimg_divup(num_vis, 256);
+    int2 *uv_s = reinterpret_cast<int2 *>(base + ws.uv);
+    int16_t *wp_s = reinterpret_cast<int16_t *>(base + ws.wp);
+    float *w_s = reinterpret_cast<float *>(base + ws.weights);
+    float2 *vis_s = reinterpret_cast<float2 *>(base + ws.vis);
+#define GATHER(PP) gather_degrid_kernel<PP><<<blocks, 256, 0, stream>>>(index.Current(), num_vis, \
+        reinterpret_cast<const int2 *>(uv), w_plane, weights, static_cast<const float2 *>(vis), uv_s, wp_s, \
+        w_s, vis_s)
+    switch (P) {
+    case 1: GATHER(1); break;
+    case 2: GATHER(2); break;
+    case 3: GATHER(3); break;
+    default: GATHER(4); break;
+    }
+#undef GATHER
+    rc = kimg_launch_status();
+    if (rc)
+        return rc;
+    rc = kimg_degrid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size, P,
+                          reinterpret_cast<const int16_t *>(uv_s), wp_s, w_s, vis_s, num_vis,
+                          convolve_kernel, w_planes, oversample, kernel_width, base + ws.table,
+                          ws.keys[0], arith, stream);
+    if (rc)
+        return rc;
+#define SCATTER(PP) scatter_vis_kernel<PP><<<blocks, 256, 0, stream>>>(index.Current(), num_vis, vis_s, \
+        static_cast<float2 *>(vis))
+    switch (P) {
+    case 1: SCATTER(1); break;
+    case 2: SCATTER(2); break;
+    case 3: SCATTER(3); break;
+    default: SCATTER(4); break;
+    }
+#undef SCATTER
+    return kimg_launch_status();
+}
+
 int kimg_grid_binned(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride, int grid_size,
                      int P, const float *weights_grid, int64_t wg_row_stride, int64_t wg_pol_stride,
                      const int16_t *uv, const int16_t *w_plane, const void *vis, int64_t num_vis,
@@ -161,25 +289,14 @@ int kimg_grid_binned(void *grid, int64_t grid_row_stride, int64_t grid_pol_strid
     if (workspace == nullptr || workspace_bytes < ws.total)
         return KIMG_EWORKSPACE;
     unsigned char *base = static_cast<unsigned char *>(workspace);
-    bin_geometry g;
-    g.half = grid_size / 2;
-    g.bin = window_slack(kernel_width) + 1;
-    g.nbu = (grid_size + g.bin - 1) / g.bin;
-    const int nbv = g.nbu;
-    g.last_key = (unsigned) g.nbu * (unsigned) nbv;
-    int bits = 1;
-    while (bits < 32 && (g.last_key >> bits) != 0)
-        bits++;
     hipcub::DoubleBuffer<unsigned> keys(reinterpret_cast<unsigned *>(base + ws.keys[0]),
                                         reinterpret_cast<unsigned *>(base + ws.keys[1]));
     hipcub::DoubleBuffer<unsigned> index(reinterpret_cast<unsigned *>(base + ws.index[0]),
                                          reinterpret_cast<unsigned *>(base + ws.index[1]));
+    int rc = sort_by_tile(uv, num_vis, grid_size, kernel_width, base, ws, keys, index, stream);
+    if (rc)
+        return rc;
     const int blocks = kimg_divup(num_vis, 256);
-    bin_key_kernel<<<blocks, 256, 0, stream>>>(reinterpret_cast<const int2 *>(uv), num_vis, g,
-                                               grid_size, keys.Current(), index.Current());
-    size_t cub_bytes = ws.cub_bytes;
-    KIMG_HIP(hipcub::DeviceRadixSort::SortPairs(base + ws.cub, cub_bytes, keys, index, (int) num_vis,
-                                                0, bits, stream));
     int2 *uv_s = reinterpret_cast<int2 *>(base + ws.uv);
     int16_t *wp_s = reinterpret_cast<int16_t *>(base + ws.wp);
     float2 *vis_s = reinterpret_cast<float2 *>(base + ws.vis);
@@ -192,7 +309,7 @@ int kimg_grid_binned(void *grid, int64_t grid_row_stride, int64_t grid_pol_strid
     default: GATHER(4); break;
     }
 #undef GATHER
-    int rc = kimg_launch_status();
+    rc = kimg_launch_status();
     if (rc)
         return rc;
     return kimg_grid_mfma(grid, grid_row_stride, grid_pol_stride, grid_size, P, weights_grid,
@@ -206,6 +323,18 @@ extern "C" size_t kimg_grid_binned_workspace_bytes(int64_t max_vis, int num_pola
 {
     return kimg_grid_binned_workspace_bytes_impl(max_vis, num_polarizations, w_planes, oversample,
                                                  kernel_width);
+}
+
+extern "C" size_t kimg_degrid_binned_workspace_bytes(int64_t max_vis, int num_polarizations,
+                                                    int w_planes, int oversample, int kernel_width)
+{
+    if (max_vis <= 0 || max_vis >= ((int64_t) 1 << 31)
+        || !kimg_degrid_mfma_supported(num_polarizations, w_planes, oversample, kernel_width))
+        return 0;
+    binned_ws ws;
+    if (layout(max_vis, num_polarizations, w_planes, oversample, kernel_width, ws, true) != hipSuccess)
+        return 0;
+    return ws.total;
 }
 
 extern "C" int kimg_grid_jumps(const int16_t *uv, int64_t num_vis, int kernel_width,

@@ -320,28 +320,9 @@ class GridDegrid(VisOperation):
         table = self.convolve_kernel.padded_data
         return (table.ptr, table.shape[0], table.shape[1], table.shape[2])
 
-
-class Gridder(GridDegrid):
-    """Instantiation of :class:`GridderTemplate` (grid.py:776-867).
-
-    Extra slot **weights_grid** float32 [pols][G][G]: density weights looked up per
-    visibility.  ``__call__`` adds ``num_vis`` visibilities to **grid**.
-    """
-
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self.slots['weights_grid'] = accel.IOSlot(self.slots['grid'].shape, np.float32)
-        num_pols = self.slots['grid'].shape[0]
-        table = self.convolve_kernel.padded_data
-        nbytes = lib().kimg_grid_workspace_bytes(self.max_vis, num_pols, table.shape[0],
-                                                 table.shape[1], table.shape[2])
-        self._workspace = None
-        self._workspace_bytes = nbytes
-        if nbytes:
-            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
-                                                queue=self.command_queue)
-        self._binned_bytes = lib().kimg_grid_binned_workspace_bytes(
-            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2])
+    # ---- stream order: window kernel as is, or tile-binned first (see GridderTemplate) ----------
+    def _init_locality(self, binned_bytes):
+        self._binned_bytes = binned_bytes
         self._jumps = None
         #: What the caller knows about the bound visibilities' order, for the `auto` variant: True =
         #: consecutive records stay close (the window kernel as is), False = no locality (bin first),
@@ -349,6 +330,19 @@ class Gridder(GridDegrid):
         self.locality_hint = None
         #: variant the last call took ('mfma', 'binned' or 'generic'), for tests and reports
         self.last_variant = None
+
+    def _binned_workspace(self):
+        """The scratch of the binned variant, allocated on first use."""
+        if not self._binned_bytes:
+            raise ValueError('the binned variant needs the MFMA window kernel (kernel width <= 64)')
+        if self._workspace_bytes < self._binned_bytes:
+            self._workspace = accel.DeviceArray(self.command_queue.context, (self._binned_bytes,),
+                                                np.uint8, queue=self.command_queue)
+            self._workspace_bytes = self._binned_bytes
+
+    def _note_variant(self, variant):
+        self.last_variant = {1: 'generic', 3: 'binned'}.get(variant, 'mfma' if self._binned_bytes
+                                                             else 'generic')
 
     def jump_fraction(self):
         """Fraction of the bound visibilities that would force a whole-window flush in the window
@@ -379,19 +373,38 @@ class Gridder(GridDegrid):
             return variant
         return GRID_VARIANTS['binned' if self.jump_fraction() > AUTO_JUMP_FRACTION else 'mfma']
 
+
+
+class Gridder(GridDegrid):
+    """Instantiation of :class:`GridderTemplate` (grid.py:776-867).
+
+    Extra slot **weights_grid** float32 [pols][G][G]: density weights looked up per
+    visibility.  ``__call__`` adds ``num_vis`` visibilities to **grid**.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.slots['weights_grid'] = accel.IOSlot(self.slots['grid'].shape, np.float32)
+        num_pols = self.slots['grid'].shape[0]
+        table = self.convolve_kernel.padded_data
+        nbytes = lib().kimg_grid_workspace_bytes(self.max_vis, num_pols, table.shape[0],
+                                                 table.shape[1], table.shape[2])
+        self._workspace = None
+        self._workspace_bytes = nbytes
+        if nbytes:
+            self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
+                                                queue=self.command_queue)
+        self._init_locality(lib().kimg_grid_binned_workspace_bytes(
+            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2]))
+
     def _run(self):
         grid = self.buffer('grid')
         wg = self.buffer('weights_grid')
         P, G = grid.shape[0], grid.shape[1]
         table, W, OV, K = self._kernel_args()
         variant = self._choose_variant()
-        if variant == GRID_VARIANTS['binned'] and self._workspace_bytes < self._binned_bytes:
-            if not self._binned_bytes:
-                raise ValueError('the binned variant needs the MFMA window kernel (kernel width <= 64)')
-            # allocated on first use: 34 + 8 P bytes per visibility of max_vis
-            self._workspace = accel.DeviceArray(self.command_queue.context, (self._binned_bytes,),
-                                                np.uint8, queue=self.command_queue)
-            self._workspace_bytes = self._binned_bytes
+        if variant == GRID_VARIANTS['binned']:
+            self._binned_workspace()        # 34 + 8 P bytes per visibility of max_vis
         rc = lib().kimg_grid(
             grid.ptr, G, G * G, G, P,
             wg.ptr, G, G * G,
@@ -401,12 +414,12 @@ class Gridder(GridDegrid):
             self._workspace_bytes, variant, self.template.arith,
             self.command_queue.handle)
         check(rc, 'kimg_grid')
-        self.last_variant = {1: 'generic', 3: 'binned'}.get(variant, 'mfma' if self._binned_bytes
-                                                             else 'generic')
+        self._note_variant(variant)
 
 
 class DegridderTemplate:
-    """grid.py:870-970.  ``tuning`` as for :class:`GridderTemplate`."""
+    """grid.py:870-970.  ``tuning`` as for :class:`GridderTemplate` (the binned variant also sorts
+    the statistical weights and scatters the residual visibilities back into the caller's order)."""
 
     def __init__(self, context, fixed_image_parameters, fixed_grid_parameters, tuning=None):
         types.require_float32(fixed_image_parameters.real_dtype, 'DegridderTemplate')
@@ -441,15 +454,21 @@ class Degridder(GridDegrid):
         if nbytes:
             self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
                                                 queue=self.command_queue)
+        self._init_locality(lib().kimg_degrid_binned_workspace_bytes(
+            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2]))
 
     def _run(self):
         grid = self.buffer('grid')
         P, G = grid.shape[0], grid.shape[1]
         table, W, OV, K = self._kernel_args()
+        variant = self._choose_variant()
+        if variant == GRID_VARIANTS['binned']:
+            self._binned_workspace()        # 38 + 12 P bytes per visibility of max_vis
         rc = lib().kimg_degrid(
             grid.ptr, G, G * G, G, P,
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('weights').ptr,
             self.buffer('vis').ptr, self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None, self._workspace_bytes,
-            self.template.variant, self.template.arith, self.command_queue.handle)
+            variant, self.template.arith, self.command_queue.handle)
         check(rc, 'kimg_degrid')
+        self._note_variant(variant)

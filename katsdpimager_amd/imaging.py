@@ -319,7 +319,10 @@ class Imaging(accel.OperationSequence):
         self._ready()
         if name == 'uv':
             # new coordinates from the host: nothing is known about their order
-            (self._side.gridder if self._use_side() else self._gridder).locality_hint = None
+            side_now = self._use_side()
+            (self._side.gridder if side_now else self._gridder).locality_hint = None
+            if self.template.fixed_grid_parameters.degrid:
+                (self._side.predict if side_now else self._predict).locality_hint = None
         if name in ('uv', 'w_plane', 'vis', 'weights') and self._use_side():
             side = self._side
             if side.buffer(name) is not side.own[name]:
@@ -391,6 +394,8 @@ class Imaging(accel.OperationSequence):
         self.num_vis = num_vis
         self.bind(uv=uv, w_plane=w_plane, vis=vis)
         self._gridder.locality_hint = None
+        if self.template.fixed_grid_parameters.degrid:
+            self._predict.locality_hint = None
         if weights is not None:
             self.bind(weights=weights)
 
@@ -421,6 +426,8 @@ class Imaging(accel.OperationSequence):
             side.bind_chunk(uv=chunk.uv, w_plane=chunk.w_plane, weights=chunk.weights,
                             vis=side.own['vis'])
             side.gridder.locality_hint = getattr(chunk, 'locality', None)
+            if self.template.fixed_grid_parameters.degrid:
+                side.predict.locality_hint = getattr(chunk, 'locality', None)
             if field == 'vis':
                 chunk.vis.copy_region(side.queue, side.own['vis'], np.s_[:n], np.s_[:n])
             else:
@@ -435,6 +442,8 @@ class Imaging(accel.OperationSequence):
         self.num_vis = n
         self.bind(uv=chunk.uv, w_plane=chunk.w_plane, weights=chunk.weights)
         self._gridder.locality_hint = getattr(chunk, 'locality', None)
+        if self.template.fixed_grid_parameters.degrid:
+            self._predict.locality_hint = getattr(chunk, 'locality', None)
         own_vis = self.buffer('vis')
         if field == 'vis':
             chunk.vis.copy_region(self.command_queue, own_vis, np.s_[:n], np.s_[:n])

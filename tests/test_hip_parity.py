@@ -1741,3 +1741,59 @@ def test_grid_image_vs_fp64_truth(golden, name):
         assert err_hip <= tol and err_ref <= tol
         if w == 0.0:
             assert err_hip <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('arith', ARITHS)
+@pytest.mark.parametrize('K,W,P', [(28, 32, 1), (8, 8, 2), (60, 16, 1), (45, 160, 3)])
+def test_degridder_binned_variant(K, W, P, arith):
+    """The degridder's KIMG_VARIANT_BINNED (device sort by grid tile, gather of coordinates /
+    weights / visibilities, window degridder, scatter back into the caller's order) on a stream
+    without locality, against the oracle and the direct window kernel; `auto` takes it for such a
+    stream and leaves a track alone."""
+    from katsdpimager_amd import grid
+    ctx, q = context_queue()
+    c = gi.make_config(512, 0.0001, 0.01, P, K, W, grid_cover=300, n_vis=70000)
+    t = gi.grid_track(c)
+    ip, gp, ap = make_params(c)
+    rs = gi.RandomState(K + W + 5)
+    n = c['n_vis']
+    order = np.random.RandomState(9).permutation(n)
+    uv4 = np.concatenate((t['uv'], t['sub_uv']), axis=1)
+    weights = rs.uniform(0.5, 2.0, (n, P)).astype(np.float32)
+    vis0 = rs.complex_uniform(-1, 1, size=(n, P)).astype(np.complex64)
+
+    def run(variant, perm, count=n):
+        fn = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': variant, 'arith': arith}) \
+            .instantiate(q, ap, ip, gp, n)
+        fn.ensure_all_bound()
+        fn.buffer('grid').set(q, gdata)
+        fn.num_vis = count
+        fn.buffer('uv').set_region(q, uv4[perm][:count], np.s_[:count], np.s_[:])
+        fn.buffer('w_plane').set_region(q, t['w_plane'][perm][:count], np.s_[:count], np.s_[:])
+        fn.buffer('weights').set_region(q, weights[perm][:count], np.s_[:count], np.s_[:])
+        fn.buffer('vis').set_region(q, vis0[perm][:count], np.s_[:count], np.s_[:])
+        fn()
+        return fn.buffer('vis').get(q)[:count], fn
+
+    G = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed).instantiate(q, ap, ip, gp, 16).slots['grid'].shape[-1]
+    gdata = rs.complex_uniform(-1, 1, size=(P, G, G)).astype(np.complex64)
+    got, fb = run('binned', order)
+    assert fb.last_variant == 'binned'
+    # the oracle on a sample of the shuffled stream (all of it would take minutes in C at K = 60)
+    m = 6000
+    expected = vis0[order][:m].copy()
+    orc.degrid(fb.convolve_kernel.data, gdata, np.ascontiguousarray(uv4[order][:m, :2]),
+               np.ascontiguousarray(uv4[order][:m, 2:]), t['w_plane'][order][:m], weights[order][:m],
+               expected)
+    scale = np.abs(expected - vis0[order][:m]).max()
+    assert np.abs(got[:m] - expected).max() <= 1e-5 * scale + 2.4e-7 * np.abs(expected).max()
+    direct, fd = run('mfma', order)
+    assert np.abs(got - direct).max() <= 1e-5 * scale + 2.4e-7 * np.abs(direct).max()
+    auto, fa = run('auto', order)
+    assert fa.last_variant == 'binned' and np.array_equal(auto, got)
+    _, ft = run('auto', np.arange(n))
+    assert ft.last_variant == 'mfma'
+    # fewer visibilities than max_vis, scratch reused
+    part, _ = run('binned', order, 12345)
+    assert np.abs(part - got[:12345]).max() <= 1e-5 * scale + 2.4e-7 * np.abs(direct).max()
