@@ -69,6 +69,13 @@ extern "C" {
                                          * falls back to ONE_LAUNCH otherwise.  Measured slower than
                                          * ONE_LAUNCH (agent-scope hand-offs cost what the kernel
                                          * boundary costs): AUTO does not take it. */
+#define KIMG_CLEAN_FORM_ONE_WORKGROUP 4 /* the whole loop in ONE workgroup: tile records and the PSF
+                                         * patch in its LDS, no kernel boundary and no hand-off per
+                                         * cycle.  One polarization, at most 8 x 8 lattice blocks,
+                                         * 6 bytes of LDS per tile + the patch; falls back to AUTO's
+                                         * choice otherwise.  Measured slower than ONE_LAUNCH (7.0 vs
+                                         * 6.3 us per cycle: one CU's memory pipe): AUTO does not
+                                         * take it. */
 
 #define KIMG_CLEAN_I 0      /* clean.py:29 */
 #define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */

@@ -337,12 +337,12 @@ class _SubtractPsf(accel.Operation):
         check(rc, 'kimg_subtract_psf')
 
 
-CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2, 'persistent': 3}     # KIMG_CLEAN_FORM_*
+CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2, 'persistent': 3, 'one_workgroup': 4}     # KIMG_CLEAN_FORM_*
 
 
 class CleanTemplate:
     """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'|
-    'persistent'}``, the form of the device-resident loop of :meth:`Clean.run_cycles` (results are
+    'persistent'|'one_workgroup'}``, the form of the device-resident loop of :meth:`Clean.run_cycles` (results are
     identical; ``auto`` takes the fastest one the PSF patch allows)."""
     def __init__(self, context, clean_parameters, dtype, num_polarizations, tuning=None):
         types.require_float32(dtype, 'CleanTemplate')

@@ -1122,6 +1122,452 @@ __global__ void persist_status_kernel(fused_scratch *scratch, const persist_head
         scratch->st[0].done = 2;
 }
 
+// ---- the whole minor-cycle loop in ONE WORKGROUP ---------------------------------------------
+// For a small PSF patch a cycle moves little data (a 111 x 133 patch rewrites 59 KB and its 30
+// lattice tiles hold 123 KB) and is otherwise a chain of latencies.  The forms above pay a kernel
+// boundary (one launch per cycle) or a hand-off between workgroups (persistent form) per cycle;
+// one workgroup on one CU pays neither: everything it needs between cycles stays in its LDS, and
+// the only synchronisation is its own barrier.  What it pays instead is instruction issue: a wave
+// issues about one instruction per 5 clocks, so the ~31 K pixels of a cycle must cost few
+// instructions per wave.
+//   * LDS holds, per tile, the metric maximum (float) and a 16-bit record: the peak's index inside
+//     the tile, a flag for "no positive metric" (clean.py:950) and -- CLEAN_I -- the sign of the
+//     pixel there, so that the peak pixel is known without a load; and the PSF patch, its rows
+//     padded with zeros so that a pixel next to the patch subtracts exactly nothing;
+//   * thread (b, a) owns the tiles (ty % 32, tx % 32) = (b, a) and keeps their best two keys in
+//     registers; the global peak is one block reduction of registers; the owner of a rewritten
+//     tile gets its new best from the new record and those two, and looks at its (at most 16) LDS
+//     values again only later, while the next cycle's loads are in flight;
+//   * a wave takes whole rows of the patch's tile lattice, four pixels per lane (lane = tile
+//     column x 8 + group of four): one load, one store and one LDS read per row and lane, and
+//     everything that depends on the row (inside the image / the patch / a tile) is wave-uniform
+//     control flow.  Groups that straddle the image's edge go pixel by pixel;
+//   * all loads of a wave's rows are issued first, then one wait, then the arithmetic with its
+//     stores: loads and stores return out of order with respect to each other, so a wave that
+//     waits for a load while it has stores in flight waits for the stores, too.  The stores are
+//     only waited for (vmcnt(0) + barrier) after the NEXT peak search.
+// Selection and arithmetic are those of the other forms, bit for bit.
+//
+// MEASURED (MI355X, 4096^2, 111 x 133 patch; wall_clock64 stamps, build flag -DKIMG_CLEAN_STAMPS,
+// -DKIMG_SOLO_STAMP_TID=<thread>): 7.0 us per cycle against 6.3 for the one-launch-per-cycle form,
+// so KIMG_CLEAN_FORM_AUTO does NOT take this form; it stays selectable and tested.  Per cycle: peak
+// search 0.7 (two DPP/LDS reduction stages, the second behind the owners' update), store drain
+// 0.35, then per wave: 1.6 (first wave) to 3.1 us (ninth) until its twelve 640-byte row loads have
+// landed -- ONE CU pulls the ~150 KB of a cycle's lattice tiles out of L2 / MALL at only ~50 GB/s --
+// 1.25 for the patch rows (LDS PSF reads + 12 stores), 1.2 for the tile maxima (3 VALU
+// instructions per pixel: four waves per SIMD share one VALU, ~31 K pixels are ~2300 VALU clocks
+// per SIMD), and up to 3 us of waiting for the slowest wave (the rows of a wave are not equally
+// expensive).  Earlier layouts of the same idea: one pixel per lane with per-row predicates 16.1
+// us; units of 8 rows x 64 pixels double-buffered 9.3 (every wait for a load behind a store was a
+// wait for the store); the same with all loads first 7.8.  What would still help: loading only
+// the patch's pixels of tiles whose old maximum lies outside the patch (halves the bytes), rows
+// dealt out by cost.  Neither brings one CU below ~4.5 us: the form trades two microseconds of
+// kernel boundary for one CU's memory pipe and VALU, which is not a good trade at this patch size.
+constexpr size_t SOLO_LDS_LIMIT = 160 * 1024 - 1024;
+constexpr int SOLO_MAX_BX = 8;              // lattice columns of a patch: 8 lanes each
+constexpr int SOLO_MAX_BLOCKS = 64;         // lattice blocks of a patch
+constexpr int SOLO_AUTO_BLOCKS = 0;         // KIMG_CLEAN_FORM_AUTO takes this form up to here: never (see MEASURED)
+constexpr int SOLO_ROWS = 12;               // rows of a wave whose loads are issued together
+constexpr int SOLO_PAD = 4;                 // zeros either side of a PSF row in LDS
+constexpr unsigned SOLO_NONE = 0x4000, SOLO_SIGN = 0x8000;
+
+// tile-local key: metric, then lower index inside the tile; bit 0 carries the pixel's sign
+__device__ inline key_t solo_pixel_key(float metric, int idx, bool negative)
+{
+    return ((key_t) __float_as_uint(metric) << 32) | (unsigned) (((1023 - idx) << 1) | (negative ? 1 : 0));
+}
+
+// global key: metric, then lower (ty, tx) in row-major order (no division to get them back)
+__device__ inline key_t solo_tile_key(float value, int ty, int tx)
+{
+    return ((key_t) __float_as_uint(value) << 32) | (unsigned) ~((ty << 16) | tx);
+}
+
+struct solo_f4 { float v[4]; };             // four pixels, 4-byte aligned
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_solo_kernel(
+    float *dirty, float *model, int64_t row_stride, int width, int height,
+    const float *__restrict__ psf, int64_t psf_row_stride, int psf_w, int psf_h, int patch_w,
+    int patch_h, int border, float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
+    float loop_gain, float threshold, int limit, fused_scratch *scratch, float *log)
+{
+    constexpr bool FAST = MODE == KIMG_CLEAN_I;     // the peak pixel is +-metric
+    extern __shared__ __align__(16) unsigned char solo_smem[];
+    __shared__ key_t s_keys[16];
+    __shared__ key_t s_tkey[SOLO_MAX_BLOCKS];       // per lattice block: best pixel key of the cycle
+    const int tiles = tiles_x * tiles_y;
+    float *s_val = reinterpret_cast<float *>(solo_smem);
+    unsigned short *s_rec = reinterpret_cast<unsigned short *>(solo_smem + (size_t) tiles * 4);
+    float *s_psf = reinterpret_cast<float *>(solo_smem + (((size_t) tiles * 6 + 15) & ~(size_t) 15));
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int own_x = tid & 31, own_y = tid >> 5;
+    const int ppx = psf_w / 2 - patch_w / 2, ppy = psf_h / 2 - patch_h / 2;   // patch origin in the PSF
+    const int pstride = patch_w + 2 * SOLO_PAD;
+
+    for (int t = tid; t < tiles; t += 1024) {
+        const float v = tile_max[t];
+        const int2 pos = *reinterpret_cast<const int2 *>(tile_pos + 2 * t);
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        unsigned rec = SOLO_NONE;
+        if (v != 0.0f) {
+            rec = (unsigned) ((pos.x - (ty * TILE + border)) * TILE + (pos.y - (tx * TILE + border)));
+            if (FAST && dirty[(int64_t) pos.x * row_stride + pos.y] < 0.0f)
+                rec |= SOLO_SIGN;
+        }
+        s_val[t] = v;
+        s_rec[t] = (unsigned short) rec;
+    }
+    for (int i = tid; i < pstride * patch_h; i += 1024) {
+        const int r = i / pstride, c = i - r * pstride - SOLO_PAD;
+        s_psf[i] = (c >= 0 && c < patch_w) ? psf[(int64_t) (ppy + r) * psf_row_stride + (ppx + c)] : 0.0f;
+    }
+    if (tid < SOLO_MAX_BLOCKS)
+        s_tkey[tid] = 0;
+    __syncthreads();
+
+    // The best two of this thread's tiles (keys; 0 = none), all (up to 16) LDS reads in flight.
+    // Tiles are visited in increasing key order of equal values, so plain key comparisons do.
+    key_t b1 = 0, b2 = 0;
+    const bool few_tiles = tiles_x <= 128 && tiles_y <= 128;
+    auto consider = [&](key_t k) {
+        const key_t lo = k > b1 ? b1 : k;
+        b1 = k > b1 ? k : b1;
+        b2 = lo > b2 ? lo : b2;
+    };
+    auto rescan = [&]() {
+        b1 = b2 = 0;
+        if (few_tiles) {
+#pragma unroll 1
+            for (int h = 0; h < 4; h++) {
+                const int ty = own_y + 32 * h;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int tx = own_x + 32 * i;
+                    v[i] = s_val[(ty < tiles_y && tx < tiles_x) ? ty * tiles_x + tx : 0];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int tx = own_x + 32 * i;
+                    consider((ty < tiles_y && tx < tiles_x) ? solo_tile_key(v[i], ty, tx) : 0);
+                }
+            }
+        } else {
+            for (int ty = own_y; ty < tiles_y; ty += 32)
+                for (int tx = own_x; tx < tiles_x; tx += 32)
+                    consider(solo_tile_key(s_val[ty * tiles_x + tx], ty, tx));
+        }
+    };
+    rescan();
+    bool stale = false;             // b1 / b2 have to be read again
+
+    const int nbx = (patch_w + TILE - 1) / TILE + 1, nby = (patch_h + TILE - 1) / TILE + 1;
+    // Work split: the lattice has nby * 32 rows of nbx * 32 pixels; the waves share the rows in
+    // consecutive runs.  Lane = (lattice column) * 8 + (group of four pixels).
+    const int lattice_rows = nby * TILE;
+    const int rows_per_wave = (lattice_rows + 15) >> 4;
+    const int row_begin = __builtin_amdgcn_readfirstlane(min(wave * rows_per_wave, lattice_rows));
+    const int row_end = __builtin_amdgcn_readfirstlane(min(row_begin + rows_per_wave, lattice_rows));
+    const int jx = (tid & 63) >> 3, grp = tid & 7;
+    const unsigned row_bytes = (unsigned) row_stride * 4u;
+
+#ifdef KIMG_CLEAN_STAMPS
+    long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = wall_clock64();
+#ifndef KIMG_SOLO_STAMP_TID
+#define KIMG_SOLO_STAMP_TID 0
+#endif
+#define SSTAMP(i) do { if (tid == KIMG_SOLO_STAMP_TID) { const long long n_ = wall_clock64(); sacc[i] += n_ - st_t; st_t = n_; } } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+    int count = 0;
+    for (;;) {
+        SSTAMP(0);
+        const key_t best = block_max_key_lds(b1, s_keys);
+        SSTAMP(1);
+        const float value = __uint_as_float((unsigned) (best >> 32));
+        if (best == 0 || value < threshold || count >= limit)      // clean.py:1065-1066
+            break;
+        const unsigned tcode = ~(unsigned) best;
+        const int pty = (int) (tcode >> 16), ptx = (int) (tcode & 0xffff);
+        const unsigned rec = s_rec[pty * tiles_x + ptx];
+        int py, px;
+        if (rec & SOLO_NONE) {              // clean.py:950 best_pos = (x0, y0)
+            py = ptx * TILE + border;
+            px = pty * TILE + border;
+        } else {
+            py = pty * TILE + border + (int) ((rec & 1023) >> 5);
+            px = ptx * TILE + border + (int) (rec & 31);
+        }
+        // every pixel store of the previous cycle must have landed before this cycle's loads
+        __syncthreads();
+        SSTAMP(2);
+        const bool pos_ok = py >= 0 && py < height && px >= 0 && px < width;
+        float pix;
+        if (FAST && !(rec & SOLO_NONE))
+            pix = (rec & SOLO_SIGN) ? -value : value;
+        else
+            pix = pos_ok ? dirty[(int64_t) py * row_stride + px] : 0.0f;
+        const float scale = loop_gain * pix;                        // clean.py:1044
+        float mod = 0.0f;
+        float *mp = model + (int64_t) py * row_stride + px;
+        if (tid == 0 && pos_ok)
+            mod = *mp;
+
+        const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;    // clean.py:1024-1027
+        // floor division: the lattice extends into the border with negative indices
+        const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
+        const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
+
+        // this lane's four pixels: the same for all rows.  "wide" lanes move them as one 16-byte
+        // access (lanes with nothing to do read a clamped address and never write); lanes whose
+        // group straddles the image's edge ("part") or the edge of the tile lattice (`t_part`)
+        // are served pixel by pixel in passes of their own that a wave without any skips.
+        const int tx = bx0 + jx;
+        const int x = tx * TILE + border + 4 * grp;
+        const bool lane_on = jx < nbx;
+        const bool part = lane_on && !(x >= 0 && x + 3 < width) && x + 3 >= 0 && x < width;
+        const bool wide_patch = lane_on && x >= 0 && x + 3 < width && x + 3 >= x0 && x < x0 + patch_w;
+        const bool tx_ok = lane_on && tx >= 0 && tx < tiles_x;
+        const bool t_all = tx_ok && x + 3 < width - border;
+        const bool t_part = tx_ok && !t_all && x < width - border;
+        const unsigned xoff = (unsigned) min(max(x, 0), width - 4) * 4u;
+        const int pidx0 = SOLO_PAD + (x - x0);
+        const bool any_part = __any(part), any_t_part = __any(t_part);
+        char *base = reinterpret_cast<char *>(dirty);
+        const int lattice_y = by0 * TILE + border;
+
+        // best of this lane's pixels in the (at most two) tile rows of its chunk: pixel (CLEAN_I)
+        // or metric, and where (row in chunk * 4 + pixel)
+        auto track = [&](float d, int code, float &bs, int &bc) {
+            // first strict maximum in row-major order; only positive metrics count
+            // (clean.py:953-958): rows come in increasing order, the comparison is strict
+            if (FAST) {
+                if (fabsf(d) > fabsf(bs)) {
+                    bs = d;
+                    bc = code;
+                }
+            } else {
+                const float m = 0.0f + d * d;
+                if (m > bs) {
+                    bs = m;
+                    bc = code;
+                }
+            }
+        };
+        auto bits = [](int lo, int hi) {        // bits [lo, hi) of a SOLO_ROWS-bit mask
+            lo = min(max(lo, 0), SOLO_ROWS);
+            hi = min(max(hi, lo), SOLO_ROWS);
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        for (int rb = row_begin; rb < row_end; rb += SOLO_ROWS) {
+            const int nr = min(SOLO_ROWS, row_end - rb);
+            const int yb = lattice_y + rb;              // image row of the chunk's first row
+            // rows of the chunk (bit r = row r): inside the image; patch rows; rows that count for
+            // the tiles of the chunk's first / second lattice tile row
+            const unsigned m_img = bits(-yb, min(height - yb, nr));
+            const unsigned m_patch = m_img & bits(y0 - yb, y0 + patch_h - yb);
+            const int trow_a = rb >> 5, split = ((trow_a + 1) << 5) - rb;   // rows [split, ..) are tile row b
+            const unsigned m_tile = m_img & bits(0, height - border - yb);
+            const bool ta_ok = by0 + trow_a >= 0 && by0 + trow_a < tiles_y;
+            const bool tb_ok = by0 + trow_a + 1 >= 0 && by0 + trow_a + 1 < tiles_y;
+            const unsigned m_a = ta_ok ? m_tile & bits(0, split) : 0u;
+            const unsigned m_b = tb_ok ? m_tile & bits(split, SOLO_ROWS) : 0u;
+            float dv[SOLO_ROWS][4];
+            // ---- loads: unconditional rows (clamped), nothing but loads in between
+#pragma unroll
+            for (int r = 0; r < SOLO_ROWS; r++) {
+                const int y = min(max(yb + min(r, nr - 1), 0), height - 1);     // uniform
+                solo_f4 v;
+                __builtin_memcpy(&v, base + ((unsigned) y * row_bytes + xoff), sizeof(v));
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    dv[r][i] = v.v[i];
+            }
+            if (any_part) {
+#pragma unroll
+                for (int r = 0; r < SOLO_ROWS; r++) {
+                    const int y = min(max(yb + min(r, nr - 1), 0), height - 1);
+                    const char *row = base + (size_t) ((unsigned) y * row_bytes);
+                    if (part) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            dv[r][i] = 0.0f;
+                            if (x + i >= 0 && x + i < width)
+                                dv[r][i] = *reinterpret_cast<const float *>(row + (size_t) ((unsigned) (x + i) * 4u));
+                        }
+                    }
+                }
+            }
+            if (stale) {
+                // in the shadow of the loads: this owner's best two, with last cycle's record in
+                rescan();
+                stale = false;
+            }
+            // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping must know
+            // that no load is pending any more, or it counts the stores against them)
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
+            SSTAMP(5);
+            // ---- the patch rows: dirty -= (loop_gain * pixel) * psf, PSF rows fetched four at a time
+            if (m_patch) {
+#pragma unroll
+                for (int h = 0; h < SOLO_ROWS; h += 4) {
+                    solo_f4 pv[4];
+                    if (wide_patch || part) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            // (rows outside the patch read a clamped row; they are not used)
+                            const int pr = min(max(yb + h + r - y0, 0), patch_h - 1);
+                            __builtin_memcpy(&pv[r], s_psf + pr * pstride + min(max(pidx0, 0), pstride - 4),
+                                             sizeof(solo_f4));
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (!(m_patch & (1u << (h + r))))
+                            continue;
+                        const unsigned row_off = (unsigned) (yb + h + r) * row_bytes;
+                        char *row = base + (size_t) row_off;
+                        if (wide_patch) {
+                            solo_f4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const float t = scale * pv[r].v[i];
+                                dv[h + r][i] -= t;
+                                v.v[i] = dv[h + r][i];
+                            }
+                            __builtin_memcpy(base + (row_off + xoff), &v, sizeof(v));
+                        }
+                        if (any_part) {
+                            if (part) {
+#pragma unroll
+                                for (int i = 0; i < 4; i++)
+                                    if (x + i >= 0 && x + i < width && x + i >= x0 && x + i < x0 + patch_w) {
+                                        const float t = scale * pv[r].v[i];
+                                        dv[h + r][i] -= t;
+                                        *reinterpret_cast<float *>(row + (size_t) ((unsigned) (x + i) * 4u)) = dv[h + r][i];
+                                    }
+                            }
+                        }
+                    }
+                }
+            }
+            SSTAMP(6);
+            // ---- the tiles' maxima
+            float bs_a = 0.0f, bs_b = 0.0f;
+            int bc_a = 0, bc_b = 0;
+#pragma unroll
+            for (int r = 0; r < SOLO_ROWS; r++) {
+                if (m_a & (1u << r)) {
+                    if (t_all) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            track(dv[r][i], r * 4 + i, bs_a, bc_a);
+                    }
+                    if (any_t_part) {
+                        if (t_part) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (x + i < width - border)
+                                    track(dv[r][i], r * 4 + i, bs_a, bc_a);
+                        }
+                    }
+                }
+                if (m_b & (1u << r)) {
+                    if (t_all) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            track(dv[r][i], r * 4 + i, bs_b, bc_b);
+                    }
+                    if (any_t_part) {
+                        if (t_part) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (x + i < width - border)
+                                    track(dv[r][i], r * 4 + i, bs_b, bc_b);
+                        }
+                    }
+                }
+            }
+            // ---- the tiles' best keys of this chunk: 8 lanes per tile, then one LDS atomic
+            auto flush = [&](float bs, int bc, int trow) {
+                const float bm = FAST ? fabsf(bs) : bs;
+                const int idx = ((rb + (bc >> 2)) & 31) * TILE + 4 * grp + (bc & 3);
+                key_t k = bm > 0.0f ? solo_pixel_key(bm, idx, FAST && bs < 0.0f) : 0;
+                k = key_max(k, key_dpp<0xB1>(k));       // quad_perm [1,0,3,2]
+                k = key_max(k, key_dpp<0x4E>(k));       // quad_perm [2,3,0,1]
+                k = key_max(k, key_dpp<0x141>(k));      // row_half_mirror
+                if (grp == 0 && k != 0 && lane_on)
+                    atomicMax(&s_tkey[trow * nbx + jx], k);
+            };
+            if (m_a)
+                flush(bs_a, bc_a, trow_a);
+            if (m_b)
+                flush(bs_b, bc_b, trow_a + 1);
+        }
+        SSTAMP(3);
+        if (tid == 0) {
+            *reinterpret_cast<float4 *>(log + (int64_t) count * 4) =
+                make_float4(value, __int_as_float(py), __int_as_float(px), scale);
+            if (pos_ok)
+                *mp = mod + scale;                                  // clean.py:1047
+        }
+        count++;
+        lds_barrier();          // the chunks' keys are in LDS
+        SSTAMP(4);
+        // The owners of the rewritten tiles (a patch spans fewer than 32 tiles either way: at most
+        // one tile per owner) take the new record; their new best is the better of it and of the
+        // best of their other tiles, which is the first of (b1, b2) that is not this tile.
+        const int ojx = (own_x - bx0) & 31, ojy = (own_y - by0) & 31;
+        if (ojx < nbx && ojy < nby) {
+            const int otx = bx0 + ojx, oty = by0 + ojy;
+            if (otx >= 0 && otx < tiles_x && oty >= 0 && oty < tiles_y) {
+                const int t = oty * tiles_x + otx;
+                const key_t kt = s_tkey[ojy * nbx + ojx];
+                s_tkey[ojy * nbx + ojx] = 0;
+                float nv = 0.0f;
+                unsigned nrec = SOLO_NONE;
+                if (kt != 0) {
+                    const unsigned lo = (unsigned) kt;
+                    nv = __uint_as_float((unsigned) (kt >> 32));
+                    nrec = (1023 - ((lo >> 1) & 1023)) | ((lo & 1) ? SOLO_SIGN : 0);
+                }
+                s_val[t] = nv;
+                s_rec[t] = (unsigned short) nrec;
+                const unsigned code = ~(unsigned) ((oty << 16) | otx);
+                const key_t others = (unsigned) b1 == code ? b2 : b1;
+                b1 = key_max(others, solo_tile_key(nv, oty, otx));
+                stale = true;
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int t = tid; t < tiles; t += 1024) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int ox = tx * TILE + border, oy = ty * TILE + border;
+        const unsigned rec = s_rec[t];
+        tile_max[t] = s_val[t];
+        int2 pos;
+        if (rec & SOLO_NONE)
+            pos = make_int2(ox, oy);        // clean.py:950 (x0, y0)
+        else
+            pos = make_int2(oy + (int) ((rec & 1023) >> 5), ox + (int) (rec & 31));
+        *reinterpret_cast<int2 *>(tile_pos + 2 * t) = pos;
+    }
+    if (tid == 0)
+        *reinterpret_cast<int4 *>(&scratch->st[0]) = make_int4(count, 1, limit, __float_as_int(threshold));
+#ifdef KIMG_CLEAN_STAMPS
+    if (tid == KIMG_SOLO_STAMP_TID) {
+        for (int i = 0; i < 8; i++)
+            scratch->st[0].pad[i] = (int) (sacc[i] * 100 / max(count, 1));     // 1/100 tick (0.1 ns) per cycle
+    }
+#endif
+#undef SSTAMP
+}
+
 // Pixel values at every tile's peak position (the part of a tile record the tile scan of
 // kimg_update_tiles does not produce); once per kimg_clean_cycles call.
 __global__ __launch_bounds__(256) void tile_pix_kernel(
@@ -1542,7 +1988,8 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
     KIMG_CHECK_ARG(form == KIMG_CLEAN_FORM_AUTO || form == KIMG_CLEAN_FORM_TWO_LAUNCH
-                   || form == KIMG_CLEAN_FORM_ONE_LAUNCH || form == KIMG_CLEAN_FORM_PERSISTENT);
+                   || form == KIMG_CLEAN_FORM_ONE_LAUNCH || form == KIMG_CLEAN_FORM_PERSISTENT
+                   || form == KIMG_CLEAN_FORM_ONE_WORKGROUP);
     hipStream_t s = (hipStream_t) stream;
     // one launch per cycle when the patch touches few lattice blocks (every workgroup then
     // repeats the global peak search)
@@ -1550,6 +1997,35 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     const bool fused = bx * (by + 1) <= FUSED_MAX_BLOCKS && bx <= 32 && by <= 32
                        && kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) <= FUSED_MAX_SLOTS
                        && form != KIMG_CLEAN_FORM_TWO_LAUNCH;
+    // the whole loop in one workgroup when the patch is small and the tile records and the PSF
+    // patch fit LDS
+    const size_t solo_lds = (((size_t) tiles_x * tiles_y * 6 + 15) & ~(size_t) 15)
+                            + (size_t) (patch_width + 2 * SOLO_PAD) * patch_height * sizeof(float);
+    const bool solo_ok = num_polarizations == 1 && bx <= SOLO_MAX_BX && by <= 32
+                         && bx * by <= SOLO_MAX_BLOCKS
+                         && (uint64_t) height * (uint64_t) row_stride < (1u << 30)
+                         && solo_lds <= SOLO_LDS_LIMIT && max_cycles > 0;
+    if (solo_ok && (form == KIMG_CLEAN_FORM_ONE_WORKGROUP
+                    || (form == KIMG_CLEAN_FORM_AUTO && bx * by <= SOLO_AUTO_BLOCKS))) {
+#define SOLO(MODE) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+            KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cycle_solo_kernel<MODE>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int) SOLO_LDS_LIMIT)); \
+            attr_set = true; \
+        } \
+        cycle_solo_kernel<MODE><<<1, 1024, solo_lds, s>>>( \
+            dirty, model, row_stride, width, height, psf, psf_row_stride, psf_width, psf_height, \
+            patch_width, patch_height, border, tile_max, tile_pos, tiles_x, tiles_y, loop_gain, \
+            threshold, max_cycles, static_cast<fused_scratch *>(state), log); } while (0)
+        if (mode == KIMG_CLEAN_I)
+            SOLO(KIMG_CLEAN_I);
+        else
+            SOLO(KIMG_CLEAN_SUMSQ);
+#undef SOLO
+        return kimg_launch_status();
+    }
     KIMG_HIP(hipMemsetAsync(state, 0, sizeof(fused_scratch), s));
     init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(state), max_cycles, threshold);
     if (fused)

@@ -1280,6 +1280,10 @@ def test_device_kernel_table_arguments():
     (1200, 4, 1, 0.0, (65, 97)),         # sum of squares over 4 polarizations, no border
     (2592, 1, 0, 0.1, (31, 31)),         # 3 x 3 groups, wide border, tiny patch
     (1120, 2, 0, 0.02, (225, 193)),      # 9 x 8 = 72 lattice blocks, more than one per tile column group
+    (1024, 1, 1, 0.05, (65, 97)),        # one polarization, sum of squares (one-workgroup form: pixel loads)
+    (4096, 1, 0, 0.02, (191, 161)),      # 7 x 7 lattice blocks, 14 884 tiles: the PSF patch does not fit LDS
+    (1024, 1, 0, 0.02, (65, 225)),       # tall patch: a wave of the one-workgroup form has two chunks of rows
+    (1008, 1, 0, 0.013, (65, 97)),       # border 13: groups of four pixels straddle the edges of image and lattice
 ])
 def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
     """The one-launch-per-cycle form (every workgroup repeats the peak search, tile records in
@@ -1321,7 +1325,7 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
         return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
                 fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
     b = run('two_launch')
-    for form in ('one_launch', 'persistent'):
+    for form in ('one_launch', 'persistent', 'one_workgroup', 'auto'):
         a = run(form)
         assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 1188
         for u, w in zip(a[0], b[0]):

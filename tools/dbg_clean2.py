@@ -14,7 +14,7 @@ for _ in range(200):
 fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
 ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
 cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, mode, 0.01, 0.5, border)
-for form in ('persistent', 'one_launch'):
+for form in (sys.argv[1:] or ('one_workgroup', 'one_launch')):
     fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form}).instantiate(q, ip)
     fn.ensure_all_bound()
     fn.buffer('psf').set(q, psf)
@@ -22,5 +22,5 @@ for form in ('persistent', 'one_launch'):
         fn.buffer('dirty').set(q, dirty); fn.buffer('model').zero(q); fn.reset(); q.finish()
         t0 = time.perf_counter(); n = len(fn.run_cycles((P,) + patch, 0.0, 1000)); q.finish()
         dt = time.perf_counter() - t0
-    st = fn._state.get(q)[:16]
+    st = np.zeros(16, np.int32); fn._state.get_region(q, st, np.s_[:16], np.s_[:])
     print(form, n, 'cycles', round(dt / n * 1e6, 2), 'us/cycle', 'stamps (100 MHz ticks per cycle):', st[4:12].tolist())
