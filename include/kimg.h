@@ -238,6 +238,20 @@ int kimg_layer_to_image(float *image, int64_t image_row_stride, const void *laye
 int kimg_image_to_layer(void *layer, const float *image, int64_t image_row_stride, int size,
                         const float *kernel1d, float lm_scale, float lm_bias, float w,
                         void *stream);
+/* The same pair for a layer whose transform is only wanted for its real part, i.e. w = 0 (the
+ * phase factor of layer_to_image is then exactly 1): the reference notes at image.py:561-566 that a
+ * complex-to-real transform would do; here it does.
+ *   kimg_grid_to_half_layer: half_layer[ly][lx], lx = 0 .. G/2 (rows of G/2 + 1 complex values),
+ *       = (g(k) + conj g(-k)) / 2 of the zero-padded, corner-DC layer g that kimg_grid_to_layer
+ *       would have made: the Hermitian part of g, whose inverse transform is Re F^-1[g].
+ *   kimg_real_layer_to_image: image[pol] += layer * n / (k1d[y] k1d[x]) with fftshift, from the REAL
+ *       output of kimg_rfft_exec(direction +1); layer_row_stride in floats (G + 2 when the
+ *       transform ran in place on the half layer). */
+int kimg_grid_to_half_layer(void *half_layer, int layer_size, const void *grid,
+                            int64_t grid_row_stride, int grid_size, void *stream);
+int kimg_real_layer_to_image(float *image, int64_t image_row_stride, const float *layer,
+                             int64_t layer_row_stride, int size, const float *kernel1d,
+                             float lm_scale, float lm_bias, void *stream);
 
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
  * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */

@@ -29,6 +29,35 @@ __global__ __launch_bounds__(256) void grid_to_layer_kernel(
     layer[(int64_t) ly * G + lx] = v;
 }
 
+// The same for a transform that is only wanted for its REAL part (the W-stack phase is 1 at
+// w = 0): Re F^-1[g] = F^-1[h] with h(k) = (g(k) + conj g(-k)) / 2, and h is Hermitian, so half
+// of it -- columns 0 .. G/2 -- feeds a complex-to-real transform of half the size (the
+// "opportunity" noted at image.py:561-566 of the reference).  half[ly][lx], row length G/2 + 1.
+__global__ __launch_bounds__(256) void grid_to_half_layer_kernel(
+    float2 *__restrict__ half_layer, int G, const float2 *__restrict__ grid,
+    int64_t grid_row_stride, int Gg)
+{
+    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ly = blockIdx.y;
+    const int W = G / 2 + 1;
+    if (lx >= W)
+        return;
+    const int half = Gg / 2;
+    const int cx = lx < G - half ? lx : lx - G;
+    const int cy = ly < G - half ? ly : ly - G;
+    float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
+    if (cx >= -half && cx < half && cy >= -half && cy < half)
+        a = grid[(int64_t) (cy + half) * grid_row_stride + (cx + half)];
+    // -k modulo G: the Nyquist row and column (a grid as large as the layer has them) are their
+    // own mirrors
+    const int mlx = lx ? G - lx : 0, mly = ly ? G - ly : 0;
+    const int mx = mlx < G - half ? mlx : mlx - G;
+    const int my = mly < G - half ? mly : mly - G;
+    if (mx >= -half && mx < half && my >= -half && my < half)
+        b = grid[(int64_t) (my + half) * grid_row_stride + (mx + half)];
+    half_layer[(int64_t) ly * W + lx] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+}
+
 __global__ __launch_bounds__(256) void layer_to_grid_kernel(
     float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, const float2 *__restrict__ layer,
     int G)
@@ -78,6 +107,28 @@ __global__ __launch_bounds__(256) void layer_to_image_kernel(
     float c, s;
     expj2pi(w * (n - 1.0f), c, s);
     const float rotated = v.x * c - v.y * s;
+    const float taper = kernel1d[y] * kernel1d[x];
+    image[(int64_t) y * image_row_stride + x] += (rotated * n) / taper;
+}
+
+// layer_to_image for w = 0 from the real output of the complex-to-real transform (rows of
+// `layer_row_stride` floats): the phase factor is exactly (1, 0), so "rotated" is the real part.
+__global__ __launch_bounds__(256) void real_layer_to_image_kernel(
+    float *__restrict__ image, int64_t image_row_stride, const float *__restrict__ layer,
+    int64_t layer_row_stride, int G, const float *__restrict__ kernel1d, float lm_scale, float lm_bias)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= G)
+        return;
+    const int half = G / 2;
+    const int sx = x < half ? x + half : x - half;
+    const int sy = y < half ? y + half : y - half;
+    const float rotated = layer[(int64_t) sy * layer_row_stride + sx];
+    const float l = lm_coord(x, lm_scale, lm_bias);
+    const float m = lm_coord(y, lm_scale, lm_bias);
+    const float l2 = l * l, m2 = m * m;
+    const float n = sqrtf(1.0f - (m2 + l2));
     const float taper = kernel1d[y] * kernel1d[x];
     image[(int64_t) y * image_row_stride + x] += (rotated * n) / taper;
 }
@@ -157,6 +208,30 @@ extern "C" int kimg_grid_to_layer(void *layer, int layer_size, const void *grid,
     dim3 g(kimg_divup(layer_size, 256), layer_size);
     grid_to_layer_kernel<<<g, 256, 0, (hipStream_t) stream>>>(
         (float2 *) layer, layer_size, (const float2 *) grid, grid_row_stride, grid_size);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_grid_to_half_layer(void *half_layer, int layer_size, const void *grid,
+                                       int64_t grid_row_stride, int grid_size, void *stream)
+{
+    KIMG_CHECK_ARG(half_layer && grid && layer_size > 0 && layer_size % 2 == 0 && grid_size > 0
+                   && grid_size % 2 == 0 && grid_size <= layer_size && grid_row_stride >= grid_size);
+    const dim3 blocks(kimg_divup(layer_size / 2 + 1, 256), layer_size);
+    grid_to_half_layer_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(
+        static_cast<float2 *>(half_layer), layer_size, static_cast<const float2 *>(grid),
+        grid_row_stride, grid_size);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_real_layer_to_image(float *image, int64_t image_row_stride, const float *layer,
+                                        int64_t layer_row_stride, int size, const float *kernel1d,
+                                        float lm_scale, float lm_bias, void *stream)
+{
+    KIMG_CHECK_ARG(image && layer && kernel1d && size > 0 && size % 2 == 0
+                   && image_row_stride >= size && layer_row_stride >= size);
+    const dim3 blocks(kimg_divup(size, 256), size);
+    real_layer_to_image_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(
+        image, image_row_stride, layer, layer_row_stride, size, kernel1d, lm_scale, lm_bias);
     return kimg_launch_status();
 }
 

@@ -241,12 +241,50 @@ class FftPlan:
             pass
 
 
+class RealFftPlan:
+    """rocFFT 2-D complex-to-real plan (with its real-to-complex twin, unused here) for the w = 0
+    layers of :class:`GridToImage`; pooled like :class:`FftPlan`."""
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in shape)
+        key = ('real',) + self.shape
+        handle = _plan_pool.take(key)
+        if handle is None:
+            handle = ctypes.c_void_p()
+            check(lib().kimg_rfft_plan_create(ctypes.byref(handle), self.shape[0], self.shape[1]),
+                  'kimg_rfft_plan_create')
+        self._handle = handle
+        self._queue = None
+
+    def execute_in_place(self, command_queue, half_layer):
+        """Half-complex [H][W/2+1] -> real rows of W + 2 floats, in the same memory."""
+        self._queue = command_queue
+        check(lib().kimg_rfft_exec(self._handle, half_layer.ptr, half_layer.ptr, 1,
+                                   command_queue.handle), 'kimg_rfft_exec')
+
+    def __del__(self):
+        try:
+            handle, self._handle = self._handle, None
+            if handle and self._queue is not None:
+                self._queue.finish()
+            if handle and not _plan_pool.give(('real',) + self.shape, handle):
+                lib().kimg_rfft_plan_destroy(handle)
+        except Exception:
+            pass
+
+
 class GridImageTemplate:
     """Grid <-> image through a complex-to-complex transform keeping the real part
-    (image.py:561-606).  The grid need not be Hermitian."""
+    (image.py:561-606).  The grid need not be Hermitian.
 
-    def __init__(self, context, real_dtype):
+    ``tuning={'real_transform': False}`` switches off the complex-to-real route that grid -> image
+    takes for w = 0 (see :class:`GridToImage`)."""
+
+    def __init__(self, context, real_dtype, tuning=None):
         types.require_float32(real_dtype, 'GridImageTemplate')
+        tuning = tuning or {}
+        if set(tuning) - {'real_transform'}:
+            raise ValueError('bad GridImageTemplate tuning {}'.format(tuning))
+        self.real_transform = bool(tuning.get('real_transform', True))
         self.context = context
         self.real_dtype = np.dtype(real_dtype)
         self.layer_to_image = LayerToImageTemplate(context, real_dtype)
@@ -288,15 +326,33 @@ class GridToImage(_GridImage):
                  allocator=None):
         super().__init__(template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
                          template.layer_to_image, allocator)
+        self._real_plan = None
 
     def _run(self):
         grid, layer = self.buffer('grid'), self.buffer('layer')
         P, Gg, _ = grid.shape
         G = layer.shape[0]
+        q = self.command_queue
+        if self._layer_image.w == 0 and self.template.real_transform:
+            # w = 0: the phase factor is 1 and only the real part of the transform is used, which
+            # is the transform of the grid's Hermitian part: half the layer, a complex-to-real
+            # transform in place (real rows of G + 2 floats), half the traffic all the way
+            if self._real_plan is None:
+                self._real_plan = RealFftPlan((G, G))
+            image = self.buffer('image')
+            li = self._layer_image
+            for pol in range(P):
+                check(lib().kimg_grid_to_half_layer(layer.ptr, G, _pol_ptr(grid, pol), Gg, Gg,
+                                                    q.handle), 'kimg_grid_to_half_layer')
+                self._real_plan.execute_in_place(q, layer)
+                check(lib().kimg_real_layer_to_image(
+                    _pol_ptr(image, pol), G, layer.ptr, G + 2, G, self.buffer('kernel1d').ptr,
+                    li.lm_scale, li.lm_bias, q.handle), 'kimg_real_layer_to_image')
+            return
         for pol in range(P):
             check(lib().kimg_grid_to_layer(layer.ptr, G, _pol_ptr(grid, pol), Gg, Gg,
-                                           self.command_queue.handle), 'kimg_grid_to_layer')
-            self._fft.execute(self.command_queue, layer, inverse=True)
+                                           q.handle), 'kimg_grid_to_layer')
+            self._fft.execute(q, layer, inverse=True)
             self._layer_image.set_polarization(pol)
             self._layer_image()
 

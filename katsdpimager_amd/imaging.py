@@ -39,7 +39,7 @@ class ImagingTemplate:
         self.gridder = grid.GridderTemplate(context, fixed_image_parameters,
                                             fixed_grid_parameters, tuning.get('gridder'))
         self.predict = predict.PredictTemplate(context, dtype, num_pols)
-        self.grid_image = image.GridImageTemplate(context, dtype)
+        self.grid_image = image.GridImageTemplate(context, dtype, tuning.get('grid_image'))
         self.psf_patch = clean.PsfPatchTemplate(context, dtype, num_pols)
         self.noise_est = clean.NoiseEstTemplate(context, dtype, num_pols)
         self.clean = clean.CleanTemplate(context, clean_parameters, dtype, num_pols,

@@ -554,6 +554,47 @@ def test_grid_to_image_smaller_grid():
     assert relerr(i2g.buffer('grid').get(q), gi.middle(full_grid, small.shape)) < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('G,Gg,P', [(96, 40, 2), (64, 64, 1), (128, 126, 3), (4096, 2486, 1)])
+def test_grid_to_image_real_transform_route(G, Gg, P):
+    """w = 0: GridToImage takes the Hermitian part of the (zero-padded) grid through a
+    complex-to-real transform of half the size.  Against the oracle (= the reference's host path on
+    the padded grid) and against the complex-to-complex route of the same operator, with
+    accumulation; grids as large as the image (the -G/2 row and column have no mirror) and smaller."""
+    from katsdpimager_amd import image
+    ctx, q = context_queue()
+    rs = gi.RandomState(G + Gg)
+    small = rs.complex_uniform(-1, 1, (P, Gg, Gg)).astype(np.complex64)
+    k1d = rs.uniform(1.0, 2.0, G).astype(np.float32)
+    lm_scale = 0.3 / G
+    lm_bias = -0.5 * G * lm_scale
+    got = {}
+    for real in (True, False):
+        template = image.GridImageTemplate(ctx, np.float32, {'real_transform': real})
+        g2i = template.instantiate_grid_to_image(q, (P, Gg, Gg), lm_scale, lm_bias,
+                                                 template.make_fft_plan((G, G)))
+        g2i.ensure_all_bound()
+        g2i.buffer('kernel1d').set(q, k1d)
+        g2i.buffer('grid').set(q, small)
+        g2i.buffer('image').zero(q)
+        g2i.set_w(0.0)
+        g2i()
+        g2i()                                   # accumulates
+        got[real] = g2i.buffer('image').get(q)
+        assert (g2i._real_plan is not None) == real
+    peak = np.abs(got[False]).max()
+    assert np.abs(got[True] - got[False]).max() <= 2e-6 * peak
+    if G <= 128:
+        full = np.zeros((P, G, G), np.complex64)
+        gi.middle(full, small.shape)[:] = small
+        expected = np.zeros((P, G, G), np.float32)
+        orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, 0.0)
+        orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, 0.0)
+        assert relerr(got[True], expected) < 1e-5
+    with pytest.raises(ValueError):
+        image.GridImageTemplate(ctx, np.float32, {'real': True})
+
+
 def test_image_streams():
     """Scale / AddImage / ApplyPrimaryBeam known answers (test_image.py:91-162)."""
     from katsdpimager_amd import image
@@ -869,7 +910,10 @@ def test_end_to_end_vs_golden(golden, name, batched, streams):
     inner = np.s_[:, G // 8:-G // 8, G // 8:-G // 8]
     assert tapered_relerr(out['dirty0'], g['dirty0'], taper) < 1e-5
     assert relerr(out['dirty0'][inner], g['dirty0'][inner]) < 1e-4
-    np.testing.assert_allclose(out['noise0'], g['noise0'], rtol=1e-4)
+    # the noise estimate is a median of |dirty|, i.e. 1-Lipschitz in the max-norm: two images within
+    # 1e-5 of the peak of each other have estimates within 1e-5 of the peak (times 1.4826)
+    assert abs(float(out['noise0']) - float(g['noise0'])) \
+        <= max(1e-4 * float(g['noise0']), 1.4826e-5 * np.abs(g['dirty0']).max())
     np.testing.assert_array_equal(out['n_minor'], g['n_minor'])
     # first major cycle: identical peak sequence
     n0 = int(g['n_minor'][0])
