@@ -399,7 +399,9 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
     out = {}
     P, G = args.polarizations, args.pixels
 
-    # grid -> image (pad/shift + rocFFT + layer_to_image)
+    # grid -> image: at w = 0 (every slice of C2 / C5) the Hermitian part of the grid goes through a
+    # complex-to-real transform of half the size (kimg_grid_to_half_layer + rocFFT C2R in place +
+    # kimg_real_layer_to_image); at w != 0 pad/shift + rocFFT C2C + layer_to_image
     template = image.GridImageTemplate(ctx, np.float32)
     g2i = template.instantiate_grid_to_image(
         q, grid_buf.shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
@@ -408,20 +410,32 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
     g2i.ensure_all_bound()
     g2i.buffer('kernel1d').set(q, gridder.convolve_kernel.taper(G).astype(np.float32))
     g2i.buffer('image').zero(q)
-    g2i()
-    q.finish()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        g2i()
-    q.finish()
-    dt = (time.perf_counter() - t0) / 5
-    out['grid_to_image_ms'] = round(dt * 1e3, 3)
-    # compulsory HBM traffic per polarization: read the grid, write + FFT the layer (2 passes,
-    # read + write each), read it again, read-modify-write the image
     Gg = grid_buf.shape[1]
+
+    def g2i_time(w):
+        g2i.set_w(w)
+        g2i()
+        q.finish()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g2i()
+        q.finish()
+        return (time.perf_counter() - t0) / 5
+    dt = g2i_time(0.0)
+    dt_c2c = g2i_time(1.0)
+    out['grid_to_image_ms'] = round(dt * 1e3, 3)
+    out['grid_to_image_route'] = 'w = 0: Hermitian part + complex-to-real transform (in place, half layer)'
+    # compulsory HBM traffic per polarization of the reference's formulation (complex layer): read
+    # the grid, write + FFT the layer (2 passes, read + write each), read it again,
+    # read-modify-write the image ...
     g2i_bytes = P * (8 * Gg * Gg + 8 * G * G + 32 * G * G + 8 * G * G + 8 * G * G)
     out['grid_to_image_GBps'] = round(g2i_bytes / dt / 1e9, 1)
     out['grid_to_image_frac_of_8TBps'] = round(g2i_bytes / dt / 1e9 / HBM_PEAK_GBS, 4)
+    # ... and of the route actually run (half layer: every layer term halves)
+    route_bytes = P * (8 * Gg * Gg + 4 * G * G + 16 * G * G + 4 * G * G + 8 * G * G)
+    out['grid_to_image_route_GBps'] = round(route_bytes / dt / 1e9, 1)
+    out['grid_to_image_c2c_ms'] = round(dt_c2c * 1e3, 3)            # w != 0
+    out['grid_to_image_c2c_GBps'] = round(g2i_bytes / dt_c2c / 1e9, 1)
 
     # restoring-beam convolution of one polarization plane (R2C + Gaussian + C2R, beam.py:351-398)
     from katsdpimager_amd import beam

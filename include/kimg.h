@@ -252,6 +252,16 @@ int kimg_grid_to_half_layer(void *half_layer, int layer_size, const void *grid,
 int kimg_real_layer_to_image(float *image, int64_t image_row_stride, const float *layer,
                              int64_t layer_row_stride, int size, const float *kernel1d,
                              float lm_scale, float lm_bias, void *stream);
+/* ... and the other way (ImageToGrid, image.py:676-740) at w = 0, where the layer is real:
+ *   kimg_image_to_real_layer: layer = image[pol] / (k1d[y] k1d[x] n) with fftshift, rows of
+ *       layer_row_stride floats (G + 2 for the in-place real-to-complex kimg_rfft_exec, direction -1);
+ *   kimg_half_layer_to_grid: the centred grid from the half spectrum [G][G/2 + 1] that transform
+ *       leaves, F(-k) = conj F(k) for the columns it does not hold. */
+int kimg_image_to_real_layer(float *layer, int64_t layer_row_stride, const float *image,
+                             int64_t image_row_stride, int size, const float *kernel1d,
+                             float lm_scale, float lm_bias, void *stream);
+int kimg_half_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
+                            const void *half_layer, int layer_size, void *stream);
 
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
  * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */

@@ -43,6 +43,8 @@ PROTOTYPES = {
     'kimg_grid_to_layer': (c_int, [P, I, P, L, I, P]),
     'kimg_grid_to_half_layer': (c_int, [P, I, P, L, I, P]),
     'kimg_real_layer_to_image': (c_int, [P, L, P, L, I, P, F, F, P]),
+    'kimg_image_to_real_layer': (c_int, [P, L, P, L, I, P, F, F, P]),
+    'kimg_half_layer_to_grid': (c_int, [P, L, I, P, I, P]),
     'kimg_layer_to_grid': (c_int, [P, L, I, P, I, P]),
     'kimg_layer_to_image': (c_int, [P, L, P, I, P, F, F, F, P]),
     'kimg_image_to_layer': (c_int, [P, P, L, I, P, F, F, F, P]),

@@ -156,6 +156,50 @@ __global__ __launch_bounds__(256) void image_to_layer_kernel(
     layer[(int64_t) sy * G + sx] = make_float2(v * c, v * s);
 }
 
+// image_to_layer for w = 0: the layer is real (phase factor exactly (1, 0)); rows of
+// `layer_row_stride` floats, ready for an in-place real-to-complex transform.
+__global__ __launch_bounds__(256) void image_to_real_layer_kernel(
+    float *__restrict__ layer, int64_t layer_row_stride, const float *__restrict__ image,
+    int64_t image_row_stride, int G, const float *__restrict__ kernel1d, float lm_scale, float lm_bias)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= G)
+        return;
+    const int half = G / 2;
+    const int sx = x < half ? x + half : x - half;
+    const int sy = y < half ? y + half : y - half;
+    const float l = lm_coord(x, lm_scale, lm_bias);
+    const float m = lm_coord(y, lm_scale, lm_bias);
+    const float l2 = l * l, m2 = m * m;
+    const float n = sqrtf(1.0f - (m2 + l2));
+    const float taper = kernel1d[y] * kernel1d[x];
+    layer[(int64_t) sy * layer_row_stride + sx] = image[(int64_t) y * image_row_stride + x] / (taper * n);
+}
+
+// layer_to_grid from the half spectrum of a real layer: F(-k) = conj F(k).
+__global__ __launch_bounds__(256) void half_layer_to_grid_kernel(
+    float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, const float2 *__restrict__ half_layer,
+    int G)
+{
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gy = blockIdx.y;
+    if (gx >= Gg)
+        return;
+    const int half = Gg / 2, W = G / 2 + 1;
+    int lx = gx - half, ly = gy - half;
+    if (lx < 0) lx += G;
+    if (ly < 0) ly += G;
+    float2 v;
+    if (lx < W) {
+        v = half_layer[(int64_t) ly * W + lx];
+    } else {
+        v = half_layer[(int64_t) (ly ? G - ly : 0) * W + (G - lx)];
+        v.y = -v.y;
+    }
+    grid[(int64_t) gy * grid_row_stride + gx] = v;
+}
+
 struct scale_t { float v[4]; };
 
 __global__ __launch_bounds__(256) void scale_kernel(
@@ -232,6 +276,30 @@ extern "C" int kimg_real_layer_to_image(float *image, int64_t image_row_stride, 
     const dim3 blocks(kimg_divup(size, 256), size);
     real_layer_to_image_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(
         image, image_row_stride, layer, layer_row_stride, size, kernel1d, lm_scale, lm_bias);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_image_to_real_layer(float *layer, int64_t layer_row_stride, const float *image,
+                                        int64_t image_row_stride, int size, const float *kernel1d,
+                                        float lm_scale, float lm_bias, void *stream)
+{
+    KIMG_CHECK_ARG(image && layer && kernel1d && size > 0 && size % 2 == 0
+                   && image_row_stride >= size && layer_row_stride >= size);
+    const dim3 blocks(kimg_divup(size, 256), size);
+    image_to_real_layer_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(
+        layer, layer_row_stride, image, image_row_stride, size, kernel1d, lm_scale, lm_bias);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_half_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
+                                       const void *half_layer, int layer_size, void *stream)
+{
+    KIMG_CHECK_ARG(half_layer && grid && layer_size > 0 && layer_size % 2 == 0 && grid_size > 0
+                   && grid_size % 2 == 0 && grid_size <= layer_size && grid_row_stride >= grid_size);
+    const dim3 blocks(kimg_divup(grid_size, 256), grid_size);
+    half_layer_to_grid_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(
+        static_cast<float2 *>(grid), grid_row_stride, grid_size,
+        static_cast<const float2 *>(half_layer), layer_size);
     return kimg_launch_status();
 }
 

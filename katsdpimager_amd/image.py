@@ -224,11 +224,20 @@ class FftPlan:
                   'kimg_fft_plan_create')
         self._handle = handle
         self._queue = None
+        self._real = None
 
     def execute(self, command_queue, layer, inverse):
         self._queue = command_queue
         check(lib().kimg_fft_exec(self._handle, layer.ptr, 1 if inverse else -1,
                                   command_queue.handle), 'kimg_fft_exec')
+
+    def real_plan(self):
+        """The real <-> half-complex plan of the same size for the w = 0 routes of GridToImage /
+        ImageToGrid, made on first use and shared by the operators that share this plan (and its
+        `layer` buffer)."""
+        if self._real is None:
+            self._real = RealFftPlan(self.shape)
+        return self._real
 
     def __del__(self):
         try:
@@ -255,10 +264,10 @@ class RealFftPlan:
         self._handle = handle
         self._queue = None
 
-    def execute_in_place(self, command_queue, half_layer):
-        """Half-complex [H][W/2+1] -> real rows of W + 2 floats, in the same memory."""
+    def execute_in_place(self, command_queue, half_layer, inverse=True):
+        """Half-complex [H][W/2+1] <-> real rows of W + 2 floats, in the same memory."""
         self._queue = command_queue
-        check(lib().kimg_rfft_exec(self._handle, half_layer.ptr, half_layer.ptr, 1,
+        check(lib().kimg_rfft_exec(self._handle, half_layer.ptr, half_layer.ptr, 1 if inverse else -1,
                                    command_queue.handle), 'kimg_rfft_exec')
 
     def __del__(self):
@@ -291,7 +300,10 @@ class GridImageTemplate:
         self.image_to_layer = ImageToLayerTemplate(context, real_dtype)
 
     def make_fft_plan(self, shape_layer, padded_shape_layer=None):
-        return FftPlan(shape_layer)
+        plan = FftPlan(shape_layer)
+        if self.real_transform:
+            plan.real_plan()        # (plan creation costs milliseconds of host time: not in the loop)
+        return plan
 
     def instantiate_grid_to_image(self, *args, **kwargs):
         return GridToImage(self, *args, **kwargs)
@@ -337,8 +349,7 @@ class GridToImage(_GridImage):
             # w = 0: the phase factor is 1 and only the real part of the transform is used, which
             # is the transform of the grid's Hermitian part: half the layer, a complex-to-real
             # transform in place (real rows of G + 2 floats), half the traffic all the way
-            if self._real_plan is None:
-                self._real_plan = RealFftPlan((G, G))
+            self._real_plan = self._fft.real_plan()
             image = self.buffer('image')
             li = self._layer_image
             for pol in range(P):
@@ -364,11 +375,27 @@ class ImageToGrid(_GridImage):
                  allocator=None):
         super().__init__(template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
                          template.image_to_layer, allocator)
+        self._real_plan = None
 
     def _run(self):
         grid, layer = self.buffer('grid'), self.buffer('layer')
         P, Gg, _ = grid.shape
         G = layer.shape[0]
+        if self._layer_image.w == 0 and self.template.real_transform:
+            # w = 0: the layer is real; real-to-complex transform in place, the grid's other half
+            # from F(-k) = conj F(k)
+            q = self.command_queue
+            self._real_plan = self._fft.real_plan()
+            image = self.buffer('image')
+            li = self._layer_image
+            for pol in range(P):
+                check(lib().kimg_image_to_real_layer(
+                    layer.ptr, G + 2, _pol_ptr(image, pol), G, G, self.buffer('kernel1d').ptr,
+                    li.lm_scale, li.lm_bias, q.handle), 'kimg_image_to_real_layer')
+                self._real_plan.execute_in_place(q, layer, inverse=False)
+                check(lib().kimg_half_layer_to_grid(_pol_ptr(grid, pol), Gg, Gg, layer.ptr, G,
+                                                    q.handle), 'kimg_half_layer_to_grid')
+            return
         for pol in range(P):
             self._layer_image.set_polarization(pol)
             self._layer_image()

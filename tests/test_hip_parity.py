@@ -593,6 +593,26 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
         assert relerr(got[True], expected) < 1e-5
     with pytest.raises(ValueError):
         image.GridImageTemplate(ctx, np.float32, {'real': True})
+    # and back (ImageToGrid at w = 0: real layer, real-to-complex transform, F(-k) = conj F(k))
+    model = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
+    back = {}
+    for real in (True, False):
+        template = image.GridImageTemplate(ctx, np.float32, {'real_transform': real})
+        i2g = template.instantiate_image_to_grid(q, (P, Gg, Gg), lm_scale, lm_bias,
+                                                 template.make_fft_plan((G, G)))
+        i2g.ensure_all_bound()
+        i2g.buffer('kernel1d').set(q, k1d)
+        i2g.buffer('image').set(q, model)
+        i2g.buffer('grid').zero(q)
+        i2g.set_w(0.0)
+        i2g()
+        back[real] = i2g.buffer('grid').get(q)
+        assert (i2g._real_plan is not None) == real
+    peak = np.abs(back[False]).max()
+    assert np.abs(back[True] - back[False]).max() <= 2e-6 * peak
+    if G <= 128:
+        full_grid, _ = orc.image_to_grid(model, k1d, lm_scale, lm_bias, 0.0)
+        assert relerr(back[True], gi.middle(full_grid, small.shape)) < 1e-5
 
 
 def test_image_streams():

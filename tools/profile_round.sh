@@ -28,7 +28,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $HEAD --tr
 echo "stats rc=$?"
 grep -h "^{\"metric\"" $OUT/stats.log | tail -1 > $OUT/${R}_bench_profiled.json
 # everything else the bench exercises (secondary measurements + the major-cycle loop)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_full -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/stats_full.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_full -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/stats_full.log 2>&1
 echo "stats_full rc=$?"
 grep -h "^{\"metric\"" $OUT/stats_full.log | tail -1 > $OUT/${R}_bench_full_profiled.json
 python3 tools/summarize_profiles.py $OUT $R stats
