@@ -522,6 +522,10 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
             q, ap, ip, gp, args.vis_block)
         dg.bind(grid=grid_buf, weights=wts)
         dg.ensure_all_bound()
+        # the order of the slice was measured once (as the resident store does) for the gridder;
+        # its answer goes to the degridder with every chunk, without it `auto` would measure -- and
+        # synchronise -- per call
+        dg.locality_hint = gridder.locality_hint
 
         def degrid_all():
             for uv_c, wp_c, vis_c, n in chunks:
