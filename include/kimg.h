@@ -110,9 +110,12 @@ int kimg_kernel_table(void *table, const double *ws, int w_planes, int kernel_wi
  *   vis             complex64 [N][P]
  *   convolve_kernel complex64 [w_planes][oversample][kernel_width], unpadded
  *   workspace       device scratch, at least kimg_grid_workspace_bytes(max N, P, w_planes,
- *                   oversample, kernel_width) bytes (0 unless the kernel table is too large for
- *                   LDS -- more than 512 rows w_planes*oversample for widths <= 32, 256 for 33..64
- *                   -- in which case a zero-padded copy of it is built there on every call)
+ *                   oversample, kernel_width) bytes: 256 bytes (the chunk counter from which the
+ *                   waves of a long launch draw their work; without it -- NULL is accepted when the
+ *                   table fits LDS -- they take their chunks in a fixed order, a few per cent slower)
+ *                   plus, when the kernel table is too large for LDS -- more than 512 rows
+ *                   w_planes*oversample for widths <= 32, 256 for 33..64 -- a zero-padded copy of it,
+ *                   built there on every call.  One call at a time per workspace.
  *   variant         KIMG_VARIANT_*: automatic = MFMA window kernel when supported (kernel_width
  *                   <= 64), else the generic scatter kernel
  *   arith           KIMG_ARITH_* (above); anything else is KIMG_EINVAL
@@ -150,8 +153,9 @@ int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t grid_pol_stri
                 int64_t num_vis,
                 const void *convolve_kernel, int w_planes, int oversample, int kernel_width,
                 void *workspace, size_t workspace_bytes, int variant, int arith, void *stream);
-/* Device scratch kimg_degrid needs (0 unless the kernel table is too large for LDS; then a padded
- * copy of it is built there on every call, as for kimg_grid). */
+/* Device scratch kimg_degrid needs, as for kimg_grid: 256 bytes (the chunk counter of long launches;
+ * optional when the table fits LDS) plus, when the kernel table is too large for LDS, a padded copy
+ * of it, built there on every call.  One call at a time per workspace. */
 size_t kimg_degrid_workspace_bytes(int num_polarizations, int w_planes, int oversample,
                                    int kernel_width);
 /* Scratch of kimg_degrid with KIMG_VARIANT_BINNED (includes the above). */

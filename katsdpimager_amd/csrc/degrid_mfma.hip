@@ -124,7 +124,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     const int16_t *__restrict__ uv, const int16_t *__restrict__ w_plane,
     const float *__restrict__ weights, float *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
-    int p_total, const unsigned char *__restrict__ padded, const unsigned *__restrict__ tab_max)
+    int p_total, const unsigned char *__restrict__ padded, const unsigned *__restrict__ tab_max,
+    int64_t chunk, unsigned long long *queue)
 {
     static_assert(!TWO || TAPS == 32 || TG, "two tables only fit LDS with single rows");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -209,9 +210,69 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
         block_end = num_vis;
     const int64_t span = block_end > block_start ? block_end - block_start : 0;
     const int64_t start = block_start + (span * wib / NW) / 64 * 64;
-    const int64_t end = wib == NW - 1 ? block_end : block_start + (span * (wib + 1) / NW) / 64 * 64;
-    if (start >= end)
+    const int64_t end_static = wib == NW - 1 ? block_end : block_start + (span * (wib + 1) / NW) / 64 * 64;
+    // What a wave degrids (as in grid_mfma_kernel): chunk == 0: the contiguous range [start,
+    // end_static); chunk > 0 (long launches): chunks of `chunk` visibilities, the first one by the
+    // wave's number, the following ones drawn from the counter `queue` (or, without one, in steps of
+    // the number of waves), so that every wave is busy until the launch ends.
+    struct batch_pos {
+        int64_t b, e;       // first visibility of the batch; end of its chunk (b >= e: no batch)
+    };
+    const int64_t wave_id = (int64_t) blockIdx.x * NW + wib, waves = (int64_t) gridDim.x * NW;
+    const int64_t chunks_total = chunk > 0 ? (num_vis + chunk - 1) / chunk : 0;
+    auto chunk_pos = [&](int64_t c) __attribute__((always_inline)) {
+        batch_pos p;
+        p.b = c < chunks_total ? c * chunk : 0;
+        p.e = c < chunks_total ? (p.b + chunk < num_vis ? p.b + chunk : num_vis) : 0;
+        return p;
+    };
+    unsigned long long ticket = 0;          // lane 0: value returned by the last draw
+    int64_t static_next = wave_id + waves;
+    auto draw = [&]() __attribute__((always_inline)) {
+        if (queue != nullptr) {
+            if (lane == 0)
+                ticket = atomicAdd(queue, 1ull);
+        } else {
+            ticket = (unsigned long long) static_next;
+            static_next += waves;
+        }
+    };
+    auto drawn = [&]() __attribute__((always_inline)) {
+        const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ticket);
+        const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (ticket >> 32));
+        const int64_t t = (int64_t) (((unsigned long long) hi << 32) | lo);
+        return queue != nullptr ? t + waves : t;
+    };
+    auto next_pos = [&](const batch_pos &p) __attribute__((always_inline)) {
+        batch_pos n = p;
+        n.b = p.b + 64;
+        if (n.b >= p.e && chunk > 0 && p.b < p.e) {
+            n = chunk_pos(drawn());
+            if (n.b < n.e)
+                draw();
+        }
+        return n;
+    };
+    batch_pos pos;
+    if (chunk > 0) {
+        pos = chunk_pos(wave_id);
+        draw();
+    } else {
+        pos.b = start;
+        pos.e = end_static;
+    }
+    if (pos.b >= pos.e)
         return;
+    // the next batch's coordinates are fetched while the current one is worked on
+    auto load_coords = [&](const batch_pos &p, int2 &packed, int &wp) __attribute__((always_inline)) {
+        const int64_t i = p.b + lane;
+        const int64_t ii = i < p.e ? i : p.e - 1;
+        packed = reinterpret_cast<const int2 *>(uv)[ii];
+        wp = w_plane[ii];
+    };
+    int2 next_packed;
+    int next_wp;
+    load_coords(pos, next_packed, next_wp);
 
     const int uv_bias = (ts.K - 1) / 2 - Gg / 2;        // grid.py:1141
     const int half = Gg / 2;
@@ -315,16 +376,19 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
         have = true;
     };
 
-    for (int64_t b0 = start; b0 < end; b0 += 64) {
+    for (; pos.b < pos.e;) {
+        const int64_t b0 = pos.b, end = pos.e;
+        const batch_pos following = next_pos(pos);
         // ---- stage 64 visibilities (lane i <-> visibility b0 + i) ---------------------------
         int gmin_u, gmax_u, gmin_v, gmax_v;
         {
             const int64_t i = b0 + lane;
-            const int64_t ii = i < end ? i : end - 1;
-            const int2 packed = reinterpret_cast<const int2 *>(uv)[ii];
+            const int2 packed = next_packed;
+            const int wp = next_wp;
+            if (following.b < following.e)
+                load_coords(following, next_packed, next_wp);
             const int u = (short) (packed.x & 0xffff), v = (short) (packed.x >> 16);
             const int su = (short) (packed.y & 0xffff), sv = (short) (packed.y >> 16);
-            const int wp = w_plane[ii];
             const bool ok = i < end && (unsigned) (u + half) < (unsigned) Gg
                             && (unsigned) (v + half) < (unsigned) Gg && (unsigned) su < (unsigned) OV
                             && (unsigned) sv < (unsigned) OV && (unsigned) wp < (unsigned) W;
@@ -515,6 +579,7 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
+        pos = following;
     }
 }
 
@@ -564,6 +629,10 @@ size_t lds_bytes(int NW, int W, int OV, int taps, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+// The chunk counter of the call in progress on this host thread (in the workspace's tail, see
+// kimg_degrid_mfma): handed to launch() this way because every launch site is a macro.
+thread_local unsigned long long *tls_queue = nullptr;
+
 template <int P, int NW, int TAPS, bool TWO, bool TG = false, bool F16 = false>
 int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const int16_t *uv,
            const int16_t *w_plane, const float *weights, float *vis, int64_t num_vis,
@@ -602,9 +671,19 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
+    // long launches: work by the chunk (see batch_pos in the kernel)
+    const int64_t waves = (int64_t) blocks * NW;
+    int64_t parts = num_vis / (waves * 512);
+    parts = parts > 32 ? 32 : parts;
+    int64_t chunk = 0;
+    if (parts >= 2)
+        chunk = ((num_vis + waves * parts - 1) / (waves * parts) + 63) / 64 * 64;
+    unsigned long long *queue = chunk > 0 ? tls_queue : nullptr;
+    if (queue != nullptr)
+        KIMG_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
     degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, uv, w_plane, weights, vis, num_vis, kern, W, OV, ts,
-        vis_per_block, p_total, padded, tab_max);
+        vis_per_block, p_total, padded, tab_max, chunk, queue);
     return kimg_launch_status();
 }
 
@@ -621,12 +700,14 @@ bool kimg_degrid_mfma_supported(int P, int w_planes, int oversample, int kernel_
            && (int64_t) w_planes * oversample < 65536;        // row index packed in 16 bits
 }
 
-// Scratch for the padded HBM copy of the table (none when the tables fit LDS).
+// Scratch: the padded HBM copy of the table (none when the tables fit LDS) and a tail of 256
+// bytes (table maximum of the fp16 form at its start, the chunk counter of long launches 128 bytes in).
 size_t kimg_degrid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
 {
-    if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width)
-        || tables_fit_lds(w_planes, oversample, kernel_width))
+    if (!kimg_degrid_mfma_supported(P, w_planes, oversample, kernel_width))
         return 0;
+    if (tables_fit_lds(w_planes, oversample, kernel_width))
+        return 256;
     return (size_t) w_planes * oversample * 65 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
 
@@ -643,6 +724,8 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
                                                                          kernel_width)))
         return KIMG_EWORKSPACE;
     unsigned char *padded = static_cast<unsigned char *>(workspace);
+    tls_queue = (workspace != nullptr && workspace_bytes >= 256)
+        ? reinterpret_cast<unsigned long long *>(padded + workspace_bytes - 128) : nullptr;
     const int K = kernel_width;
     const bool wide = K > WIN;
     const int Kh = wide ? (K + 1) / 2 : K;

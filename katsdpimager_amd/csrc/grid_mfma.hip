@@ -275,6 +275,11 @@ struct pair_ops {
     uint2 t0[SUBP], t1[SUBP];   // column taps of the two tiles, same format
 };
 
+#ifdef KIMG_GRID_TIMING
+// (test builds only) per-wave {first, last} wall_clock64 of the last launch
+__device__ long long *g_timing = nullptr;
+#endif
+
 template <int P, int NW, int SUB, int ROW, bool TWO, bool TG = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     float *__restrict__ grid, int64_t row_stride, int64_t pol_stride, int Gg,
@@ -283,8 +288,11 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const float2 *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
     int p_total, int dbg, const unsigned char *__restrict__ padded,
-    const unsigned *__restrict__ tab_max)
+    const unsigned *__restrict__ tab_max, int64_t chunk, unsigned long long *queue)
 {
+#ifdef KIMG_GRID_TIMING
+    const long long t_begin = wall_clock64();
+#endif
     static_assert(!TWO || ROW == 32 || TG, "two tables only fit LDS with single rows");
     static_assert(!F16 || SUB % 2 == 0, "fp16 form: visibilities go in pairs");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -334,7 +342,68 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const int64_t start = block_start + wave_edge(wib);
     const int64_t end = wib == NW - 1 ? block_end : block_start + wave_edge(wib + 1);
 
-    auto load_raw = [&](int64_t b, vis_raw<P> &raw) __attribute__((always_inline)) {
+    // What a wave grids.  chunk == 0: the contiguous range [start, end) above.  chunk > 0 (long
+    // launches): the stream is cut into chunks of `chunk` visibilities (a multiple of 64); a wave
+    // starts with the chunk of its own number and then takes the next free one from a counter in
+    // device memory (`queue`), until none is left.  With one contiguous range per wave the launch
+    // ends in a long tail: the three waves of a SIMD do not advance at the same pace (the oldest
+    // wave wins the arbitration for the matrix pipe), so the first is done after 72 % of the
+    // launch and the last runs alone for the final 13 % -- at a fraction of the SIMD's rate.  Taking
+    // work by the chunk keeps all waves busy to the end; a chunk's end costs what a baseline
+    // boundary costs, one window flush.  Without a counter (`queue` null: no workspace given) wave g
+    // takes chunks g, g + waves, g + 2 waves, ... instead.
+    struct batch_pos {
+        int64_t b, e;       // first visibility of the batch; end of its chunk (b >= e: no batch)
+    };
+    const int64_t wave_id = (int64_t) blockIdx.x * NW + wib, waves = (int64_t) gridDim.x * NW;
+    const int64_t chunks_total = chunk > 0 ? (num_vis + chunk - 1) / chunk : 0;
+    auto chunk_pos = [&](int64_t c) __attribute__((always_inline)) {
+        batch_pos p;
+        p.b = c < chunks_total ? c * chunk : 0;
+        p.e = c < chunks_total ? (p.b + chunk < num_vis ? p.b + chunk : num_vis) : 0;
+        return p;
+    };
+    // the ticket for the chunk after the current one is drawn when the current one is entered, and
+    // only looked at when it is left (the atomic's round trip is off the critical path)
+    unsigned long long ticket = 0;          // lane 0: value returned by the last draw
+    int64_t static_next = wave_id + waves;
+    auto draw = [&]() __attribute__((always_inline)) {
+        if (queue != nullptr) {
+            if (lane == 0)
+                ticket = atomicAdd(queue, 1ull);
+        } else {
+            ticket = (unsigned long long) static_next;
+            static_next += waves;
+        }
+    };
+    auto drawn = [&]() __attribute__((always_inline)) {
+        const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ticket);
+        const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (ticket >> 32));
+        const int64_t t = (int64_t) (((unsigned long long) hi << 32) | lo);
+        return queue != nullptr ? t + waves : t;
+    };
+    auto next_pos = [&](const batch_pos &p) __attribute__((always_inline)) {
+        batch_pos n = p;
+        n.b = p.b + 64;
+        if (n.b >= p.e && chunk > 0 && p.b < p.e) {
+            n = chunk_pos(drawn());
+            if (n.b < n.e)
+                draw();
+        }
+        return n;
+    };
+    batch_pos p0;
+    if (chunk > 0) {
+        p0 = chunk_pos(wave_id);
+        draw();
+    } else {
+        p0.b = start;
+        p0.e = end;
+    }
+    batch_pos p1 = next_pos(p0), p2 = next_pos(p1);
+
+    auto load_raw = [&](const batch_pos &pos, vis_raw<P> &raw) __attribute__((always_inline)) {
+        const int64_t b = pos.b, end = pos.e;
         int64_t ii = b + lane;
         ii = ii < end ? ii : end - 1;
         raw.uv = reinterpret_cast<const int2 *>(uv)[ii];
@@ -344,14 +413,14 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
             raw.v[p] = vis[ii * p_total + p];
     };
     const int half = Gg / 2;
-    auto coords_ok = [&](int64_t b, const vis_raw<P> &raw) __attribute__((always_inline)) {
+    auto coords_ok = [&](const batch_pos &pos, const vis_raw<P> &raw) __attribute__((always_inline)) {
         const int u = (short) (raw.uv.x & 0xffff), v = (short) (raw.uv.x >> 16);
         const int su = (short) (raw.uv.y & 0xffff), sv = (short) (raw.uv.y >> 16);
-        return b + lane < end && (unsigned) (u + half) < (unsigned) Gg
+        return pos.b + lane < pos.e && (unsigned) (u + half) < (unsigned) Gg
                && (unsigned) (v + half) < (unsigned) Gg && (unsigned) su < (unsigned) OV
                && (unsigned) sv < (unsigned) OV && (unsigned) raw.wp < (unsigned) W;
     };
-    auto gather = [&](int64_t b, vis_raw<P> &raw) __attribute__((always_inline)) {
+    auto gather = [&](const batch_pos &b, vis_raw<P> &raw) __attribute__((always_inline)) {
         const int u = (short) (raw.uv.x & 0xffff), v = (short) (raw.uv.x >> 16);
         const int64_t wa = coords_ok(b, raw) ? (int64_t) (v + half) * wg_row_stride + (u + half) : 0;
 #pragma unroll
@@ -362,10 +431,13 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     // Two-deep prefetch of the visibility stream: issue the first loads before staging the
     // kernel table so that their latency hides behind it.
     vis_raw<P> r0, r1;
-    const bool active = start < end;
+    const bool active = p0.b < p0.e;
     if (active) {
-        load_raw(start, r0);
-        load_raw(start + 64, r1);
+        load_raw(p0, r0);
+        if (p1.b < p1.e)
+            load_raw(p1, r1);
+        else
+            r1 = r0;
     }
 
     // Stage the kernel table(s): taps [tap0, tap0 + Kp) of every row, zero-padded to 32 taps
@@ -447,7 +519,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     }
     if (!active)
         return;
-    gather(start, r0);
+    gather(p0, r0);
 
     const int uv_bias = (ts.K - 1) / 2 - Gg / 2;        // grid.py:1038
     const int Su = WIN - ts.Ku, Sv = WIN - ts.Kv;       // window slack along u and v
@@ -782,7 +854,8 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         }
     };
 
-    for (int64_t b = start; b < end; b += 64) {
+    for (; p0.b < p0.e; p0 = p1, p1 = p2, p2 = next_pos(p2)) {
+        const batch_pos &b = p0;
         // ---- stage batch b (lane i <-> visibility b + i) and its per-group bounds ----------
         int gb_u, gb_v;         // per group of 8 lanes: min | max << 16 of the first-tap coordinates
         int gmax_bits[P];       // fp16 form: bits of the group's largest sample | (spread too wide)
@@ -868,13 +941,13 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         // advance the global prefetch pipeline: b+64 gets its (dependent) weight gather,
         // b+128 its raw loads
         r0 = r1;
-        if (b + 64 < end)
-            gather(b + 64, r0);
-        if (b + 128 < end)
-            load_raw(b + 128, r1);
+        if (p1.b < p1.e)
+            gather(p1, r0);
+        if (p2.b < p2.e)
+            load_raw(p2, r1);
         __builtin_amdgcn_wave_barrier();        // LDS is in-order per wave; just pin the order
 
-        const int count = end - b < 64 ? (int) (end - b) : 64;
+        const int count = b.e - b.b < 64 ? (int) (b.e - b.b) : 64;
         const int npairs = (count + 2 * SUB - 1) / (2 * SUB);
         typename std::conditional<F16, pair_ops<P, SUB / 2>, sub_ops<P, SUB>>::type X, Y;
         stage_a(0);
@@ -974,6 +1047,12 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     }
     if (have && !(dbg & 1))
         flush_window<P, F16>(acc, grid, row_stride, pol_stride, Gg, Wu, Wv, Wu, Wv, true, lane, out_scale);
+#ifdef KIMG_GRID_TIMING
+    if (g_timing && lane == 0) {
+        g_timing[2 * wave_id] = t_begin;
+        g_timing[2 * wave_id + 1] = wall_clock64();
+    }
+#endif
 }
 
 template <int P>
@@ -1027,13 +1106,22 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+#ifndef KIMG_INTERLEAVE_MIN_CHUNK
+#define KIMG_INTERLEAVE_MIN_CHUNK 512
+#endif
+#ifndef KIMG_INTERLEAVE_MAX_PARTS
+#define KIMG_INTERLEAVE_MAX_PARTS 32
+#endif
+constexpr int64_t INTERLEAVE_MIN_CHUNK = KIMG_INTERLEAVE_MIN_CHUNK;     // visibilities: bounds the extra window flushes
+constexpr int64_t INTERLEAVE_MAX_PARTS = KIMG_INTERLEAVE_MAX_PARTS;
 
 template <int P, int ROW, int NW, bool TWO, bool TG = false, bool F16 = false>
 int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const float *wg,
            int64_t wg_row_stride, int64_t wg_pol_stride, const int16_t *uv,
            const int16_t *w_plane, const float2 *vis, int64_t num_vis, const float2 *kern,
            int W, int OV, const tap_split &ts, int p_total, hipStream_t stream,
-           unsigned char *padded = nullptr, size_t tab_max_offset = 0)
+           unsigned char *padded = nullptr, size_t tab_max_offset = 0,
+           unsigned long long *queue = nullptr)
 {
     constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
     const size_t lds = TG ? lds_bytes(P, NW, 0, 0, ROW) : lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
@@ -1073,9 +1161,20 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     if (vis_per_block < 64 * NW)
         vis_per_block = 64 * NW;
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
+    // Long launches: every wave takes its work from up to 16 places of the stream (chunks of at
+    // least ~1000 visibilities, see batch_pos in the kernel) instead of one contiguous range
+    const int64_t waves = (int64_t) blocks * NW;
+    int64_t parts = num_vis / (waves * INTERLEAVE_MIN_CHUNK);
+    parts = parts > INTERLEAVE_MAX_PARTS ? INTERLEAVE_MAX_PARTS : parts;
+    int64_t chunk = 0;
+    if (parts >= 2)
+        chunk = ((num_vis + waves * parts - 1) / (waves * parts) + 63) / 64 * 64;
+    if (chunk > 0 && queue != nullptr)
+        KIMG_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
     grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded, tab_max);
+        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded, tab_max, chunk,
+        chunk > 0 ? queue : nullptr);
     return kimg_launch_status();
 }
 
@@ -1105,14 +1204,17 @@ static bool table_in_lds(int P, int w_planes, int oversample, int kernel_width)
     return tables_fit_lds(P, w_planes, oversample, kernel_width) && kernel_width <= WIN;
 }
 
-// Scratch for the padded table copy (none when the kernel reads its table from LDS).
+// Scratch: the padded table copy (none when the kernel reads its table from LDS) and a tail of 256
+// bytes -- the table's maximum (fp16 form, tables in HBM) at its start, the chunk counter of long
+// launches 128 bytes in.  (A caller that gives a kernel with its table in LDS no scratch still
+// works: its waves then take their chunks in a fixed order.)
 size_t kimg_grid_mfma_workspace_bytes(int P, int w_planes, int oversample, int kernel_width)
 {
     if (!kimg_grid_mfma_supported(P, w_planes, oversample, kernel_width))
         return 0;
     const bool fits = tables_fit_lds(P, w_planes, oversample, kernel_width);
     if (fits && kernel_width <= WIN)
-        return 0;
+        return 256;
     return (size_t) w_planes * oversample * 64 * sizeof(float2) * (kernel_width > WIN ? 2 : 1) + 256;
 }
 
@@ -1129,6 +1231,8 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                                                                        kernel_width)))
         return KIMG_EWORKSPACE;
     unsigned char *padded = static_cast<unsigned char *>(workspace);
+    unsigned long long *queue = (workspace != nullptr && workspace_bytes >= 256)
+        ? reinterpret_cast<unsigned long long *>(padded + workspace_bytes - 128) : nullptr;
     const int K = kernel_width;
     const bool wide = K > WIN;
     const int Kh = wide ? (K + 1) / 2 : K;              // taps per block along one axis
@@ -1153,10 +1257,10 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
 #define GO(PP, ROWV, NWV, TWOV, TGV) do { \
         if (f16) rc = launch<PP, ROWV, NWV, TWOV, TGV, true>(g, grid_row_stride, grid_pol_stride, \
             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
-            oversample, ts, P, stream, padded, tab_max_offset); \
+            oversample, ts, P, stream, padded, tab_max_offset, queue); \
         else rc = launch<PP, ROWV, NWV, TWOV, TGV, false>(g, grid_row_stride, grid_pol_stride, \
             grid_size, wg, wg_row_stride, wg_pol_stride, uv, w_plane, v, num_vis, kern, w_planes, \
-            oversample, ts, P, stream, padded, tab_max_offset); } while (0)
+            oversample, ts, P, stream, padded, tab_max_offset, queue); } while (0)
                 const size_t tab_max_offset = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
                 // Diagonal blocks of a wide kernel take row and column taps from the same half of
                 // the table: one table, which fits LDS whenever a narrow kernel's would.
@@ -1205,3 +1309,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
     }
     return 0;
 }
+
+#ifdef KIMG_GRID_TIMING
+extern "C" int kimg_debug_grid_timing(void *buffer)
+{
+    long long *p = static_cast<long long *>(buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
