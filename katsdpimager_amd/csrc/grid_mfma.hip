@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
     const float2 *__restrict__ vis, int64_t num_vis,
     const float2 *__restrict__ kern, int W, int OV, tap_split ts, int64_t vis_per_block,
     int p_total, int dbg, const unsigned char *__restrict__ padded,
-    const unsigned *__restrict__ tab_max, int64_t chunk, unsigned long long *queue)
+    const unsigned *__restrict__ tab_max, int64_t chunk, int64_t scramble, unsigned long long *queue)
 {
 #ifdef KIMG_GRID_TIMING
     const long long t_begin = wall_clock64();
@@ -356,11 +356,19 @@ __global__ __launch_bounds__(NW * 64) void grid_mfma_kernel(
         int64_t b, e;       // first visibility of the batch; end of its chunk (b >= e: no batch)
     };
     const int64_t wave_id = (int64_t) blockIdx.x * NW + wib, waves = (int64_t) gridDim.x * NW;
+    // Ticket t is chunk (t * scramble) mod chunks_total (scramble is coprime to the number of chunks):
+    // the chunks in flight at any moment are spread over the whole stream.  Neighbouring chunks are
+    // neighbouring pieces of one baseline's track, and waves that flush their windows into the same
+    // region of the grid at the same time contend for the same cache lines in L2 (measured: handing
+    // out the first 85 % of a launch in 8 x longer chunks, in stream order, costs 4 %; gridding a
+    // stream that was physically interleaved gains 10 %).
     const int64_t chunks_total = chunk > 0 ? (num_vis + chunk - 1) / chunk : 0;
-    auto chunk_pos = [&](int64_t c) __attribute__((always_inline)) {
+    auto chunk_pos = [&](int64_t t) __attribute__((always_inline)) {
         batch_pos p;
-        p.b = c < chunks_total ? c * chunk : 0;
-        p.e = c < chunks_total ? (p.b + chunk < num_vis ? p.b + chunk : num_vis) : 0;
+        const int64_t c = t < chunks_total ? (int64_t) ((unsigned long long) t * (unsigned long long) scramble
+                                                        % (unsigned long long) chunks_total) : 0;
+        p.b = t < chunks_total ? c * chunk : 0;
+        p.e = t < chunks_total ? (p.b + chunk < num_vis ? p.b + chunk : num_vis) : 0;
         return p;
     };
     // the ticket for the chunk after the current one is drawn when the current one is entered, and
@@ -1107,10 +1115,10 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 #ifndef KIMG_INTERLEAVE_MIN_CHUNK
-#define KIMG_INTERLEAVE_MIN_CHUNK 512
+#define KIMG_INTERLEAVE_MIN_CHUNK 1024
 #endif
 #ifndef KIMG_INTERLEAVE_MAX_PARTS
-#define KIMG_INTERLEAVE_MAX_PARTS 32
+#define KIMG_INTERLEAVE_MAX_PARTS 16
 #endif
 constexpr int64_t INTERLEAVE_MIN_CHUNK = KIMG_INTERLEAVE_MIN_CHUNK;     // visibilities: bounds the extra window flushes
 constexpr int64_t INTERLEAVE_MAX_PARTS = KIMG_INTERLEAVE_MAX_PARTS;
@@ -1169,11 +1177,22 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     int64_t chunk = 0;
     if (parts >= 2)
         chunk = ((num_vis + waves * parts - 1) / (waves * parts) + 63) / 64 * 64;
+    // chunk numbers are scrambled by a multiplier coprime to their count
+    int64_t scramble = 1;
+    if (chunk > 0) {
+        const int64_t total = (num_vis + chunk - 1) / chunk;
+        static const int64_t primes[] = {7919, 7907, 7901, 7883, 7879, 7877, 7873};
+        for (int64_t m : primes)
+            if (total % m != 0) {
+                scramble = m;
+                break;
+            }
+    }
     if (chunk > 0 && queue != nullptr)
         KIMG_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
     grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16><<<blocks, NW * 64, lds, stream>>>(
         grid, row_stride, pol_stride, Gg, wg, wg_row_stride, wg_pol_stride, uv, w_plane, vis,
-        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded, tab_max, chunk,
+        num_vis, kern, W, OV, ts, vis_per_block, p_total, dbg, padded, tab_max, chunk, scramble,
         chunk > 0 ? queue : nullptr);
     return kimg_launch_status();
 }

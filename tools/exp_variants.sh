@@ -1,4 +1,4 @@
-for v in "1024 16" "512 32" "256 64" "2048 8"; do
+for v in "512 32" "1024 16" "2048 8" "4096 4"; do
   set -- $v
   python -c "from katsdpimager_amd import build; build.build_lib(force=True, extra_flags=['-DKIMG_INTERLEAVE_MIN_CHUNK=$1', '-DKIMG_INTERLEAVE_MAX_PARTS=$2'])" > gpurun_out/build_v.log 2>&1
   echo "== min_chunk $1 max_parts $2"
