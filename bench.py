@@ -355,7 +355,7 @@ def main():
             sec['chunked_' + arith] = {
                 'Mvis_per_s': round(n_vis / s_c / 1e6, 1), 'vis_block': vb,
                 'avg_launch_us': r['avg_launch_us'], 'frac': r['frac']}
-        sec.update(secondary(args, ctx, q, obs, ip, gp, ap, fn, grid_buf, chunks))
+        sec.update(secondary(args, ctx, q, obs, ip, gp, ap, fn, grid_buf, chunks, whole, n_vis))
         sec.update(geometry_sweep(args, ctx, q, dev))
         result['secondary'] = sec
         if args.extras:
@@ -391,7 +391,7 @@ def load_traffic(args, roofline):
     return t.get('bytes_per_launch') if same else None
 
 
-def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
+def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=None, n_whole=0):
     """CLEAN minor-cycles/s (second half of BASELINE's metric), FFT + layer_to_image, degrid,
     DFT predict."""
     import torch
@@ -541,8 +541,32 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks):
         rate = 2 * total / (time.perf_counter() - t0)
         peak = FP32_MFMA_PEAK_TFLOPS if arith == 'fp32' else F16_MFMA_PEAK_TFLOPS
         out['degrid_' + arith] = {'Mvis_per_s': round(rate / 1e6, 1),
-                                  'frac': round(flop_per_vis * rate / 1e12 / peak, 4), 'peak': peak}
+                                  'frac': round(flop_per_vis * rate / 1e12 / peak, 4), 'peak': peak,
+                                  'vis_block': args.vis_block}
         del dg
+        if whole is not None:
+            # ... and as the resident-store driver runs it: one launch over the whole slice
+            n_pad = whole['uv'].shape[0]
+            dgs = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(
+                q, ap, ip, gp, n_pad)
+            wts_all = accel.DeviceArray(ctx, (n_pad, P), np.float32,
+                                        tensor=torch.ones((n_pad, P), device=ctx.device))
+            torch.cuda.synchronize()
+            dgs.bind(grid=grid_buf, weights=wts_all, **whole)
+            dgs.ensure_all_bound()
+            dgs.num_vis = n_whole
+            dgs.locality_hint = gridder.locality_hint
+            dgs._run()
+            q.finish()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dgs._run()
+            q.finish()
+            rate = 3 * n_whole / (time.perf_counter() - t0)
+            out['degrid_slice_' + arith] = {'Mvis_per_s': round(rate / 1e6, 1),
+                                            'frac': round(flop_per_vis * rate / 1e12 / peak, 4),
+                                            'peak': peak}
+            del dgs, wts_all
 
     # direct (DFT) prediction of a 1000-component model: the reference's default predictor when
     # --degrid is not given (frontend.py:113-138, predict.py:419-438)
