@@ -288,6 +288,71 @@ def test_c2_forms_repeatable_at_scale():
     assert int((split[0] != 0).sum()) == int((exact[0] != 0).sum())
 
 
+@pytest.mark.parametrize('arith', ['fp32', 'split_fp16'])
+def test_long_launch_work_by_the_chunk(arith):
+    """A launch long enough for the window kernels to hand out their work by the chunk (>= 2 x 1024
+    visibilities per wave: 8.4 M here): (a) one launch with the chunk counter in the workspace, (b)
+    the same launch without a workspace (chunks taken round-robin; the C ABI accepts NULL when the
+    table fits LDS), (c) 1 M-visibility launches (one contiguous range per wave), gridder and
+    degridder.  Same cells, values within float32 summation-order rounding."""
+    import torch
+    from katsdpimager_amd import accel, grid
+    from katsdpimager_amd._lib import lib, check
+    n = 8 << 20
+    ctx, q, obs, fn_chunked, wg = _setup(4096, n, 32, 1, arith=arith)           # (c) vis_block 1 M
+    _, _, _, fn, _ = _setup(4096, n, 32, 1, vis_block=n, arith=arith, variant='mfma')
+    fn.bind(weights_grid=wg)
+    want = _grid_all(ctx, q, obs, fn_chunked).clone()
+    got_queue = _grid_all(ctx, q, obs, fn).clone()                              # (a)
+    peak = float(want.abs().max())
+    # (another split of the stream over the waves is another order of summation per cell: float32
+    # rounding of sums of ~10^3 terms, not just the order of the atomics)
+    tol = (4e-6 if arith == 'fp32' else 6e-6) * peak
+    assert float((got_queue - want).abs().max()) <= tol
+    assert int((got_queue != 0).sum()) == int((want != 0).sum())
+    # (b) straight through the C ABI, no workspace
+    assert fn._workspace_bytes == 256
+    g = fn.buffer('grid')
+    g.zero(q)
+    P, G = g.shape[0], g.shape[1]
+    table, W, OV, K = fn._kernel_args()
+    rc = lib().kimg_grid(g.ptr, G, G * G, G, P, wg.ptr, G, G * G, fn.buffer('uv').ptr,
+                         fn.buffer('w_plane').ptr, fn.buffer('vis').ptr, n, table, W, OV, K,
+                         None, 0, grid.GRID_VARIANTS['mfma'], grid.GRID_ARITH[arith], q.handle)
+    check(rc, 'kimg_grid')
+    q.finish()
+    got_static = g.tensor.clone()
+    assert float((got_static - want).abs().max()) <= tol
+    assert int((got_static != 0).sum()) == int((want != 0).sum())
+    # degridder: one long launch against 1 M-visibility launches (the order of a visibility's sum
+    # follows the window's position, so the two differ by float32 rounding)
+    import synth
+    ip, gp, ap = synth.make_parameters(obs, 1, 28)
+    model = accel.DeviceArray(ctx, g.shape, np.complex64, tensor=(want / peak).contiguous())
+    torch.cuda.synchronize()
+    res = {}
+    for vb in (n, 1 << 20):
+        dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith, 'variant': 'mfma'}) \
+            .instantiate(q, ap, ip, gp, vb)
+        out = torch.zeros((n, 1), dtype=torch.complex64, device=ctx.device)
+        ones = accel.DeviceArray(ctx, (vb, 1), np.float32, tensor=torch.ones((vb, 1), device=ctx.device))
+        dg.bind(grid=model, weights=ones)
+        dg.ensure_all_bound()
+        torch.cuda.synchronize()
+        for start in range(0, n, vb):
+            sl = slice(start, start + vb)
+            dg.bind(uv=accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=obs.uv[sl]),
+                    w_plane=accel.DeviceArray(ctx, (vb,), np.int16, tensor=obs.w_plane[sl]),
+                    vis=accel.DeviceArray(ctx, (vb, 1), np.complex64, tensor=out[sl]))
+            dg.num_vis = vb
+            dg()
+        q.finish()
+        res[vb] = out
+    scale = float(res[n].abs().max())
+    assert scale > 0
+    assert float((res[n] - res[1 << 20]).abs().max()) <= (2e-6 if arith == 'fp32' else 4e-6) * scale
+
+
 # ---- BASELINE config 5: the major-cycle loop at full size -------------------------------------
 def _c5_inputs(n_in=12_000_000, n_sources=150):
     import torch
