@@ -220,6 +220,8 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
     };
     const int64_t wave_id = (int64_t) blockIdx.x * NW + wib, waves = (int64_t) gridDim.x * NW;
     const int64_t chunks_total = chunk > 0 ? (num_vis + chunk - 1) / chunk : 0;
+    // (chunks are handed out in stream order: the degridder only reads the grid, neighbouring
+    // chunks share cache lines instead of contending for them)
     auto chunk_pos = [&](int64_t c) __attribute__((always_inline)) {
         batch_pos p;
         p.b = c < chunks_total ? c * chunk : 0;
@@ -673,8 +675,14 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
     // long launches: work by the chunk (see batch_pos in the kernel)
     const int64_t waves = (int64_t) blocks * NW;
-    int64_t parts = num_vis / (waves * 512);
-    parts = parts > 32 ? 32 : parts;
+#ifndef KIMG_DEGRID_MIN_CHUNK
+#define KIMG_DEGRID_MIN_CHUNK 512
+#endif
+#ifndef KIMG_DEGRID_MAX_PARTS
+#define KIMG_DEGRID_MAX_PARTS 32
+#endif
+    int64_t parts = num_vis / (waves * KIMG_DEGRID_MIN_CHUNK);
+    parts = parts > KIMG_DEGRID_MAX_PARTS ? KIMG_DEGRID_MAX_PARTS : parts;
     int64_t chunk = 0;
     if (parts >= 2)
         chunk = ((num_vis + waves * parts - 1) / (waves * parts) + 63) / 64 * 64;
