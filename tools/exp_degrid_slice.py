@@ -13,7 +13,7 @@ q = ctx.create_command_queue()
 dev = ctx.device
 obs = synth.make_observation(G, n, W, P, device=dev, seed=1)
 ip, gp, ap = synth.make_parameters(obs, P, K, degrid=True)
-for arith in ('fp32', 'split_fp16'):
+for arith in (sys.argv[1:] or ('fp32', 'split_fp16')):
     dg = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith, 'variant': 'mfma'}).instantiate(q, ap, ip, gp, n)
     shape = dg.slots['grid'].shape
     gen = torch.Generator(device=dev); gen.manual_seed(3)
