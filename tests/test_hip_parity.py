@@ -1347,6 +1347,7 @@ def test_device_kernel_table_arguments():
     (1024, 1, 1, 0.05, (65, 97)),        # one polarization, sum of squares (one-workgroup form: pixel loads)
     (4096, 1, 0, 0.02, (191, 161)),      # 7 x 7 lattice blocks, 14 884 tiles: the PSF patch does not fit LDS
     (1024, 1, 0, 0.02, (65, 225)),       # tall patch: a wave of the one-workgroup form has two chunks of rows
+    (4096, 1, 0, 0.02, (711, 675)),      # 24 x 23 = 552 lattice blocks: more than CUs, every form ends up with two launches
     (1008, 1, 0, 0.013, (65, 97)),       # border 13: groups of four pixels straddle the edges of image and lattice
 ])
 def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):

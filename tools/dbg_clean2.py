@@ -4,8 +4,13 @@ from helpers import context_queue
 from katsdpimager_amd import clean, parameters
 ctx, q = context_queue()
 G, P, mode, border, patch = 4096, 1, 0, 0.02, (111, 133)
+args = sys.argv[1:]
+if '--patch' in args:
+    i = args.index('--patch')
+    patch = (int(args[i + 1]), int(args[i + 2]))
+    del args[i:i + 3]
 rs = np.random.RandomState(G + P)
-g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 4.0) ** 2).astype(np.float32)
+g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / (4.0 if patch[0] < 300 else 60.0)) ** 2).astype(np.float32)
 psf = np.repeat((np.outer(g1, g1))[None].astype(np.float32), P, axis=0)
 dirty = (0.05 * rs.standard_normal((P, G, G))).astype(np.float32)
 for _ in range(200):
@@ -14,7 +19,7 @@ for _ in range(200):
 fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
 ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
 cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, mode, 0.01, 0.5, border)
-for form in (sys.argv[1:] or ('one_workgroup', 'one_launch')):
+for form in (args or ('one_workgroup', 'one_launch')):
     fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form}).instantiate(q, ip)
     fn.ensure_all_bound()
     fn.buffer('psf').set(q, psf)
