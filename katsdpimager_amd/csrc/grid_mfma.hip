@@ -1115,7 +1115,7 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 #ifndef KIMG_INTERLEAVE_MIN_CHUNK
-#define KIMG_INTERLEAVE_MIN_CHUNK 1024
+#define KIMG_INTERLEAVE_MIN_CHUNK 512
 #endif
 #ifndef KIMG_INTERLEAVE_MAX_PARTS
 #define KIMG_INTERLEAVE_MAX_PARTS 16
