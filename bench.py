@@ -688,6 +688,12 @@ def major_cycle_loop(args, ctx, q, obs, extras=False, arith='fp32', add_sources=
         accel.DeviceArray(ctx, (n, P), np.float32, tensor=obs.weights),
         accel.DeviceArray(ctx, (n, P), np.complex64, tensor=vis))
     torch.cuda.synchronize()
+    # the resident store measures the order of a stored slice once (VisibilityReaderDevice._locality)
+    # and hands the answer on with every chunk; without it the `auto` variant of gridder and
+    # degridder would measure -- and synchronise -- in every pass of the loop
+    im.set_chunk_device(chunk, 'vis')
+    im._gridder.measure_locality()
+    chunk.locality = im._gridder.locality_hint
     times = {}
 
     def timed(name, fn):
