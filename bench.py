@@ -74,6 +74,9 @@ def parse_args():
                    help='HBM bytes per launch from a rocprofv3 --pmc pass of this same command '
                         '(tools/profile_round.sh); included as roofline.traffic only if its '
                         'recorded configuration matches this run')
+    p.add_argument('--roctx', action='store_true',
+                   help='named roctx ranges around the stages of the major-cycle loop '
+                        '(rocprofv3 --marker-trace)')
     p.add_argument('--rehearse', action='store_true',
                    help='CPU rehearsal of the multi-process plumbing (rendezvous, broadcast, channel '
                         'assignment, barriers, reductions, the JSON line) with no device work; for '
@@ -696,11 +699,16 @@ def major_cycle_loop(args, ctx, q, obs, extras=False, arith='fp32', add_sources=
     chunk.locality = im._gridder.locality_hint
     times = {}
 
+    from katsdpimager_amd import trace
+    if getattr(args, 'roctx', False):
+        trace.enable()
+
     def timed(name, fn):
         q.finish()
         t0 = time.perf_counter()
-        out = fn()
-        q.finish()
+        with trace.range(name):
+            out = fn()
+            q.finish()
         times[name] = times.get(name, 0.0) + time.perf_counter() - t0
         return out
 

@@ -1159,7 +1159,15 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
             hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
-    const int dbg = 12 << 8;        // bits 8-15: span stagger of a SIMD's waves, percent
+    // bits 8-15: span stagger of a SIMD's waves, percent.  Bits 0-1 (test builds with
+    // -DKIMG_NO_ATOMICS, the counterpart of the reference's NO_ATOMICS switch,
+    // imager_kernels/atomic.mako:29-40): no end flush / no window flushes -- wrong results, for
+    // measuring what the float atomics cost.
+#ifdef KIMG_NO_ATOMICS
+    const int dbg = (12 << 8) | 3;
+#else
+    const int dbg = 12 << 8;
+#endif
     // as many blocks resident per CU as the LDS (kernel table + staging) allows;
     // every block streams a contiguous span (a multiple of 64).
     const int per_cu = (!TG && lds <= LDS_LIMIT / 2) ? 2 : 1;

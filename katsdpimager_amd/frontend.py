@@ -12,7 +12,7 @@ reference's ``iter_slice`` works through the façade's host setters.
 """
 import numpy as np
 
-from . import clean, weight
+from . import clean, trace, weight
 
 
 def _device_reader(reader):
@@ -97,10 +97,12 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
         return None
     num_pols = len(image_p.fixed.polarizations)
     imager.clear_model()
-    weights_noise, normalized_noise = make_weights(reader, rel_channel, imager, weight_type,
-                                                   vis_block)
+    with trace.range('make_weights'):
+        weights_noise, normalized_noise = make_weights(reader, rel_channel, imager, weight_type,
+                                                       vis_block)
     mid_w = slice_mid_w(image_p, grid_p)
-    make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
+    with trace.range('make_psf'):
+        make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
     dirty = imager.buffer('dirty')
     centre = dirty.shape[1] // 2
     psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
@@ -119,11 +121,13 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
         psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
         out['restoring_beam'] = beam.fit_beam(psf_core)
     for i in range(major):
-        make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
-                   i != 0, subtract_model)
+        with trace.range('make_dirty[%d]' % i):
+            make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
+                       i != 0, subtract_model)
         imager.scale_dirty(scale)
         out['major'] += 1
-        noise = imager.noise_est()
+        with trace.range('noise_est'):
+            noise = imager.noise_est()
         out['noise'] = noise
         imager.clean_reset()
         peak_value = imager.clean_cycle(psf_patch)
@@ -137,7 +141,8 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
             break
         threshold_metric = clean.power_to_metric(clean_p.mode, threshold)
         if batched_clean:
-            values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1)
+            with trace.range('clean[%d]' % i):
+                values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1)
             # the reference counts the cycle that found the peak below threshold too (:579-582)
             out['minor'] += len(values) + (1 if len(values) < clean_p.minor - 1 else 0)
         else:

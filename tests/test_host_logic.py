@@ -605,3 +605,20 @@ def test_loader_blocks_are_baseline_sorted(tmp_path):
     assert got == 100
     with pytest.raises(ValueError):
         next(ds2.data_iter(2, 2))
+
+
+def test_trace_ranges_off_and_on():
+    """trace.range is free when off, pushes / pops roctx ranges when on (libroctx64 ships with
+    ROCm; a missing library leaves tracing off)."""
+    from katsdpimager_amd import trace
+    trace.disable()
+    with trace.range('nothing'):
+        pass
+    assert not trace.enabled()
+    assert trace.enable('libdoes_not_exist_anywhere.so') is False
+    if trace.enable():
+        with trace.range('outer'):
+            with trace.range('inner'):
+                pass
+        trace.disable()
+    assert not trace.enabled()
