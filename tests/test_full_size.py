@@ -355,6 +355,23 @@ def test_long_launch_work_by_the_chunk(arith, K, W):
     assert float((res[n] - res[1 << 20]).abs().max()) <= (2e-6 if arith == 'fp32' else 4e-6) * scale
 
 
+def test_long_launch_ragged_length():
+    """The chunked long launch with a length that is no multiple of 64, of the chunk or of anything
+    else (last chunk and last batch partial), against 1 M-visibility launches."""
+    n = 7_000_003
+    ctx, q, obs, fn_chunked, wg = _setup(4096, n, 32, 1)
+    _, _, _, fn, _ = _setup(4096, n, 32, 1, vis_block=n, variant='mfma')
+    fn.bind(weights_grid=wg)
+    want = _grid_all(ctx, q, obs, fn_chunked).clone()
+    got = _grid_all(ctx, q, obs, fn).clone()
+    peak = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 4e-6 * peak
+    assert int((got != 0).sum()) == int((want != 0).sum())
+    # every visibility was gridded exactly once: the sums of all cells agree
+    a, b = got.to(__import__('torch').complex128).sum(), want.to(__import__('torch').complex128).sum()
+    assert abs(a - b) <= 1e-6 * abs(b)
+
+
 # ---- BASELINE config 5: the major-cycle loop at full size -------------------------------------
 def _c5_inputs(n_in=12_000_000, n_sources=150):
     import torch
