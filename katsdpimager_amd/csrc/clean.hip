@@ -1902,7 +1902,10 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 // hipGraph of GRAPH_CYCLES minor cycles, cached per argument set: the minor-cycle loop is
 // launch-bound, and replaying a captured graph costs far less host time than 2 launches
 // per cycle.  The device-side `limit` makes surplus cycles of the last replay no-ops.
-constexpr int GRAPH_CYCLES = 64;
+#ifndef KIMG_GRAPH_CYCLES
+#define KIMG_GRAPH_CYCLES 64
+#endif
+constexpr int GRAPH_CYCLES = KIMG_GRAPH_CYCLES;
 constexpr int GRAPH_CACHE = 32;     // argument sets (channels in flight x patch sizes)
 
 struct graph_entry {
