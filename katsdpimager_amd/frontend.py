@@ -220,3 +220,64 @@ def process_channels(jobs, workers=2):
     with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
         futures = [pool.submit(run, job) for job in jobs]
         return [f.result() for f in futures]
+
+
+def process_channel_stream(make_job, channels, workers=2):
+    """Image ``channels`` (any number) with at most ``workers`` of them in flight AND in memory.
+
+    :func:`process_channels` takes ready-made jobs, i.e. one imager per channel; a band of
+    hundreds of channels per GPU would not fit that way.  Here ``workers`` host threads draw
+    channels from a queue; a thread makes the job of its next channel only when it is free to
+    image it (``make_job(channel)`` or ``make_job(channel, worker)``, see
+    ``parallel.image_assigned_channels``) and drops it when the channel is done, so at most
+    ``workers`` imagers exist at a time -- or exactly ``workers`` for the whole band when the
+    callback re-uses one imager per ``worker`` index.  Returns the results in ``channels`` order.
+    """
+    import inspect
+    import queue
+    import threading
+    channels = list(channels)
+    try:
+        takes_worker = len(inspect.signature(make_job).parameters) >= 2
+    except (TypeError, ValueError):
+        takes_worker = False
+    results = [None] * len(channels)
+    errors = []
+    todo = queue.Queue()
+    for item in enumerate(channels):
+        todo.put(item)
+
+    def work(worker):
+        while not errors:
+            try:
+                index, channel = todo.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                job = make_job(channel, worker) if takes_worker else make_job(channel)
+                imager = job.get('imager')
+                if imager is not None and hasattr(imager, 'command_queue'):
+                    # the current HIP device is per host thread (new threads start on device 0)
+                    import torch
+                    with torch.cuda.device(imager.command_queue.context.device):
+                        results[index] = process_channel(**job)
+                else:
+                    results[index] = process_channel(**job)
+                del job, imager
+            except BaseException as exc:        # noqa: B902 -- re-raised in the caller's thread
+                errors.append(exc)
+                return
+
+    count = max(1, min(int(workers), len(channels)))
+    if count == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(w,), name='kimg-channel-%d' % w)
+                   for w in range(count)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return results

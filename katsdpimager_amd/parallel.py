@@ -69,17 +69,32 @@ def gather_stats(values, device='cpu'):
 def image_assigned_channels(make_job, num_channels, workers=2, runner=None):
     """Image this rank's share of `num_channels` channels: channel c belongs to rank c mod world_size
     (:func:`assign_channels`); a rank with several channels keeps up to `workers` of them in flight
-    on its GPU (``frontend.process_channels``: one host thread and one HIP stream per channel).
+    on its GPU (one host thread and one HIP stream per channel in flight).
 
-    ``make_job(channel)`` returns the keyword arguments of ``frontend.process_channel`` for one channel
-    (its own ``imager``, hence its own command queue).  Returns {channel: result} for this rank's
+    ``make_job(channel)`` -- or ``make_job(channel, worker)`` with ``worker`` in ``range(workers)``,
+    so that a callback can keep ONE imager and command queue per worker and re-use it for every
+    channel that worker images -- returns the keyword arguments of ``frontend.process_channel`` for
+    one channel.  Jobs are made lazily, when a worker is free to image them, and dropped when their
+    channel is done: at most `workers` imagers (grids, images, FFT layer, CLEAN state, workspaces)
+    exist at any time however many channels the rank owns (the reference images a band's channels one
+    after the other with one imager, frontend.py:749-767).  Returns {channel: result} for this rank's
     channels; no collective is involved (gather statistics with :func:`gather_stats` if needed).
-    ``runner`` replaces ``frontend.process_channels`` in tests."""
+    ``runner(make_job, channels, workers)`` replaces ``frontend.process_channel_stream`` in tests."""
     rank, size = world()
     mine = assign_channels(num_channels, size, rank)
-    jobs = [make_job(c) for c in mine]
     if runner is None:
         from . import frontend
-        runner = frontend.process_channels
-    results = runner(jobs, workers=workers) if jobs else []
+        runner = frontend.process_channel_stream
+    results = runner(make_job, mine, workers=workers) if mine else []
     return dict(zip(mine, results))
+
+
+def check_rank_devices(device_index, device='cpu'):
+    """Every rank of the job must drive its own GPU: gathers ``device_index`` (the rank's
+    ``torch.cuda.current_device()``, or any per-node unique id) and raises on rank collisions.
+    Returns the list of indices in rank order.  (One node: the driver launches one rank per GPU.)"""
+    rank, size = world()
+    ids = [int(x) for x in gather_stats([float(device_index)], device)[:, 0].tolist()]
+    if len(set(ids)) != len(ids):
+        raise RuntimeError('ranks share a GPU: device index by rank = {}'.format(ids))
+    return ids

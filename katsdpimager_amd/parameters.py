@@ -17,13 +17,17 @@ CLEAN_SUMSQ = 1
 
 
 def is_smooth(x):
-    """parameters.py:17-25."""
-    if x % 8 != 0:
+    """Is ``x`` an image size the FFT likes: a multiple of 8 with no prime factor above 7
+    (same answers as parameters.py:17-25 for every positive size)."""
+    x = int(x)
+    if x <= 0 or x & 7:
         return False
-    for d in [2, 3, 5, 7]:
-        while x % d == 0:
-            x = x // d
-    return x == 1
+    # divide out everything 2, 3, 5 and 7 contribute, whole bunches at a time
+    while True:
+        common = math.gcd(x, 2 * 2 * 2 * 3 * 5 * 7)
+        if common == 1:
+            return x == 1
+        x //= common
 
 
 class ArrayParameters:
@@ -87,22 +91,31 @@ def w_kernel_width(image_parameters, w, eps_w, antialias_width=0):
 
 
 def w_slices(image_parameters, max_w, eps_w, kernel_width, antialias_width=0):
-    """parameters.py:161-183."""
-    lo, hi = 0, 1
-    max_w = max_w * 0.5
+    """Fewest W slices for which the combined W + anti-aliasing kernel fits ``kernel_width``
+    taps (parameters.py:161-183; ``max_w`` in metres).
 
-    def measure(slices):
-        return w_kernel_width(image_parameters, max_w / (slices - 0.5), eps_w, antialias_width)
+    A slice is corrected to its centre, so only half of its thickness remains as residual w; the
+    first slice is half as thick as the others, hence ``count - 0.5`` slices share ``max_w``.
+    The kernel width falls monotonically with the slice count: double the count until the kernel
+    fits, then bisect between the last count known to fail and the first known to fit (the
+    reference's two comparisons, ``>`` while growing and ``<`` while bisecting, are kept so that
+    a kernel of exactly ``kernel_width`` is judged the same way)."""
+    residual_w = 0.5 * max_w
 
-    while measure(hi) > kernel_width:
-        hi *= 2
-    while hi - lo > 1:
-        mid = (lo + hi) // 2
-        if measure(mid) < kernel_width:
-            hi = mid
+    def width_with(count):
+        return w_kernel_width(image_parameters, residual_w / (count - 0.5), eps_w, antialias_width)
+
+    fits = 1
+    while width_with(fits) > kernel_width:
+        fits *= 2
+    fails = 0
+    while fits - fails > 1:
+        probe = (fits + fails) // 2
+        if width_with(probe) < kernel_width:
+            fits = probe
         else:
-            lo = mid
-    return hi
+            fails = probe
+    return fits
 
 
 class WeightParameters:

@@ -728,3 +728,81 @@ def get_totals(image, beam_major, beam_minor):
     sums = np.nansum(image, axis=(1, 2), dtype=np.float64)
     beam_area = 2 * math.pi * beam_major * beam_minor / (8 * math.log(2))
     return sums / beam_area
+
+
+# --------------------------------------------------------------------------
+# io.py:18-270 -- FITS output.  Parity status of THIS section: UNPINNED by a reference file
+# (astropy is absent, so the reference's writer cannot be run here and it has no test of its
+# own); the functions below restate, card by card, what io.py hands to astropy.io.fits, and
+# the test compares the product's header cards and raw data block with them.
+# --------------------------------------------------------------------------
+# io.py:21-34 (IQUV 1..4, RR LL RL LR -1..-4, and X / Y swapped relative to the IEEE
+# enumeration: YY XX YX XY = -5..-8); keys are the reference's polarization constants
+# (polarization.py:14-25: I Q U V = 1..4, RR RL LR LL = 5..8, XX XY YX YY = 9..12)
+FITS_POLARIZATIONS = {1: 1, 2: 2, 3: 3, 4: 4, 5: -1, 8: -2, 6: -3, 7: -4, 12: -5, 9: -6, 11: -7,
+                      10: -8}
+
+
+def fits_polarization_cards(axis, polarizations):
+    """io.py:38-85: ([(key, value)], permutation) of the STOKES axis."""
+    codes = np.array([FITS_POLARIZATIONS[p] for p in polarizations])
+    permute = np.argsort(codes) if codes[0] >= 0 else np.argsort(-codes)     # :66-70
+    codes = codes[permute]
+    ref = codes[0]
+    delta = codes[1] - codes[0] if len(codes) > 1 else 1                     # :73-76
+    if np.any(codes != np.arange(len(codes)) * delta + ref):                 # :77-78
+        raise ValueError('Polarizations do not form a linear sequence in FITS enumeration')
+    a = str(axis)
+    return [('CTYPE' + a, 'STOKES'), ('CRPIX' + a, 1.0), ('CRVAL' + a, float(ref)),
+            ('CDELT' + a, float(delta))], permute
+
+
+def fits_image(image, pixel_size, wavelength, polarizations, phase_centre_rad, beam=None,
+               bunit='Jy/beam', extra_fits_headers=None):
+    """io.py:126-204: the header cards in insertion order (DATE left out: it is the wall
+    clock) and the array handed to the HDU.  ``beam`` = (major, minor, theta) in pixels /
+    radians.  ORIGIN / HISTORY carry the reference's package name (io.py:129-130)."""
+    cards = []
+    if bunit is not None:
+        cards.append(('BUNIT', bunit))                                       # :127-128
+    cards += [('ORIGIN', 'katsdpimager'), ('HISTORY', 'Created by katsdpimager'),
+              ('TIMESYS', 'UTC')]
+    cards += [('CRPIX1', image.shape[2] * 0.5), ('CRPIX2', image.shape[1] * 0.5 + 1.0),
+              ('CRPIX4', 1.0)]                                               # :140-142
+    delt = float(np.degrees(np.arcsin(pixel_size)))                          # :144
+    cards += [('CDELT1', -delt), ('CDELT2', delt), ('CDELT4', 1.0)]
+    cards += [('EQUINOX', 2000.0), ('RADESYS', 'FK5'), ('CUNIT1', 'deg'), ('CUNIT2', 'deg'),
+              ('CUNIT4', 'Hz'), ('CTYPE1', 'RA---SIN'), ('CTYPE2', 'DEC--SIN'), ('CTYPE4', 'FREQ'),
+              ('CRVAL1', float(np.degrees(phase_centre_rad[0]))),
+              ('CRVAL2', float(np.degrees(phase_centre_rad[1]))),
+              ('CRVAL4', 299792458.0 / wavelength)]                          # :153-165
+    if beam is not None:                                                     # :166-171
+        cards += [('BMAJ', float(np.degrees(beam[0] * pixel_size))),
+                  ('BMIN', float(np.degrees(beam[1] * pixel_size))),
+                  ('BPA', float(np.degrees(beam[2])))]
+    cards += fits_polarization_cards(3, polarizations)[0]                    # :172
+    datamin = float(np.fmin.reduce(image, axis=None))                        # :176-180
+    datamax = float(np.fmax.reduce(image, axis=None))
+    if not np.isnan(datamin):
+        cards += [('DATAMIN', datamin), ('DATAMAX', datamax)]
+    if extra_fits_headers:                                                   # :182-184 (dict update)
+        d = dict(cards)
+        d.update(extra_fits_headers)
+        keys = [k for k, _ in cards] + [k for k in extra_fits_headers if k not in dict(cards)]
+        cards = [(k, d[k]) for k in keys]
+    return cards, image[np.newaxis, :, :, ::-1]                              # :191
+
+
+def fits_grid(grid_, cell_size, polarizations, real_dtype=np.float32):
+    """io.py:246-270: cards and the [complex][polarization][v][u] array of write_fits_grid."""
+    parts = np.ascontiguousarray(grid_).view(real_dtype).reshape(grid_.shape + (2,))   # :246
+    parts = parts.transpose(3, 0, 1, 2)                                                 # :247
+    cards = [('BUNIT', 'Jy'), ('ORIGIN', 'katsdpimager'),
+             ('CUNIT1', 'm'), ('CRPIX1', parts.shape[3] // 2 + 1.0), ('CRVAL1', 0.0),
+             ('CDELT1', float(cell_size)),
+             ('CUNIT2', 'm'), ('CRPIX2', parts.shape[2] // 2 + 1.0), ('CRVAL2', 0.0),
+             ('CDELT2', float(cell_size))]
+    pol_cards, permute = fits_polarization_cards(3, polarizations)
+    cards += pol_cards
+    cards += [('CTYPE4', 'COMPLEX'), ('CRPIX4', 1.0), ('CRVAL4', 1.0), ('CDELT4', 1.0)]
+    return cards, parts[:, permute, :, :]                                    # :269

@@ -140,6 +140,35 @@ def predict_inputs(c, seed=1):
                 components=components, w=1.2)
 
 
+def predict_mild_components():
+    """The reference's own predict test (test_predict.py:45-52) puts three sources within 2.5
+    arcmin of the phase centre, so that |phase| stays below ~40 turns and float32 carries it to
+    ~1e-5: three components at the pixel offsets of those sources from the centre of the 4096^2,
+    1e-5 rad/pixel image ((-16, -8), (-31, +10), (-70, -1) pixels in (l, m)), fluxes (I, Q, V) of
+    the same order as the catalogue's at 1.5 GHz."""
+    return {
+        (2048 - 8, 2048 - 16): np.array([14.8, 1.48, 0.0], np.float32),
+        (2048 + 10, 2048 - 31): np.array([6.2, 1.24, 1.24], np.float32),
+        (2048 - 1, 2048 - 70): np.array([1.9, 0.19, 1.9], np.float32),
+    }
+
+
+# ---- G12: parameter formulas (parameters.py:17-26, :135-183) -------------------------------
+W_SLICES_CASES = [
+    # pixel_size, pixels, wavelength, max_w, eps_w, kernel_width, antialias_width
+    (1e-5, 4096, 0.2, 5.0, 0.001, 7, 7.0),
+    (1e-5, 4096, 0.2, 8000.0, 0.001, 28, 7.0),
+    (2.6e-5, 4800, 0.21, 1000.0, 0.001, 60, 7.0),
+    (2.6e-5, 4800, 0.21, 8000.0, 0.001, 60, 7.0),
+    (2.6e-5, 4800, 0.21, 8000.0, 0.01, 64, 7.0),
+    (4e-5, 1024, 0.3, 100.0, 0.001, 16, 7.0),
+    (4e-5, 8192, 0.05, 7700.0, 0.003, 33, 5.0),
+    (1.3e-5, 6144, 0.21, 7700.0, 0.001, 16, 7.0),
+    (1.3e-5, 6144, 0.21, 0.5, 0.001, 64, 0.0),
+]
+IS_SMOOTH_RANGE = 20000
+
+
 # ---- G5 ---------------------------------------------------------------------
 IMAGE_CONFIGS = {
     # off-centre lm_bias and w as test_image.py:17-21

@@ -87,6 +87,25 @@ def test_parameters_match_reference_formulas():
     assert parameters.w_kernel_width(auto, 500.0 / (slices - 0.5), 0.001, 7.0) <= 60
 
 
+def test_parameter_formulas_vs_golden(golden):
+    """G12: is_smooth for every size below 20000 and w_slices / w_kernel_width on nine
+    configurations against the values of the reference's own functions (parameters.py:17-26,
+    :135-183; tools/gen_golden.py)."""
+    from types import SimpleNamespace
+    from katsdpimager_amd import parameters
+    g = golden('g12_parameters')
+    smooth = [x for x in range(1, gi.IS_SMOOTH_RANGE) if parameters.is_smooth(x)]
+    assert smooth == g['smooth'].tolist()
+    assert not parameters.is_smooth(0) and not parameters.is_smooth(-8)
+    for k, (ps, px, wl, max_w, eps, kw, aa) in enumerate(gi.W_SLICES_CASES):
+        ip = SimpleNamespace(image_size=ps * px, wavelength=wl)
+        n = parameters.w_slices(ip, max_w, eps, kw, aa)
+        assert n == g['w_slices'][k]
+        assert float(parameters.w_kernel_width(ip, 0.5 * max_w / (n - 0.5), eps, aa)) == \
+            g['w_kernel_width'][k]
+    assert len(set(g['w_slices'].tolist())) >= 4          # the cases do exercise the bisection
+
+
 def test_extract_sky_image_known():
     """test_predict.py:107-133 against the product's host code."""
     from katsdpimager_amd import predict, parameters
@@ -549,6 +568,126 @@ def test_write_fits_grid(tmp_path):
     ip3 = parameters.ImageParameters(fixed3, 1.0, None, 0.21, None, pixel_size=2e-5, pixels=64)
     with pytest.raises(ValueError):
         io.write_fits_grid(np.zeros((3, 8, 8), np.complex64), ip3, str(tmp_path / 'y.fits'), 0)
+
+
+def _fits_cards_and_block(path):
+    """(ordered [(key, value)] without the mandatory SIMPLE / BITPIX / NAXIS* cards, raw data bytes)"""
+    header, history, data = _read_fits(path)
+    raw = open(path, 'rb').read()
+    cards, pos = [], 0
+    while not raw[pos:pos + 3] == b'END':
+        key = raw[pos:pos + 8].decode('ascii').strip()
+        if key == 'HISTORY':
+            cards.append((key, raw[pos + 8:pos + 80].decode('ascii').rstrip()))
+        elif not (key in ('SIMPLE', 'BITPIX') or key.startswith('NAXIS')):
+            cards.append((key, header[key]))
+        pos += 80
+    start = (pos + 80) + (-(pos + 80) % 2880)
+    return cards, raw[start:start + data.nbytes], header
+
+
+def test_fits_writers_vs_restated_reference(tmp_path):
+    """The FITS files against a card-by-card restatement of io.py:88-270 (oracle.fits_image /
+    fits_grid: what the reference hands to astropy.io.fits): same cards in the same order, same
+    values to the last bit, and the raw big-endian data block byte for byte.  NOT pinned by a
+    reference-produced file: astropy is absent, the reference's writer cannot run here and has no
+    test of its own."""
+    import math
+    from oracle import kimg_oracle as orc
+    from katsdpimager_amd import beam, io, parameters, polarization as pol
+    rs = np.random.RandomState(11)
+    cases = [
+        ([pol.STOKES_I, pol.STOKES_Q, pol.STOKES_U, pol.STOKES_V], (0.3, -1.1), beam.Beam(1.0, 4.2, 2.2, -0.7),
+         'Jy/beam', {'OBJECT': 'J1939-6342', 'BUNIT': 'JY/BEAM', 'OBSERVER': 'x'}),
+        ([pol.STOKES_I], (5.9, 0.2), None, 'Jy/beam', None),
+        ([pol.STOKES_RR, pol.STOKES_LL], (0.0, -0.5), None, None, None),
+        ([pol.STOKES_XX, pol.STOKES_YY], (1.0, 0.5), beam.Beam(1.0, 2.0, 2.0, 0.0), 'Jy/beam', None),
+    ]
+    for n, (pols, centre, b, bunit, extra) in enumerate(cases):
+        fixed = parameters.FixedImageParameters(pols, np.float32)
+        ip = parameters.ImageParameters(fixed, 1.0, None, 0.2142, None, pixel_size=3.1e-5, pixels=40)
+        image = rs.standard_normal((len(pols), 40, 40)).astype(np.float32)
+        image[0, 3, 4] = np.nan
+        path = str(tmp_path / ('i%d.fits' % n))
+        try:
+            io.write_fits_image(image, ip, path, 0, centre, beam=b, bunit=bunit, extra_fits_headers=extra)
+        except ValueError:
+            # (XX, YY) is FITS (-6, -5): the file would need the permuted order, which the
+            # reference's write_fits_image silently ignores (io.py:172) and this writer refuses
+            assert pols == [pol.STOKES_XX, pol.STOKES_YY]
+            continue
+        want_cards, want_data = orc.fits_image(
+            image, ip.pixel_size, ip.wavelength, pols, centre,
+            None if b is None else (b.major, b.minor, b.theta), bunit, extra)
+        cards, block, header = _fits_cards_and_block(path)
+        assert header['BITPIX'] == -32 and header['NAXIS'] == 4
+        assert [header['NAXIS%d' % i] for i in (4, 3, 2, 1)] == list(want_data.shape)
+        # ours names itself in ORIGIN / HISTORY and stamps DATE; everything else is identical
+        strip = lambda cs: [(k, v) for k, v in cs if k not in ('ORIGIN', 'HISTORY', 'DATE')]
+        assert [k for k, _ in cards if k != 'DATE'] == [k for k, _ in want_cards]
+        for (k, v), (wk, wv) in zip(strip(cards), strip(want_cards)):
+            assert k == wk and type(v) is type(wv) and v == wv, (k, v, wv)
+        assert dict(cards)['ORIGIN'] == 'katsdpimager_amd'
+        assert block == np.ascontiguousarray(want_data, '>f4').tobytes()
+    # grids: every linear polarization list, permuted where FITS wants another order
+    for n, pols in enumerate([[pol.STOKES_I], [pol.STOKES_Q, pol.STOKES_I],
+                              [pol.STOKES_LL, pol.STOKES_RR], [pol.STOKES_XX, pol.STOKES_YY],
+                              [pol.STOKES_V, pol.STOKES_U, pol.STOKES_Q, pol.STOKES_I]]):
+        fixed = parameters.FixedImageParameters(pols, np.float32)
+        ip = parameters.ImageParameters(fixed, 1.0, None, 0.2142, None, pixel_size=3.1e-5, pixels=40)
+        g = (rs.standard_normal((len(pols), 22, 22)) + 1j * rs.standard_normal((len(pols), 22, 22))) \
+            .astype(np.complex64)
+        path = str(tmp_path / ('g%d.fits' % n))
+        io.write_fits_grid(g, ip, path, 0)
+        want_cards, want_data = orc.fits_grid(g, ip.cell_size, pols)
+        cards, block, header = _fits_cards_and_block(path)
+        assert [header['NAXIS%d' % i] for i in (4, 3, 2, 1)] == list(want_data.shape)
+        assert [k for k, _ in cards] == [k for k, _ in want_cards]
+        for (k, v), (wk, wv) in zip(cards, want_cards):
+            if k != 'ORIGIN':
+                assert type(v) is type(wv) and v == wv, (k, v, wv)
+        assert block == np.ascontiguousarray(want_data, '>f4').tobytes()
+    assert math.isclose(dict(want_cards)['CDELT1'], ip.cell_size)
+
+
+def test_process_channel_stream_bounds_live_jobs(monkeypatch):
+    """frontend.process_channel_stream / parallel.image_assigned_channels: jobs are made lazily, at
+    most `workers` exist at a time (a rank with hundreds of channels must not hold
+    hundreds of imagers), results come back in channel order, errors propagate."""
+    import threading
+    import time as _time
+    from katsdpimager_amd import frontend, parallel
+    lock = threading.Lock()
+    live, peak, made = set(), [0], []
+
+    class Job(dict):
+        def __del__(self):
+            with lock:
+                live.discard(self['channel'])
+
+    def make_job(channel, worker):
+        assert 0 <= worker < 3
+        with lock:
+            live.add(channel)
+            made.append((channel, worker))
+            peak[0] = max(peak[0], len(live))
+        return Job(channel=channel)
+
+    def fake_process_channel(channel):
+        _time.sleep(0.002)
+        if channel == 77:
+            raise RuntimeError('boom')
+        return channel * 2
+    monkeypatch.setattr(frontend, 'process_channel', fake_process_channel)
+    out = frontend.process_channel_stream(make_job, range(40), workers=3)
+    assert out == [2 * c for c in range(40)]
+    assert peak[0] <= 3 and len(made) == 40 and len({w for _, w in made}) >= 2
+    assert frontend.process_channel_stream(lambda c: Job(channel=c), [5, 3], workers=1) == [10, 6]
+    with pytest.raises(RuntimeError):
+        frontend.process_channel_stream(lambda c: Job(channel=c), [1, 77, 2], workers=2)
+    assert frontend.process_channel_stream(make_job, [], workers=2) == []
+    got = parallel.image_assigned_channels(make_job, 7, workers=3)
+    assert got == {c: 2 * c for c in range(7)}
 
 
 def _loader_arrays(rows=600, channels=3, pols=2, antennas=5, seed=8):

@@ -46,11 +46,15 @@ def _worker(rank, world_size, port, result_dir):
         # 3b. a rank with several channels hands exactly its own to the per-GPU channel pool
         seen = []
 
-        def runner(jobs, workers):
-            seen.append((tuple(j['channel'] for j in jobs), workers))
-            return [j['channel'] * 10 for j in jobs]
+        def runner(make_job, channels, workers):
+            seen.append((tuple(channels), workers))
+            return [make_job(c)['channel'] * 10 for c in channels]
         got = parallel.image_assigned_channels(lambda c: dict(channel=c), 5, workers=3, runner=runner)
         assert got == {c: c * 10 for c in mine} and seen == [(tuple(mine), 3)]
+        # 3c. every rank reports its own device; a collision is an error on every rank
+        assert parallel.check_rank_devices(rank) == list(range(world_size))
+        with pytest.raises(RuntimeError):
+            parallel.check_rank_devices(0)
         # 4. timing reduction and statistics gather
         slowest = parallel.max_over_ranks(1.0 + rank)
         stats = parallel.gather_stats([float(rank), checksum, float(len(mine))])
