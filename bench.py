@@ -118,6 +118,7 @@ class Timer:
         for k in range(steps):
             step(ev0[k], ev1[k])
         torch.cuda.synchronize()
+        self.local_sec_per_step = (time.perf_counter() - t0) / steps      # this rank's own clock
         self.barrier()
         t1 = time.perf_counter()
         elapsed = parallel.max_over_ranks(t1 - t0, self.dev) if reduce else t1 - t0
@@ -187,6 +188,12 @@ def main():
     ctx = accel.Context(local_rank)
     q = ctx.create_command_queue()
     dev = ctx.device
+    if world > 1:
+        # one process per GPU, every rank on its own device (one node: LOCAL_RANK = device index)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        rank_devices = parallel.check_rank_devices(torch.cuda.current_device(), dev)
+    else:
+        rank_devices = [torch.cuda.current_device()]
     P, K, W, G = args.polarizations, args.kernel_width, args.w_planes, args.pixels
 
     def barrier():
@@ -290,6 +297,10 @@ def main():
     sec_per_step, kern_ms = timer.run(slice_step('fp32'), args.steps, args.warmup)
     mvis = world * n_vis / sec_per_step / 1e6
     roofline = grid_roofline('fp32', K, P, n_vis, 1, kern_ms, args.variant)
+    # every rank's own numbers, so that the first multi-GPU run localises a slow rank
+    per_rank = parallel.gather_stats(
+        [float(channel), timer.local_sec_per_step * 1e3, kern_ms, roofline['frac'],
+         float(torch.cuda.current_device())], dev if world > 1 else 'cpu')
     traffic = load_traffic(args, roofline)
     if traffic is not None:
         roofline['traffic'] = traffic
@@ -308,7 +319,11 @@ def main():
                    'window_jump_fraction': round(jump_fraction, 5),
                    'broadcast_ms': round(t_bcast * 1e3, 3)},
         'roofline': roofline,
+        'per_rank': [{'rank': r, 'band_channel': int(row[0]), 'ms_per_step': round(row[1], 3),
+                      'kernel_ms': round(row[2], 3), 'roofline_frac': round(row[3], 4),
+                      'device': int(row[4])} for r, row in enumerate(per_rank.tolist())],
     }
+    assert [p['device'] for p in result['per_rank']] == rank_devices
 
     # ---- the opt-in fp16 hi/lo form, same step, scored against the pipe it uses -----------
     if args.variant != 'generic' and K <= 64:
@@ -360,7 +375,12 @@ def main():
                 'avg_launch_us': r['avg_launch_us'], 'frac': r['frac']}
         sec.update(secondary(args, ctx, q, obs, ip, gp, ap, fn, grid_buf, chunks, whole, n_vis))
         sec.update(geometry_sweep(args, ctx, q, dev))
+        sec.update(other_configs(args, ctx, q, dev))
+        extra_cpu = sec.pop('_cpu_baseline', None)
+        if extra_cpu and 'cpu_baseline' in result:
+            result['cpu_baseline'].update(extra_cpu)
         result['secondary'] = sec
+        result['production_order'] = production_order(args, ctx, q, obs, ip, gp, ap, wg, grid_buf)
         if args.extras:
             result['extras'] = extras(args, ctx, q, obs, ip, gp, ap, templates['fp32'], grid_buf,
                                       wg, uv_all, wp_all, vis_all)
@@ -511,6 +531,8 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     # bytes a cycle moves: 12 P patch^2 + tile refresh; only meaningful for big patches
     cyc_bytes = 12 * P * patch[1] * patch[2] + 4 * P * 1024 * ((patch[1] + 31) // 32 + 1) * ((patch[2] + 31) // 32 + 1)
     out['clean']['large_patch_GBps'] = round(cyc_bytes * large / 1e9, 1)
+    if args.cpu_sample > 0:
+        out['_cpu_baseline'] = cpu_baseline_rest(args, obs, gridder, sky, psf, small, ip, cp)
     del cl, pp
 
     # degridder over every chunk of the channel (hot loop of the 2nd+ major cycles with --degrid,
@@ -613,15 +635,33 @@ def geometry_sweep(args, ctx, q, dev):
     P, G, K = args.polarizations, args.pixels, args.kernel_width
     n2 = min(args.vis, 16 * args.vis_block)
 
-    def rate(obs2, Kx, arith='fp32', order=None):
+    def rate(obs2, Kx, arith='fp32', store_order=False):
+        """M records/s of one gridder launch over the whole stream.  The stream's order is measured
+        once, outside the timing, as the resident store does per slice (VisibilityReaderDevice.
+        _locality); `store_order`: first re-ordered the way the store does when it is closed
+        (kimg_store_reorder, no merge), and the cost of that one pass is returned too."""
         ip2, gp2, ap2 = synth.make_parameters(obs2, P, Kx)
         n = obs2.n_vis
+        uv, wp, vis = obs2.uv, obs2.w_plane, obs2.vis
+        reorder_ms = None
+        if store_order:
+            from katsdpimager_amd import preprocess
+            arrays = dict(uv=accel.DeviceArray(ctx, (n, 4), np.int16, tensor=uv),
+                          w_plane=accel.DeviceArray(ctx, (n,), np.int16, tensor=wp),
+                          weights=accel.DeviceArray(ctx, (n, P), np.float32, tensor=obs2.weights),
+                          vis=accel.DeviceArray(ctx, (n, P), np.complex64, tensor=vis))
+            torch.cuda.synchronize()
+            for _ in range(2):          # (the first call loads the kernels)
+                q.finish()
+                t0 = time.perf_counter()
+                out, kept = preprocess.reorder_device_arrays(q, P, n, arrays, Kx, obs2.oversample,
+                                                             obs2.w_planes, False)
+                q.finish()
+                reorder_ms = (time.perf_counter() - t0) * 1e3
+            uv, wp, vis = out['uv'].tensor, out['w_plane'].tensor, out['vis'].tensor
         op = grid.GridderTemplate(ctx, ip2.fixed, gp2.fixed, {'variant': args.variant, 'arith': arith}) \
             .instantiate(q, ap2, ip2, gp2, n)
         shape = op.slots['grid'].shape
-        uv, wp, vis = obs2.uv, obs2.w_plane, obs2.vis
-        if order is not None:
-            uv, wp, vis = uv[order].contiguous(), wp[order].contiguous(), vis[order].contiguous()
         op.bind(grid=accel.DeviceArray(ctx, shape, np.complex64),
                 weights_grid=accel.DeviceArray(ctx, shape, np.float32,
                                                tensor=torch.ones(shape, device=dev)),
@@ -631,6 +671,10 @@ def geometry_sweep(args, ctx, q, dev):
         op.ensure_all_bound()
         op.num_vis = n
         torch.cuda.synchronize()
+        if store_order:
+            op.locality_hint = True         # what the store hands on for a re-ordered slice
+        else:
+            op.measure_locality()
         op._run()
         q.finish()
         reps = 2
@@ -639,7 +683,8 @@ def geometry_sweep(args, ctx, q, dev):
             op._run()
         q.finish()
         taken.append(op.last_variant)
-        return round(reps * n / (time.perf_counter() - t0) / 1e6, 1)
+        r = round(reps * n / (time.perf_counter() - t0) / 1e6, 1)
+        return (r, round(reorder_ms, 3)) if store_order else r
 
     taken = []
     obs2 = synth.make_observation(G, n2, 256, P, device=dev, seed=5)
@@ -659,6 +704,161 @@ def geometry_sweep(args, ctx, q, dev):
         o = fn_order(obs3)
         out['order_%s_Mvis_per_s' % name] = rate(o['obs'], K)
         out['order_%s_note' % name] = o['note'] + '; variant taken by auto: ' + str(taken[-1])
+        # steady state of a channel: the resident store re-orders the slice once (when it is
+        # closed); every gridding / degridding pass after that runs the window kernel on it
+        r, ms = rate(o['obs'], K, store_order=True)
+        out['order_%s_store_order_Mvis_per_s' % name] = r
+        out['order_%s_store_reorder_ms' % name] = ms
+    return out
+
+
+def production_order(args, ctx, q, obs, ip, gp, ap, wg, grid_buf):
+    """The SAME channel as the reference's gridder receives it, and as this package's gridder
+    receives it after the resident store has been closed.
+
+    The headline stream is uncompressed (every dump of every baseline, whole tracks).  The
+    reference's preprocessor never delivers that: its loaders hand over blocks of ~256 dumps sorted
+    by baseline (loader_ms.py:465-468) and compress() merges neighbouring records that fall on the
+    same sub-cell (preprocess.cpp:334-397).  `as_delivered` grids exactly that stream with the
+    window kernel; `store_order` after the once-per-channel re-order of the resident store
+    (kimg_store_reorder: strips of grid columns swept along v), `store_merged` with the
+    whole-slice merge that goes with it by default.  Rates are in stored RECORDS per second and in
+    INPUT visibilities per second (the channel's 50 M); each roofline block counts the algorithmic
+    flops of the records actually gridded."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel, grid, preprocess
+    P, K = args.polarizations, args.kernel_width
+    o = synth.order_loader_blocks(obs)
+    m = o['obs']
+    out = {'stream': o['note'], 'input_visibilities': obs.n_vis}
+    n0 = m.n_vis
+    arrival = dict(uv=accel.DeviceArray(ctx, (n0, 4), np.int16, tensor=m.uv),
+                   w_plane=accel.DeviceArray(ctx, (n0,), np.int16, tensor=m.w_plane),
+                   weights=accel.DeviceArray(ctx, (n0, P), np.float32, tensor=m.weights),
+                   vis=accel.DeviceArray(ctx, (n0, P), np.complex64, tensor=m.vis))
+    tg = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': args.variant})
+    td = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': args.variant})
+    g = tg.instantiate(q, ap, ip, gp, n0)
+    d = td.instantiate(q, ap, ip, gp, n0)
+    resid = accel.DeviceArray(ctx, (n0, P), np.complex64)
+    torch.cuda.synchronize()
+
+    def timed(op, reps=3):
+        op._run()
+        q.finish()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(q.stream)
+        for _ in range(reps):
+            op._run()
+        e1.record(q.stream)
+        q.finish()
+        return e0.elapsed_time(e1) / reps
+
+    def measure(arrays, n, ordered):
+        g.bind(grid=grid_buf, weights_grid=wg, uv=arrays['uv'], w_plane=arrays['w_plane'],
+               vis=arrays['vis'])
+        d.bind(grid=grid_buf, uv=arrays['uv'], w_plane=arrays['w_plane'], weights=arrays['weights'],
+               vis=resid)
+        for op in (g, d):
+            op.ensure_all_bound()
+            op.num_vis = n
+        if ordered:
+            g.locality_hint = d.locality_hint = True
+            jumps = None
+        else:
+            jumps = g.measure_locality()
+            d.locality_hint = g.locality_hint
+        grid_buf.zero(q)
+        ms = timed(g)
+        roof = grid_roofline('fp32', K, P, n, 1, ms, args.variant)
+        ms_d = timed(d)
+        block = {
+            'records': n, 'grid_ms': round(ms, 4),
+            'records_per_s_M': round(n / ms / 1e3, 1),
+            'input_vis_per_s_M': round(obs.n_vis / ms / 1e3, 1),
+            'variant': g.last_variant,
+            'roofline': {k: roof[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                              'flop_per_vis', 'vis_per_launch', 'avg_launch_us')},
+            'degrid_ms': round(ms_d, 4), 'degrid_records_per_s_M': round(n / ms_d / 1e3, 1),
+            'degrid_frac': round(8.0 * K * K * P * n / (ms_d * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        }
+        if jumps is not None:
+            block['window_jump_fraction'] = round(jumps, 5)
+        return block
+    out['as_delivered'] = measure(arrival, n0, False)
+    for label, merge in (('store_order', False), ('store_merged', True)):
+        for _ in range(2):              # (the first call loads the kernels)
+            q.finish()
+            t0 = time.perf_counter()
+            arrays, kept = preprocess.reorder_device_arrays(q, P, n0, arrival, K, obs.oversample,
+                                                            obs.w_planes, merge)
+            q.finish()
+            ms = (time.perf_counter() - t0) * 1e3
+        block = measure(arrays, kept, True)
+        # paid once per channel, when the store is closed (includes the 8-byte read-back of the count)
+        block['reorder_ms_once_per_channel'] = round(ms, 3)
+        out[label] = block
+        del arrays
+    out['speedup_store_order_over_as_delivered'] = round(
+        out['as_delivered']['grid_ms'] / out['store_order']['grid_ms'], 2)
+    return out
+
+
+def other_configs(args, ctx, q, dev):
+    """Two more whole-channel gridding measurements in the default run (float32, one launch per
+    W-slice, same timing as the headline): BASELINE config 4 (8192^2, 64 W-planes, 4 polarizations)
+    and the C2 geometry with the longest baseline at 0.49 of the image size, so that the grid is
+    (nearly) the full 4096^2 the metric's wording names (the headline's `cover` = 0.30 gives a
+    2486^2 grid: SURVEY 8d)."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel, grid
+    out = {}
+
+    def one(G, W, P, cover, seed):
+        obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=cover, seed=seed)
+        ip, gp, ap = synth.make_parameters(obs, P, args.kernel_width)
+        n = obs.n_vis
+        op = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': args.variant}) \
+            .instantiate(q, ap, ip, gp, n)
+        shape = op.slots['grid'].shape
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        op.bind(grid=accel.DeviceArray(ctx, shape, np.complex64),
+                weights_grid=accel.DeviceArray(ctx, shape, np.float32,
+                                               tensor=torch.rand(shape, generator=gen, device=dev)),
+                uv=accel.DeviceArray(ctx, (n, 4), np.int16, tensor=obs.uv),
+                w_plane=accel.DeviceArray(ctx, (n,), np.int16, tensor=obs.w_plane),
+                vis=accel.DeviceArray(ctx, (n, P), np.complex64, tensor=obs.vis))
+        op.ensure_all_bound()
+        op.num_vis = n
+        torch.cuda.synchronize()
+        op.measure_locality()
+        op._run()
+        q.finish()
+        reps = 3
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(q.stream)
+        for _ in range(reps):
+            op._run()
+        e1.record(q.stream)
+        q.finish()
+        ms = e0.elapsed_time(e1) / reps
+        launches = (P + 1) // 2                 # two polarizations per launch
+        roof = grid_roofline('fp32', args.kernel_width, P, n, launches, ms, args.variant)
+        return {'Mvis_per_s': round(n / ms / 1e3, 1), 'ms_per_pass': round(ms, 3),
+                'grid_size': shape[1], 'pixels': G, 'w_planes': W, 'polarizations': P,
+                'visibilities': n, 'frac': roof['frac'], 'achieved_TFLOPs': roof['achieved'],
+                'peak': roof['peak'], 'launches_per_pass': launches}
+    out['full_cover_grid'] = one(args.pixels, args.w_planes, args.polarizations, 0.49, 11)
+    out['full_cover_grid_Mvis_per_s'] = out['full_cover_grid']['Mvis_per_s']
+    if (args.pixels, args.w_planes, args.polarizations) == (4096, 32, 1):
+        out['c4'] = one(8192, 64, 4, 0.30, 12)
+        out['c4']['workload'] = ('C4: 8192^2 image, 64 W-planes, 4 polarizations, K={}, {} vis, one '
+                                 'pass = all polarizations').format(args.kernel_width, args.vis)
     return out
 
 
@@ -915,6 +1115,78 @@ def cpu_baseline(args, obs, gridder, wg, Gg):
     return out
 
 
+def cpu_baseline_rest(args, obs, gridder, sky, psf, patch, ip, cp):
+    """The other halves of the metric on the host, 1 thread, median of 5 (3 for the FFT), same
+    inputs as the GPU measurements next to them:
+      clean_cycles_per_s  the oracle's restatement of CleanHost (clean.py:1060-1075, _tile_peak
+                          :946-968 in C, the PSF subtraction in numpy like the reference) on the
+                          bench's CLEAN image, same patch as `secondary.clean.small_patch`;
+      grid_to_image_ms    GridToImageHost (image.py:781-799): numpy ifft2 (pocketfft) of the padded
+                          4096^2 layer + taper / n correction, one polarization, w = 0;
+      degrid_Mvis_per_s   the C restatement of `_degrid` (grid.py:1138-1154)."""
+    from oracle import kimg_oracle as orc
+    out = {}
+    G = args.pixels
+    # CLEAN
+    cycles = 200
+    rates = []
+    for _ in range(5):
+        dirty = sky.copy()
+        model = np.zeros_like(dirty)
+        ref = orc.Clean(G, cp.border, cp.loop_gain, cp.mode, dirty, psf, model)
+        ref.reset()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            ref(patch, 0.0)
+        rates.append(cycles / (time.perf_counter() - t0))
+    out['clean_cycles_per_s'] = round(float(np.median(rates)), 1)
+    out['clean_sample'] = ('median of 5 runs of {} cycles, {}^2 image, patch {}x{}, CleanHost restated '
+                           '(tile scan in C, subtraction in numpy)').format(cycles, G, patch[1], patch[2])
+    # grid -> image
+    Gg = gridder.slots['grid'].shape[1]
+    full = np.zeros((1, G, G), np.complex64)
+    lo = (G - Gg) // 2
+    rs = np.random.RandomState(1)
+    full[0, lo:lo + Gg, lo:lo + Gg] = (rs.standard_normal((Gg, Gg))
+                                       + 1j * rs.standard_normal((Gg, Gg))).astype(np.complex64)
+    k1d = gridder.convolve_kernel.taper(G).astype(np.float32)
+    image = np.zeros((1, G, G), np.float32)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.grid_to_image(full, image, k1d, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size), 0.0)
+        times.append(time.perf_counter() - t0)
+    out['grid_to_image_ms'] = round(float(np.median(times)) * 1e3, 1)
+    out['grid_to_image_sample'] = 'median of 3, one polarization, {}^2, numpy pocketfft, 1 thread'.format(G)
+    del full, image
+    # degrid
+    S = min(max(args.cpu_sample // 4, 1), obs.n_vis)
+    runs = 64
+    run_len = max(S // runs, 1)
+    starts = np.linspace(0, obs.n_vis - run_len, runs).astype(np.int64)
+    idx = (starts[:, None] + np.arange(run_len)[None, :]).reshape(-1)
+    import torch
+    sel = torch.from_numpy(idx).to(obs.uv.device)
+    uv = obs.uv[sel].cpu().numpy()
+    wp = obs.w_plane[sel].cpu().numpy()
+    vis = obs.vis[sel].cpu().numpy()
+    wts = obs.weights[sel].cpu().numpy()
+    P = vis.shape[1]
+    model = (rs.standard_normal((P, Gg, Gg)) + 1j * rs.standard_normal((P, Gg, Gg))).astype(np.complex64)
+    uv01 = np.ascontiguousarray(uv[:, :2])
+    uv23 = np.ascontiguousarray(uv[:, 2:])
+    kernel = gridder.convolve_kernel.data
+    times = []
+    for _ in range(5):
+        v = vis.copy()
+        t0 = time.perf_counter()
+        orc.degrid(kernel, model, uv01, uv23, wp, wts, v)
+        times.append(time.perf_counter() - t0)
+    out['degrid_Mvis_per_s'] = round(len(idx) / float(np.median(times)) / 1e6, 4)
+    out['degrid_sample'] = 'median of 5 passes over {} visibilities ({} runs of {})'.format(len(idx), runs, run_len)
+    return out
+
+
 def rehearse(args):
     """The multi-process skeleton of main() on CPU tensors (gloo): same rendezvous, broadcast,
     channel assignment, barrier-bracketed timing, max-over-ranks and one JSON line from rank 0 --
@@ -947,9 +1219,11 @@ def rehearse(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))
+    local_ms = (time.perf_counter() - t0) / args.steps * 1e3      # this rank's own clock
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
-    stats = parallel.gather_stats([float(channel), checksum])
+    stats = parallel.gather_stats([float(channel), checksum, local_ms])
+    devices = parallel.check_rank_devices(rank)        # (stands in for the GPU index of the rank)
     if rank == 0:
         print(json.dumps({
             'metric': 'Mvis/s gridded (4096^2 grid, 32 W-planes)',
@@ -959,7 +1233,9 @@ def rehearse(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rehearsal': 'no device work: plumbing only',
             'config': {'workload': 'rehearsal', 'channels': world,
-                       'band_channels': [int(c) for c in stats[:, 0].tolist()]}}))
+                       'band_channels': [int(c) for c in stats[:, 0].tolist()]},
+            'per_rank': [{'rank': r, 'band_channel': int(row[0]), 'ms_per_step': round(row[2], 3),
+                          'device': devices[r]} for r, row in enumerate(stats.tolist())]}))
     if world > 1:
         dist.destroy_process_group()
 

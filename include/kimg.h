@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KIMG_VERSION 2
+#define KIMG_VERSION 3
 
 #define KIMG_EINVAL (-10001)      /* bad argument (null pointer, negative size ...) */
 #define KIMG_EUNSUPPORTED (-10002) /* parameter combination not supported by this build */
@@ -222,6 +222,27 @@ int kimg_preprocess_compress(int num_polarizations, int64_t num_vis, int w_slice
                              int16_t *out_uv, int16_t *out_w_plane, float *out_weights, void *out_vis,
                              uint64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
 int kimg_real_to_complex(void *dst, const float *src, int64_t count, void *stream);
+
+/* ---- once-per-channel re-ordering of a stored W-slice (csrc/store.hip).  No launch site of the
+ * reference corresponds to it: the reference's preprocessor leaves a slice in arrival order
+ * (baseline-sorted load blocks, adjacent-merged: loader_ms.py:465-468, preprocess.cpp:334-397) and
+ * its gridder bins per pass inside the kernel (grid.mako; grid.py:436-463 get_bin_size).  The
+ * resident store (preprocess.VisibilityCollectorDevice) calls this once when it is closed; every
+ * later pass of the channel runs the window kernels on the result.
+ *   order: strips of (32 - taps + 1) grid columns (taps = kernel_width, or (kernel_width + 1) / 2
+ *       for widths above 32), each strip sorted by v, odd strips backwards; stable.
+ *   merge != 0: the sort also covers (u in strip, sub_v, sub_u, w_plane), and every run of records
+ *       with equal (u, v, sub_u, sub_v, w_plane) becomes ONE record whose weights and visibilities
+ *       are the run's sums, added left to right in float32 in arrival order -- compress() of
+ *       preprocess.cpp:334-372 applied to whole-slice runs instead of arrival runs.
+ *   Outputs need room for num_vis records; *out_count (device uint64) = records written.
+ *   workspace: kimg_store_reorder_workspace_bytes(num_vis) bytes (28 per record + sort scratch). */
+size_t kimg_store_reorder_workspace_bytes(int64_t num_vis);
+int kimg_store_reorder(int num_polarizations, int64_t num_vis, int kernel_width, int oversample,
+                       int w_planes, int merge, const int16_t *uv, const int16_t *w_plane,
+                       const float *weights, const void *vis, int16_t *out_uv, int16_t *out_w_plane,
+                       float *out_weights, void *out_vis, uint64_t *out_count, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ---- grid <-> image: image.py:649-673 GridToImage._run, :716-740 ImageToGrid._run,
  * :153-180 _LayerImage._run + layer_to_image.mako / image_to_layer.mako.

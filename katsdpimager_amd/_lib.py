@@ -18,7 +18,7 @@ I = c_int
 L = c_int64
 F = c_float
 
-VERSION = 2     # KIMG_VERSION of include/kimg.h
+VERSION = 3     # KIMG_VERSION of include/kimg.h
 
 PROTOTYPES = {
     'kimg_version': (c_int, []),
@@ -40,6 +40,8 @@ PROTOTYPES = {
     'kimg_preprocess_workspace_bytes': (ctypes.c_size_t, [L, I]),
     'kimg_preprocess_compress': (c_int, [I, L, I, P, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
     'kimg_real_to_complex': (c_int, [P, P, L, P]),
+    'kimg_store_reorder_workspace_bytes': (c_size_t, [L]),
+    'kimg_store_reorder': (c_int, [I, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     'kimg_grid_to_layer': (c_int, [P, I, P, L, I, P]),
     'kimg_grid_to_half_layer': (c_int, [P, I, P, L, I, P]),
     'kimg_real_layer_to_image': (c_int, [P, L, P, L, I, P, F, F, P]),

@@ -394,8 +394,16 @@ class Gridder(GridDegrid):
         if nbytes:
             self._workspace = accel.DeviceArray(self.command_queue.context, (nbytes,), np.uint8,
                                                 queue=self.command_queue)
-        self._init_locality(lib().kimg_grid_binned_workspace_bytes(
-            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2]))
+        binned = lib().kimg_grid_binned_workspace_bytes(
+            self.max_vis, num_pols, table.shape[0], table.shape[1], table.shape[2])
+        # the window gridder packs first-tap coordinates into 16 bits and addresses a polarization
+        # plane with 32-bit byte offsets (kimg_grid: grid_size <= 32000, grid_size * row_stride * 8
+        # < 2^32); wider grids go to the generic kernel whatever the stream's order, so `auto`
+        # must not ask for the binned variant there
+        Gg = self.slots['grid'].shape[1]
+        if Gg > 32000 or Gg * Gg * 8 >= 1 << 32:
+            binned = 0
+        self._init_locality(binned)
 
     def _run(self):
         grid = self.buffer('grid')

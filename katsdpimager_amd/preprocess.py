@@ -25,6 +25,11 @@ from . import accel
 from ._lib import lib, check
 
 
+def _trace_range(name):
+    from . import trace
+    return trace.range(name)
+
+
 def make_store_dtype(num_polarizations):
     """Record type yielded by ``iter_slice``: the fields and offsets of the reference's
     ``_make_dtype`` applied to ``vis_t<P>`` (preprocess.py:42-56, preprocess.cpp:39-52)."""
@@ -54,6 +59,43 @@ class DeviceChunk:
         return self.num_vis
 
 
+def reorder_device_arrays(queue, num_polarizations, num_vis, arrays, kernel_width, oversample,
+                          w_planes, merge, rows=None):
+    """``kimg_store_reorder`` on a dict of device arrays ``uv`` int16 [N][4], ``w_plane`` int16 [N],
+    ``weights`` float32 [N][P], ``vis`` complex64 [N][P] (the first ``num_vis`` rows): returns
+    (dict of new arrays with ``rows`` rows, zero beyond the data; number of records kept).
+    Synchronises with ``queue`` (one 8-byte read-back: the record count)."""
+    context = queue.context
+    P = num_polarizations
+    L = lib()
+    n = int(num_vis)
+    rows = n if rows is None else int(rows)
+    ws_bytes = int(L.kimg_store_reorder_workspace_bytes(n))
+    if ws_bytes == 0:
+        raise ValueError('cannot re-order {} records'.format(n))
+    ws = accel.DeviceArray(context, (ws_bytes,), np.uint8, queue=queue)
+    out = dict(
+        uv=accel.DeviceArray(context, (rows, 4), np.int16, queue=queue),
+        w_plane=accel.DeviceArray(context, (rows,), np.int16, queue=queue),
+        weights=accel.DeviceArray(context, (rows, P), np.float32, queue=queue),
+        vis=accel.DeviceArray(context, (rows, P), np.complex64, queue=queue))
+    count = accel.DeviceArray(context, (1,), np.int64, queue=queue)
+    check(L.kimg_store_reorder(
+        P, n, int(kernel_width), int(oversample), int(w_planes), 1 if merge else 0,
+        arrays['uv'].ptr, arrays['w_plane'].ptr, arrays['weights'].ptr, arrays['vis'].ptr,
+        out['uv'].ptr, out['w_plane'].ptr, out['weights'].ptr, out['vis'].ptr,
+        count.ptr, ws.ptr, ws_bytes, queue.handle), 'kimg_store_reorder')
+    kept = int(count.get(queue)[0])
+    if kept < rows:
+        # rows beyond the data are read (and masked) by full-block views: keep them zero
+        torch = accel._torch()
+        with torch.cuda.stream(queue.stream):
+            for a in out.values():
+                a.tensor[kept:].zero_()
+        queue.finish()
+    return out, kept
+
+
 class _SliceStore:
     """Growable structure-of-arrays for one (channel, w_slice).  ``slack`` rows beyond the
     data are always allocated so that a full-size block view can start at any row."""
@@ -66,6 +108,8 @@ class _SliceStore:
         self.length = 0
         self.capacity = 0
         self.arrays = None
+        #: True once :meth:`reorder` has put the records into the window kernels' order
+        self.ordered = False
 
     def _allocate(self, rows):
         P = self.P
@@ -104,6 +148,23 @@ class _SliceStore:
                                   np.s_[self.length:self.length + count])
         self.length += count
 
+    def reorder(self, kernel_width, oversample, w_planes, merge):
+        """Put the slice into the order the window gridder / degridder run fastest on (strips of
+        grid columns swept along v: ``kimg_store_reorder``, csrc/store.hip) and, with ``merge``,
+        sum all records with equal quantised coordinates into one.  Once per channel; every later
+        pass reads the result.  Returns the number of records kept."""
+        if self.length == 0 or self.ordered:
+            self.ordered = True
+            return self.length
+        n = self.length
+        out, kept = reorder_device_arrays(self.queue, self.P, n, self.arrays, kernel_width,
+                                          oversample, w_planes, merge, rows=n + self.slack)
+        self.arrays = out
+        self.capacity = n + self.slack
+        self.length = kept
+        self.ordered = True
+        return kept
+
     def view(self, start, rows):
         out = {}
         for name, a in self.arrays.items():
@@ -141,7 +202,8 @@ class VisibilityCollectorDevice:
         preprocess.cpp:431-509); also the largest block ``iter_slice_device`` can serve.
     """
 
-    def __init__(self, command_queue, image_parameters, grid_parameters, buffer_size):
+    def __init__(self, command_queue, image_parameters, grid_parameters, buffer_size,
+                 reorder=True, merge=True):
         if len(image_parameters) != len(grid_parameters):
             raise ValueError('Inconsistent lengths of image_parameters and grid_parameters')
         if buffer_size <= 0:
@@ -158,6 +220,11 @@ class VisibilityCollectorDevice:
         self.store_dtype = make_store_dtype(P)
         self.num_input = 0
         self.num_output = 0
+        #: records held after :meth:`close` (``num_output`` counts what the reference counts: the
+        #: records its compress() emits; the whole-slice merge of the re-order can only lower it)
+        self.num_stored = 0
+        self.reorder = bool(reorder)
+        self.merge = bool(merge)
         self._closed = False
         self._stores = [
             [_SliceStore(self.context, self.queue, P, self.buffer_size)
@@ -288,7 +355,24 @@ class VisibilityCollectorDevice:
         self.queue.finish()
 
     def close(self):
+        """preprocess.py:152-156.  New here: with ``reorder`` (the default) every stored W-slice is
+        put, once, into the order the window gridder / degridder run fastest on, and with ``merge``
+        all its records with equal quantised coordinates are summed into one
+        (:meth:`_SliceStore.reorder`); every later pass of the channel -- weights, PSF, image,
+        degrid + regrid per major cycle -- reads that order."""
+        if self._closed:
+            return
         self._closed = True
+        if self.reorder:
+            with _trace_range('store_reorder'):
+                for ch, stores in enumerate(self._stores):
+                    gp = self.grid_parameters[ch]
+                    kernel_width = getattr(gp.fixed, 'kernel_width', None)
+                    if kernel_width is None or kernel_width > 64:
+                        continue            # (no window kernel for this geometry)
+                    for store in stores:
+                        store.reorder(kernel_width, gp.fixed.oversample, gp.w_planes, self.merge)
+        self.num_stored = sum(s.length for ch in self._stores for s in ch)
 
     def reader(self):
         """Only after :meth:`close` (preprocess.py:152-156)."""
@@ -346,6 +430,9 @@ class VisibilityReaderDevice:
         if key not in self._locality_cache:
             from . import grid
             store = self._stores[channel][w_slice]
+            if store.ordered:
+                self._locality_cache[key] = True        # strip order: made for the window kernels
+                return True
             kernel_width = getattr(self.collector.grid_parameters[channel].fixed, 'kernel_width', None)
             if kernel_width is None or store.length < grid.AUTO_MIN_VIS:
                 self._locality_cache[key] = None

@@ -806,3 +806,56 @@ def fits_grid(grid_, cell_size, polarizations, real_dtype=np.float32):
     cards += pol_cards
     cards += [('CTYPE4', 'COMPLEX'), ('CRPIX4', 1.0), ('CRVAL4', 1.0), ('CDELT4', 1.0)]
     return cards, parts[:, permute, :, :]                                    # :269
+
+
+# --------------------------------------------------------------------------
+# Resident-store order (katsdpimager_amd/csrc/store.hip).  NOT a restatement of the reference --
+# it has no such step -- but of this package's own definition, kept here so that the device
+# kernels are checked against independent numpy code.  What IS pinned to the reference is the
+# result of gridding / degridding the re-ordered store: equal (to float rounding) to `grid` /
+# `degrid` above applied to the stream in arrival order.
+# --------------------------------------------------------------------------
+def store_strip_width(kernel_width):
+    taps = kernel_width if kernel_width <= 32 else (kernel_width + 1) // 2
+    return 32 - taps + 1
+
+
+def _bits_for(values):
+    b = 0
+    while (1 << b) < values:
+        b += 1
+    return b
+
+
+def store_reorder(uv4, w_plane, weights, vis, kernel_width, oversample, w_planes, merge):
+    """uv4 int16 [N][4] = (u, v, sub_u, sub_v).  Returns (uv4, w_plane, weights, vis) in store
+    order; with ``merge`` runs of equal coordinates are summed left to right in float32."""
+    width = store_strip_width(kernel_width)
+    u = uv4[:, 0].astype(np.int64) + 32768
+    v = uv4[:, 1].astype(np.int64) + 32768
+    strip = u // width
+    vv = np.where(strip & 1, 65535 - v, v)
+    key = (strip << 16) | vv
+    if merge:
+        sub_bits, wp_bits, in_bits = _bits_for(oversample), _bits_for(w_planes), _bits_for(width)
+        key = (key << in_bits) | (u - strip * width)
+        key = (key << sub_bits) | (uv4[:, 3].astype(np.int64) & ((1 << sub_bits) - 1))
+        key = (key << sub_bits) | (uv4[:, 2].astype(np.int64) & ((1 << sub_bits) - 1))
+        key = (key << wp_bits) | (w_plane.astype(np.int64) & ((1 << wp_bits) - 1))
+    order = np.argsort(key.astype(np.uint64), kind='stable')
+    uv_s, wp_s, w_s, vis_s = uv4[order], w_plane[order], weights[order], vis[order]
+    if not merge or len(order) == 0:
+        return uv_s, wp_s, w_s, vis_s
+    head = np.ones(len(order), bool)
+    head[1:] = np.any(uv_s[1:] != uv_s[:-1], axis=1) | (wp_s[1:] != wp_s[:-1])
+    starts = np.flatnonzero(head)
+    lengths = np.diff(np.append(starts, len(order)))
+    out_w = w_s[starts].copy()
+    out_v = vis_s[starts].copy()
+    # k-th member of every run that has one, added in turn: left to right within each run
+    for k in range(1, int(lengths.max())):
+        sel = lengths > k
+        idx = starts[sel] + k
+        out_w[sel] = out_w[sel] + w_s[idx]
+        out_v[sel] = (out_v[sel].real + vis_s[idx].real) + 1j * (out_v[sel].imag + vis_s[idx].imag)
+    return uv_s[starts], wp_s[starts], out_w, out_v.astype(np.complex64)

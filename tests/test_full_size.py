@@ -557,8 +557,31 @@ def test_c2_orders_binned_vs_track_order():
     ref, v0 = run(obs)
     assert v0 == 'mfma'
     peak = float(ref.abs().max())
+    from katsdpimager_amd import preprocess
     for order, want_variant in ((synth.order_time_major, 'binned'), (synth.order_shuffled, 'binned'),
                                 (synth.order_loader_blocks, 'mfma')):
-        got, variant = run(order(obs)['obs'])
+        o = order(obs)['obs']
+        fn.locality_hint = None
+        got, variant = run(o)
         assert variant == want_variant, order.__name__
         assert float((got - ref).abs().max()) <= 1e-5 * peak, order.__name__
+        # ... and after the resident store's once-per-channel re-order (with and without the
+        # whole-slice merge): the window kernel as it is, the same grid
+        m = o.n_vis
+        arrays = dict(uv=accel.DeviceArray(ctx, (m, 4), np.int16, tensor=o.uv),
+                      w_plane=accel.DeviceArray(ctx, (m,), np.int16, tensor=o.w_plane),
+                      weights=accel.DeviceArray(ctx, (m, 1), np.float32, tensor=o.weights),
+                      vis=accel.DeviceArray(ctx, (m, 1), np.complex64, tensor=o.vis))
+        torch.cuda.synchronize()
+        for merge in (False, True):
+            out, kept = preprocess.reorder_device_arrays(q, 1, m, arrays, 28, obs.oversample,
+                                                         obs.w_planes, merge)
+            assert (kept == m) if not merge else (0 < kept <= m)
+            q.finish()
+            so = synth._copy_with(o, out['uv'].tensor[:kept], out['w_plane'].tensor[:kept],
+                                  out['vis'].tensor[:kept], out['weights'].tensor[:kept])
+            fn.locality_hint = True
+            got, variant = run(so)
+            assert variant == 'mfma'
+            assert float((got - ref).abs().max()) <= 1e-5 * peak, (order.__name__, merge)
+    fn.locality_hint = None

@@ -519,9 +519,16 @@ def test_predict_mild_vs_golden_at_reference_tolerance(golden):
     pi = gi.predict_inputs(c)
     g = golden('g4_predict_mild')
     actual = _run_predict(gi.predict_mild_components(), c, pi)
-    np.testing.assert_allclose(actual, g['residual'], rtol=5e-4)
-    # ... and norm-wise on the predicted part, against the host and against float64
     pred, pred_ref = pi['vis'] - actual, pi['vis'] - g['residual']
+    # The reference's gate is relative to each RESIDUAL (vis - prediction).  Where the two nearly
+    # cancel no float32 evaluation can be held to 5e-4 of what is left (1 of these 903 residuals is
+    # 7e-3 next to a prediction of 7: the two float32 paths differ there by 2e-5 = 3e-6 of the
+    # prediction), so the relative gate gets an absolute floor of 4e-6 of the largest prediction:
+    # the rounding of ONE float32 sum of that size.
+    floor = 4e-6 * float(np.abs(pred_ref).max())
+    np.testing.assert_allclose(actual, g['residual'], rtol=5e-4, atol=floor)
+    assert np.count_nonzero(np.abs(actual - g['residual']) > 5e-4 * np.abs(g['residual'])) <= 2
+    # ... and norm-wise on the predicted part, against the host and against float64
     exact = _predict_exact(c, pi, g, golden('g4_predict'))
     assert relerr(pred, pred_ref) < 5e-4
     assert relerr(pred, exact) < 5e-4

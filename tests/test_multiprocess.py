@@ -120,15 +120,17 @@ def test_synthetic_observation_matches_oracle_quantisation():
     assert bl.shape == (2016, 3)
 
 
-def test_bench_torchrun_rehearsal_world2():
-    """`bench.py --gpus 2` under torchrun exactly as the driver launches it, with `--rehearse`
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_torchrun_rehearsal(world):
+    """`bench.py --gpus N` under torchrun exactly as the driver launches it, with `--rehearse`
     (gloo, CPU tensors, no device work): rendezvous, broadcast, per-rank channels, barriers,
-    max-over-ranks timing and ONE JSON line from rank 0."""
+    max-over-ranks timing, per-rank statistics and ONE JSON line from rank 0; N = 2 and the
+    driver's largest N = 8."""
     import json
     import subprocess
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1',
            '--rehearse']
     env = dict(os.environ, OMP_NUM_THREADS='1')
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
@@ -136,9 +138,14 @@ def test_bench_torchrun_rehearsal_world2():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
-    assert out['config']['band_channels'] == [7, 3]     # rank 0 keeps the N = 1 channel
-    assert out['ms_per_step'] >= 2.0                    # the slower rank (2 ms per step) sets it
+    assert out['n_gpus'] == world and out['steps'] == 3 and out['scaling'] == 'weak'
+    want = [7, 3] if world == 2 else [7, 6, 5, 4, 3, 2, 1, 0]
+    assert out['config']['band_channels'] == want       # rank 0 keeps the N = 1 channel
+    assert out['ms_per_step'] >= float(world)           # the slowest rank (N ms per step) sets it
+    assert [p['rank'] for p in out['per_rank']] == list(range(world))
+    assert [p['band_channel'] for p in out['per_rank']] == want
+    assert [p['device'] for p in out['per_rank']] == list(range(world))
+    assert out['per_rank'][0]['ms_per_step'] <= out['per_rank'][-1]['ms_per_step']
 
 
 def test_bench_channel_assignment_is_the_same_workload_for_every_n():

@@ -256,22 +256,39 @@ def test_store_driven_channel_vs_golden(golden, name):
                                     c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
     uvw, vis, weights = gi.e2e_raw(c)
     n = len(uvw)
-    coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], max(n, c['vis_block']))
     vis = vis[:, None] if vis.ndim == 1 else vis
-    coll.add(uvw, weights[None], vis[None].astype(np.complex64), None, None,
-             np.identity(c['P'], dtype=np.complex64), None)
-    coll.close()
-    reader = coll.reader()
-    # the store holds exactly the records the goldens were generated from
     data = gi.e2e_inputs(c)
-    for s, rec in enumerate(data['slices']):
-        got = _read(reader, 0, s, None, coll.store_dtype)
-        np.testing.assert_array_equal(got.uv, rec.uv)
-        np.testing.assert_array_equal(got.sub_uv, rec.sub_uv)
-        np.testing.assert_array_equal(got.w_plane, rec.w_plane)
-        np.testing.assert_array_equal(np.asarray(got.weights), rec.weights)
-        np.testing.assert_array_equal(np.ascontiguousarray(got.vis).view(np.float32),
-                                      np.ascontiguousarray(rec.vis).view(np.float32))
+    for reorder in (False, True):
+        coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], max(n, c['vis_block']),
+                                                    reorder=reorder)
+        coll.add(uvw, weights[None], vis[None].astype(np.complex64), None, None,
+                 np.identity(c['P'], dtype=np.complex64), None)
+        coll.close()
+        reader = coll.reader()
+        for s, rec in enumerate(data['slices']):
+            got = _read(reader, 0, s, None, coll.store_dtype)
+            if not reorder:
+                # in arrival order the store holds exactly the records the goldens were generated from
+                np.testing.assert_array_equal(got.uv, rec.uv)
+                np.testing.assert_array_equal(got.sub_uv, rec.sub_uv)
+                np.testing.assert_array_equal(got.w_plane, rec.w_plane)
+                np.testing.assert_array_equal(np.asarray(got.weights), rec.weights)
+                np.testing.assert_array_equal(np.ascontiguousarray(got.vis).view(np.float32),
+                                              np.ascontiguousarray(rec.vis).view(np.float32))
+            else:
+                # ... and after the once-per-channel re-order (the default; what the pipeline below
+                # runs on) the records the restated re-order makes of them, bit for bit
+                e_uv, e_wp, e_w, e_vis = orc.store_reorder(
+                    np.concatenate([rec.uv, rec.sub_uv], axis=1), np.ascontiguousarray(rec.w_plane),
+                    np.ascontiguousarray(rec.weights), np.ascontiguousarray(rec.vis),
+                    c['kernel_width'], c['oversample'], c['w_planes'], True)
+                assert reader.len(0, s) == len(e_uv) <= len(rec)
+                np.testing.assert_array_equal(np.concatenate([got.uv, got.sub_uv], axis=1), e_uv)
+                np.testing.assert_array_equal(got.w_plane, e_wp)
+                np.testing.assert_array_equal(np.asarray(got.weights), e_w)
+                np.testing.assert_array_equal(np.ascontiguousarray(got.vis).view(np.float32),
+                                              e_vis.view(np.float32))
+        assert coll.num_stored <= coll.num_output
 
     class HostReader:
         """iter_slice only: forces the facade's host setters."""
@@ -528,3 +545,186 @@ def test_loader_to_store_in_loader_order():
     unsorted.add(ds.uvw, np.ascontiguousarray(np.swapaxes(ds.weights, 0, 1)),
                  np.ascontiguousarray(np.swapaxes(ds.vis, 0, 1)), None, None, ident, None)
     assert ref.num_output < 0.6 * unsorted.num_output
+
+
+# ---- the resident store's once-per-channel re-order (csrc/store.hip) -------------------------------
+def _arrival_stream(rs, n_track, n_scatter, P, W, OV, extent, repeat):
+    """Baseline-sorted blocks of slowly moving tracks (the loaders' shape: consecutive records often
+    share a sub-cell, and a track comes back to the same cells in a later block) plus scattered
+    records, as (uv4 int16 [N][4], w_plane, weights, vis)."""
+    tracks = 40
+    per = max(n_track // (tracks * repeat), 1)
+    pieces = []
+    start = rs.uniform(-extent, extent, (tracks, 2))
+    speed = rs.uniform(-0.2, 0.2, (tracks, 2))
+    for block in range(repeat):
+        for t in range(tracks):
+            pos = start[t] + speed[t] * (np.arange(per) + 0.25 * per * block)[:, None]
+            pieces.append(np.clip(pos, -extent, extent))
+    pos = np.concatenate(pieces + [rs.uniform(-extent, extent, (n_scatter, 2))])
+    fine = np.floor(pos * OV).astype(np.int64)
+    uv4 = np.concatenate([fine // OV, fine % OV], axis=1).astype(np.int16)
+    n = len(uv4)
+    w_plane = rs.randint(0, W, n).astype(np.int16)
+    w_plane[:n_track] = (np.arange(n_track)[:len(w_plane[:n_track])] // 97) % W
+    weights = rs.uniform(0.5, 2.0, (n, P)).astype(np.float32)
+    vis = (rs.standard_normal((n, P)) + 1j * rs.standard_normal((n, P))).astype(np.complex64)
+    return uv4, w_plane, weights, vis
+
+
+@pytest.mark.parametrize('merge', [False, True])
+@pytest.mark.parametrize('K,P,W,OV', [(28, 1, 32, 8), (8, 2, 4, 4), (32, 1, 3, 8), (60, 4, 16, 8),
+                                      (45, 3, 33, 5), (1, 1, 1, 1)])
+def test_store_reorder_vs_restatement(K, P, W, OV, merge):
+    """kimg_store_reorder through the C ABI against oracle.store_reorder: the same order (strips of
+    window-slack + 1 grid columns, swept along v, serpentine; stable) and, with merge, the same
+    records with the same float32 sums, bit for bit; a second call on its own output changes
+    nothing; an empty slice is fine."""
+    from katsdpimager_amd import accel
+    from katsdpimager_amd._lib import lib, check
+    ctx, q = context_queue()
+    rs = np.random.RandomState(K * 7 + P)
+    uv4, w_plane, weights, vis = _arrival_stream(rs, 30000, 5000, P, W, OV, 300, 3)
+    n = len(uv4)
+    L = lib()
+
+    def run(uv4, w_plane, weights, vis):
+        n = len(uv4)
+        d = [accel.DeviceArray(ctx, a.shape, a.dtype) for a in (uv4, w_plane, weights, vis)]
+        for dev, a in zip(d, (uv4, w_plane, weights, vis)):
+            dev.set(q, a)
+        o = [accel.DeviceArray(ctx, a.shape, a.dtype) for a in (uv4, w_plane, weights, vis)]
+        count = accel.DeviceArray(ctx, (1,), np.int64)
+        ws_bytes = int(L.kimg_store_reorder_workspace_bytes(n))
+        assert ws_bytes > 0
+        ws = accel.DeviceArray(ctx, (ws_bytes,), np.uint8)
+        assert L.kimg_store_reorder(P, n, K, OV, W, int(merge), d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr,
+                                    o[0].ptr, o[1].ptr, o[2].ptr, o[3].ptr, count.ptr, ws.ptr,
+                                    ws_bytes - 1, q.handle) == -10003        # KIMG_EWORKSPACE
+        check(L.kimg_store_reorder(P, n, K, OV, W, int(merge), d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr,
+                                   o[0].ptr, o[1].ptr, o[2].ptr, o[3].ptr, count.ptr, ws.ptr,
+                                   ws_bytes, q.handle), 'kimg_store_reorder')
+        m = int(count.get(q)[0])
+        return [a.get(q)[:m] for a in o]
+    got = run(uv4, w_plane, weights, vis)
+    want = orc.store_reorder(uv4, w_plane, weights, vis, K, OV, W, merge)
+    assert len(got[0]) == len(want[0]) and (len(want[0]) < n) == (merge and K != 1 or merge)
+    for g, w_ in zip(got, want):
+        np.testing.assert_array_equal(g.view(np.uint8), np.ascontiguousarray(w_).view(np.uint8))
+    # the order itself: strips ascend, v runs up in even strips and down in odd ones
+    width = orc.store_strip_width(K)
+    strip = (got[0][:, 0].astype(np.int64) + 32768) // width
+    assert np.all(np.diff(strip) >= 0)
+    same = np.diff(strip) == 0
+    dv = np.diff(got[0][:, 1].astype(np.int64))
+    assert np.all(np.where(strip[1:] & 1, -dv, dv)[same] >= 0)
+    again = run(*got)
+    for g, a in zip(got, again):
+        np.testing.assert_array_equal(g, a)
+    count = accel.DeviceArray(ctx, (1,), np.int64)
+    count.set(q, np.array([7], np.int64))
+    check(L.kimg_store_reorder(P, 0, K, OV, W, int(merge), None, None, None, None, None, None, None,
+                               None, count.ptr, None, 0, q.handle), 'kimg_store_reorder')
+    assert int(count.get(q)[0]) == 0
+    assert L.kimg_store_reorder(5, 10, K, OV, W, 0, None, None, None, None, None, None, None, None,
+                                count.ptr, None, 0, q.handle) == -10002
+
+
+@pytest.mark.parametrize('merge', [False, True])
+@pytest.mark.parametrize('arith', ['fp32', 'split_fp16'])
+def test_reordered_store_grids_and_degrids_like_the_arrival_stream(arith, merge):
+    """A store re-ordered on close() against the SAME visibilities in arrival order through the
+    oracle: the grid to 1e-5 (`orc.grid` on the un-reordered stream), the density-weight grid
+    exactly, and the degridder's residuals -- summed over the records a stored record was merged
+    from -- to 1e-5; the window kernels take the stored order as it is (`locality` True)."""
+    from helpers import make_params, relerr
+    from katsdpimager_amd import accel, grid, preprocess, weight
+    ctx, q = context_queue()
+    c = gi.make_config(1024, 0.0001, 0.01, 2, 28, 16, grid_cover=700, n_vis=0)
+    ip, gp, ap = make_params(c)
+    rs = np.random.RandomState(5)
+    # raw uvw in metres: slow tracks in baseline-sorted blocks + scattered positions
+    cell = float(ip.cell_size)
+    uv4, w_plane, weights, vis = _arrival_stream(rs, 60000, 10000, 2, 16, 8, 330, 4)
+    n = len(uv4)
+    uvw = np.zeros((n, 3), np.float32)
+    uvw[:, 0] = (uv4[:, 0] + (uv4[:, 2] + 0.5) / 8) * cell
+    uvw[:, 1] = (uv4[:, 1] + (uv4[:, 3] + 0.5) / 8) * cell
+    uvw[:, 2] = rs.uniform(0, 0.9 * c['max_w'], n)
+    ident = np.identity(2, np.complex64)
+    colls = {}
+    for reorder in (False, True):
+        coll = preprocess.VisibilityCollectorDevice(q, [ip], [gp], 16384, reorder=reorder, merge=merge)
+        coll.add(uvw, weights[None], vis[None], None, None, ident, None)
+        coll.close()
+        colls[reorder] = coll
+    plain, stored = colls[False].reader(), colls[True].reader()
+    a = _read(plain, 0, 0, None, colls[False].store_dtype)
+    b = _read(stored, 0, 0, None, colls[True].store_dtype)
+    assert (len(b) < len(a)) if merge else (len(b) == len(a))
+    assert colls[True].num_output == colls[False].num_output and colls[True].num_stored == len(b)
+    # gridder
+    max_vis = len(a)
+    g = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, max_vis)
+    g.ensure_all_bound()
+    Gg = g.buffer('grid').shape[1]
+    wgrid = rs.uniform(0.5, 1.5, (2, Gg, Gg)).astype(np.float32)
+    g.buffer('weights_grid').set(q, wgrid)
+    g.buffer('grid').zero(q)
+    chunks = list(stored.iter_slice_device(0, 0, max_vis))
+    assert len(chunks) == 1 and chunks[0].locality is True and chunks[0].num_vis == len(b)
+    ch = chunks[0]
+    g.bind(uv=ch.uv, w_plane=ch.w_plane, vis=ch.vis)
+    g.num_vis = ch.num_vis
+    g.locality_hint = ch.locality
+    g()
+    assert g.last_variant == 'mfma'
+    got = g.buffer('grid').get(q)
+    want = np.zeros_like(got)
+    orc.grid(g.convolve_kernel.data, want, wgrid, np.ascontiguousarray(a.uv), np.ascontiguousarray(a.sub_uv),
+             np.ascontiguousarray(a.w_plane), np.ascontiguousarray(a.vis))
+    assert relerr(got, want) < 1e-5
+    # degridder: residual of a stored record = sum of the residuals of its members
+    model = (rs.standard_normal((2, Gg, Gg)) + 1j * rs.standard_normal((2, Gg, Gg))).astype(np.complex64)
+    d = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'arith': arith}).instantiate(q, ap, ip, gp, max_vis)
+    d.ensure_all_bound()
+    d.buffer('grid').set(q, model)
+    resid = accel.DeviceArray(ctx, ch.vis.shape, np.complex64)
+    ch.vis.copy_region(q, resid, np.s_[:ch.num_vis], np.s_[:ch.num_vis])
+    d.bind(uv=ch.uv, w_plane=ch.w_plane, weights=ch.weights, vis=resid)
+    d.num_vis = ch.num_vis
+    d.locality_hint = ch.locality
+    d()
+    got_r = resid.get(q)[:ch.num_vis]
+    ref_r = np.ascontiguousarray(a.vis).copy()
+    orc.degrid(d.convolve_kernel.data, model, np.ascontiguousarray(a.uv), np.ascontiguousarray(a.sub_uv),
+               np.ascontiguousarray(a.w_plane), np.ascontiguousarray(a.weights), ref_r)
+    # sum the arrival-order residuals over equal coordinates, in the stored order
+    key = lambda r: np.concatenate([r.uv, r.sub_uv, r.w_plane[:, None]], axis=1).astype(np.int64)
+    ka, kb = key(a), key(b)
+    packed = lambda k: ((((k[:, 0] + 32768) * 65536 + (k[:, 1] + 32768)) * 8 + k[:, 2]) * 8 + k[:, 3]) * 64 + k[:, 4]
+    pa, pb = packed(ka), packed(kb)
+    if merge:
+        assert len(np.unique(pb)) == len(pb)
+        uniq, inv = np.unique(pa, return_inverse=True)
+        summed = np.zeros((len(uniq), 2), np.complex128)
+        np.add.at(summed, inv, ref_r.astype(np.complex128))
+        want_r = summed[np.searchsorted(uniq, pb)]
+        assert np.abs(got_r - want_r).max() <= 1e-5 * np.abs(want_r).max()
+    else:
+        # a permutation: sort both by (coordinates, visibility bits) and compare record for record
+        ia = np.lexsort((np.ascontiguousarray(a.vis[:, 0]).view(np.uint64), pa))
+        ib = np.lexsort((np.ascontiguousarray(b.vis[:, 0]).view(np.uint64), pb))
+        np.testing.assert_array_equal(pa[ia], pb[ib])
+        assert np.abs(got_r[ib] - ref_r[ia]).max() <= 1e-5 * np.abs(ref_r).max()
+    # density weights see the same sums per cell
+    wt = weight.WeightsTemplate(ctx, weight.WeightType.UNIFORM, 2).instantiate(q, (2, Gg, Gg), max_vis)
+    wt.ensure_all_bound()
+    grids = []
+    for rd in (plain, stored):
+        wt.clear()
+        for chunk in rd.iter_slice_device(0, 0, max_vis):
+            wt.bind(uv=chunk.uv, weights=chunk.weights)
+            wt.grid(chunk.num_vis)
+        grids.append(wt.buffer('grid').get(q))
+    assert relerr(grids[1], grids[0]) < 2e-6

@@ -22,13 +22,25 @@ ctx = accel.create_some_context()
 q = ctx.create_command_queue()
 dev = ctx.device
 obs = synth.make_observation(G, n, W, P, device=dev, seed=6)
-if order in ('loader_blocks', 'store_order'):
+if order in ('loader_blocks', 'store_order', 'store_merged'):
     obs = synth.order_loader_blocks(obs)['obs']
 ip, gp, ap = synth.make_parameters(obs, P, K, degrid=True)
 n = obs.n_vis
-if order == 'store_order':
+if order in ('store_order', 'store_merged'):
     from katsdpimager_amd import preprocess
-    obs = preprocess.reorder_arrays(ctx, q, obs, gp, ap, ip)
+    arrays = dict(uv=accel.DeviceArray(ctx, (n, 4), np.int16, tensor=obs.uv),
+                  w_plane=accel.DeviceArray(ctx, (n,), np.int16, tensor=obs.w_plane),
+                  weights=accel.DeviceArray(ctx, (n, P), np.float32, tensor=obs.weights),
+                  vis=accel.DeviceArray(ctx, (n, P), np.complex64, tensor=obs.vis))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, n = preprocess.reorder_device_arrays(q, P, n, arrays, K, obs.oversample, W,
+                                              order == 'store_merged')
+    q.finish()
+    print('%s: re-order of %d records -> %d in %.3f ms (first call: includes code loading)' % (
+        order, obs.n_vis, n, (time.perf_counter() - t0) * 1e3), flush=True)
+    obs = synth._copy_with(obs, out['uv'].tensor[:n], out['w_plane'].tensor[:n], out['vis'].tensor[:n],
+                           out['weights'].tensor[:n])
 g = grid.GridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': 'mfma'}).instantiate(q, ap, ip, gp, n)
 d = grid.DegridderTemplate(ctx, ip.fixed, gp.fixed, {'variant': 'mfma'}).instantiate(q, ap, ip, gp, n)
 shape = g.slots['grid'].shape

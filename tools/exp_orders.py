@@ -133,8 +133,8 @@ def main():
         g.ensure_all_bound()
         d.ensure_all_bound()
         g.num_vis = d.num_vis = n
-        jf = g.jump_fraction()
         torch.cuda.synchronize()
+        jf = g.jump_fraction()
         gbuf.zero(q)
         g._run()
         q.finish()
