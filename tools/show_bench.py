@@ -21,3 +21,13 @@ if 'major_cycle_loop' in d:
     print('   major_cycle_loop', d['major_cycle_loop'])
 if 'cpu_baseline' in d:
     print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('all_cores'))
+    print('   cpu', {k: v for k, v in d['cpu_baseline'].items() if k.endswith(('_per_s', '_ms'))})
+po = d.get('production_order')
+if po:
+    print('production order:', po['stream'])
+    for k in ('as_delivered', 'store_order', 'store_merged'):
+        b = po[k]
+        print('   %-13s %8d records  grid %.3f ms %8.1f Mrec/s (frac %.3f)  degrid %.3f ms %8.1f Mrec/s%s' % (
+            k, b['records'], b['grid_ms'], b['records_per_s_M'], b['roofline']['frac'], b['degrid_ms'],
+            b['degrid_records_per_s_M'],
+            '  reorder %.3f ms' % b['reorder_ms_once_per_channel'] if 'reorder_ms_once_per_channel' in b else ''))
