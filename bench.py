@@ -528,6 +528,35 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
         'bound': 'latency', 'budget_us_one_launch_cycle': 5.85,
     }
     out['clean']['small_patch_us_per_cycle'] = round(1e6 / out['clean']['small_patch_cycles_per_s'], 2)
+    # several channels per launch (kimg_clean_cycles_batch: cycle i of C channels in ONE launch, the
+    # kernel boundary is paid once): aggregate minor cycles per second over C channels of a band,
+    # each with its own dirty image (the same sky at another amplitude and noise), same PSF patch
+    extra = []
+    for c in range(7):
+        e = clean.CleanTemplate(ctx, cp, np.float32, P).instantiate(q, ip)
+        e.ensure_all_bound()
+        e.buffer('psf').set(q, psf)
+        extra.append(e)
+    skies = [sky] + [(sky * (1.0 + 0.07 * (c + 1))
+                      + (0.002 * np.random.RandomState(50 + c).standard_normal(sky.shape))).astype(np.float32)
+                     for c in range(7)]
+
+    def batch_rate(C):
+        ops = [cl] + extra[:C - 1]
+        for op, sk in zip(ops, skies):
+            op.buffer('dirty').set(q, sk)
+            op.buffer('model').zero(q)
+            op.reset()
+        q.finish()
+        t0 = time.perf_counter()
+        runs = clean.run_cycles_batch(ops, [small] * C, [0.0] * C, [args.clean_cycles] * C)
+        q.finish()
+        return sum(len(r) for r in runs) / (time.perf_counter() - t0)
+    batch_rate(2)                # first call: graph capture
+    for C in (2, 4, 8):
+        batch_rate(C)
+        out['clean']['batched_%d_channels_cycles_per_s' % C] = round(batch_rate(C), 1)
+    del extra, skies
     # bytes a cycle moves: 12 P patch^2 + tile refresh; only meaningful for big patches
     cyc_bytes = 12 * P * patch[1] * patch[2] + 4 * P * 1024 * ((patch[1] + 31) // 32 + 1) * ((patch[2] + 31) // 32 + 1)
     out['clean']['large_patch_GBps'] = round(cyc_bytes * large / 1e9, 1)
@@ -1030,6 +1059,8 @@ def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm):
         res = frontend.process_channels(jobs, workers=workers)
         torch.cuda.synchronize()
         out['four_channels_%d_in_flight_ms' % workers] = round((time.perf_counter() - t0) * 1e3, 2)
+        out['four_channels_%d_in_flight_clean_batches' % workers] = [
+            list(b) for b in frontend.process_channel_stream.last_batches]
     out['four_channels_minor_cycles'] = [int(r['minor']) for r in res]
     return out
 

@@ -408,6 +408,36 @@ int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t po
                       float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
                       int max_cycles, int form, void *state, float *log, void *stream);
 
+/* The same loop for several channels of a band at once: cycle i of every channel runs in ONE
+ * launch (the reference loops over channels serially, frontend.py:749-767, and within a channel
+ * over cycles with a host round trip each, clean.py:848-891).  A minor cycle is a latency chain
+ * that occupies a fraction of the device; the channels' images have the same shape, so their
+ * cycles share the kernel boundary.  Each channel keeps its own images, PSF and patch size, tile
+ * arrays, state / log buffers (as for kimg_clean_cycles), threshold and cycle limit, and stops on
+ * its own; the results per channel are bit-identical to kimg_clean_cycles on that channel alone.
+ *   channels_host  HOST array of num_channels (<= KIMG_CLEAN_BATCH_MAX) descriptors; the device
+ *                  pointers in them follow the conventions of kimg_clean_cycles
+ *   Every channel's patch must allow the one-launch-per-cycle form (at most 32 x 32 lattice
+ *   blocks and (patch_width / 32 + 2) * (patch_height / 32 + 3) <= 256): KIMG_EUNSUPPORTED
+ *   otherwise, and the caller runs the channels one by one. */
+#define KIMG_CLEAN_BATCH_MAX 8
+typedef struct kimg_clean_channel {
+    float *dirty, *model;
+    const float *psf;
+    float *tile_max;
+    int32_t *tile_pos;
+    void *state;
+    float *log;
+    int32_t patch_width, patch_height;
+    float threshold;
+    int32_t max_cycles;
+} kimg_clean_channel;
+int kimg_clean_cycles_batch(const kimg_clean_channel *channels_host, int num_channels,
+                            int64_t row_stride, int64_t pol_stride, int width, int height,
+                            int num_polarizations, int64_t psf_row_stride, int64_t psf_pol_stride,
+                            int psf_width, int psf_height, int border, int mode, float loop_gain,
+                            int tiles_x, int tiles_y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

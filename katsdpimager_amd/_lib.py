@@ -73,7 +73,20 @@ PROTOTYPES = {
     'kimg_clean_state_bytes': (c_size_t, [I, I, I]),
     'kimg_clean_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, F,
                                   P, P, I, I, I, I, P, P, P]),
+    'kimg_clean_cycles_batch': (c_int, [P, I, L, L, I, I, I, L, L, I, I, I, I, F, I, I, P]),
 }
+
+
+class CleanChannel(ctypes.Structure):
+    """``kimg_clean_channel`` of include/kimg.h (one channel of kimg_clean_cycles_batch)."""
+    _fields_ = [('dirty', c_void_p), ('model', c_void_p), ('psf', c_void_p),
+                ('tile_max', c_void_p), ('tile_pos', c_void_p), ('state', c_void_p),
+                ('log', c_void_p), ('patch_width', ctypes.c_int32),
+                ('patch_height', ctypes.c_int32), ('threshold', c_float),
+                ('max_cycles', ctypes.c_int32)]
+
+
+CLEAN_BATCH_MAX = 8     # KIMG_CLEAN_BATCH_MAX
 
 
 class KimgLibraryError(RuntimeError):

@@ -434,7 +434,7 @@ constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to
 // A tile record rewritten by one cycle and consumed by the next, stored at the slot of the thread
 // that owns the tile in the peak search (see cycle_fused_kernel).  `tag` = 2 + the cycle that wrote
 // it: a record is live for exactly the cycle after (0 = never written; the table is cleared per call).
-struct delta_t {
+struct __attribute__((aligned(16))) delta_t {
     int tag;
     int tile;
     float value;
@@ -453,12 +453,32 @@ struct fused_state {
 // value -1 = none.  Two, because when one owned tile gets a new value the owner's new BEST is
 // then known without looking at the other tiles: it is the better of the new record and of the
 // best of the others, which is the first of the two that is not the rewritten tile.
-struct owner_best_t {
+// (16-byte aligned and moved as ONE 16-byte access: the keeper workgroup of a launch rewrites an
+// owner's record while lattice workgroups of the same launch read it; either version is fine for
+// them, a mix of the two would not be.)
+struct __attribute__((aligned(16))) owner_best_t {
     float v1;
     int t1;
     float v2;
     int t2;
 };
+static_assert(sizeof(owner_best_t) == 16, "one 16-byte access");
+
+__device__ inline owner_best_t load_owner_best(const owner_best_t *p)
+{
+    const int4 w = *reinterpret_cast<const int4 *>(p);
+    owner_best_t b;
+    b.v1 = __int_as_float(w.x);
+    b.t1 = w.y;
+    b.v2 = __int_as_float(w.z);
+    b.t2 = w.w;
+    return b;
+}
+
+__device__ inline void store_owner_best(owner_best_t *p, const owner_best_t &b)
+{
+    *reinterpret_cast<int4 *>(p) = make_int4(__float_as_int(b.v1), b.t1, __float_as_int(b.v2), b.t2);
+}
 
 struct fused_scratch {
     fused_state st[2];
@@ -560,13 +580,16 @@ __device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *t
 // The kernel is one chain of dependent steps executed once, so what counts is the latency of
 // every step on the chain (global round trips ~0.8 us, LDS round trips and barriers ~0.1 us),
 // not throughput: reductions use DPP and one LDS exchange, state words travel as one 16-byte load.
+// The cycle of one channel, executed by the workgroup that serves lattice block (blk_x, blk_y) of
+// its PSF patch, or by the channel's bookkeeping workgroup (`keeper`).  Two kernels call it: one
+// channel per launch (cycle_fused_kernel) and several channels per launch (cycle_fused_batch_kernel).
 template <int MODE>
-__global__ __launch_bounds__(1024) void cycle_fused_kernel(
+__device__ __attribute__((always_inline)) inline void fused_cycle(
     float *dirty, float *model, int64_t row_stride, int64_t pol_stride, int width, int height,
     int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
     int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
     int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain,
-    fused_scratch *scratch, int parity, float *log)
+    fused_scratch *scratch, int parity, float *log, int blk_x, int blk_y, bool keeper)
 {
     __shared__ key_t s_keys[16];
     __shared__ int s_pos[2];
@@ -577,13 +600,8 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     delta_t *dout = scratch->deltas[parity ^ 1];
     float *tile_pix = reinterpret_cast<float *>(scratch + 1);
     const int tid = threadIdx.x;
-    // The last row of the grid holds the one workgroup that does the bookkeeping instead of a
-    // lattice block (its other members have nothing to do).
-    const bool keeper = blockIdx.y == gridDim.y - 1;
-    if (keeper && blockIdx.x != 0)
-        return;
 #ifdef KIMG_CLEAN_STAMPS
-    const int bid = (!keeper && blockIdx.x == 0 && blockIdx.y == 0) ? 0 : 1;   // stamps: one lattice block
+    const int bid = (!keeper && blk_x == 0 && blk_y == 0) ? 0 : 1;   // stamps: one lattice block
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
@@ -597,7 +615,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     const int count = st.x, done = st.y, limit = st.z;
     const float threshold = __int_as_float(st.w);
     const delta_t d = din[tid];
-    const owner_best_t ob = scratch->owner_best[tid];
+    const owner_best_t ob = load_owner_best(&scratch->owner_best[tid]);
     if (done) {
         if (keeper && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, st.w);
@@ -625,7 +643,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
         const owner_best_t nb = walk.best(tile_max, ptile, d.value);
         if (live) {
             apply_delta(d, tile_max, tile_pos, tile_pix);
-            scratch->owner_best[tid] = nb;
+            store_owner_best(&scratch->owner_best[tid], nb);
         }
     }
     // The record of this thread's candidate is fetched now, before it is known whether the
@@ -692,7 +710,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
     const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
     const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
-    const int tx = bx0 + (int) blockIdx.x, ty = by0 + (int) blockIdx.y;
+    const int tx = bx0 + blk_x, ty = by0 + blk_y;
     const int ox = tx * TILE + border, oy = ty * TILE + border;
     const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;
     const bool is_tile = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;
@@ -761,6 +779,73 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
         }
         dout[(ty & 31) * 32 + (tx & 31)] = o;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_fused_kernel(
+    float *dirty, float *model, int64_t row_stride, int64_t pol_stride, int width, int height,
+    int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+    int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
+    int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain,
+    fused_scratch *scratch, int parity, float *log)
+{
+    // The last row of the grid holds the one workgroup that does the bookkeeping instead of a
+    // lattice block (its other members have nothing to do).
+    const bool keeper = blockIdx.y == gridDim.y - 1;
+    if (keeper && blockIdx.x != 0)
+        return;
+    fused_cycle<MODE>(dirty, model, row_stride, pol_stride, width, height, P, psf, psf_row_stride,
+                      psf_pol_stride, psf_w, psf_h, patch_w, patch_h, border, tile_max, tile_pos,
+                      tiles_x, tiles_y, loop_gain, scratch, parity, log, (int) blockIdx.x,
+                      (int) blockIdx.y, keeper);
+}
+
+// ---- several channels per launch -------------------------------------------------------------
+// A minor cycle is a latency chain (kernel boundary 2.1 us + cold first load 1 us + ~3 us of
+// dependent work) that occupies ~30 of the 256 CUs.  Channels of a band are independent and have
+// images of the same shape, so cycle i of up to KIMG_CLEAN_BATCH_MAX channels runs as ONE launch:
+// blockIdx.z is the channel, whose pointers, patch size and (through its own state words)
+// threshold, cycle limit and stop flag are its own; a finished channel's workgroups return after
+// their first load.  The boundary and the cold load are paid once for all of them.  The table of
+// channels travels in the kernel arguments (scalar loads with a uniform index: no extra round trip).
+struct batch_channel {
+    float *dirty, *model;
+    const float *psf;
+    float *tile_max;
+    int32_t *tile_pos;
+    fused_scratch *scratch;
+    float *log;
+    int patch_w, patch_h;
+};
+
+struct batch_table {
+    batch_channel ch[KIMG_CLEAN_BATCH_MAX];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void cycle_fused_batch_kernel(
+    batch_table tab, int64_t row_stride, int64_t pol_stride, int width, int height, int P,
+    int64_t psf_row_stride, int64_t psf_pol_stride, int psf_w, int psf_h, int border, int tiles_x,
+    int tiles_y, float loop_gain, int parity)
+{
+    // grid = (largest number of lattice blocks of any channel + 1, 1, channels): block 0 of a
+    // channel keeps its books, blocks 1 .. bx * by serve its lattice row by row; no workgroup is
+    // launched only to find that it has nothing to do unless the channels' patches differ in size
+    // (8 channels with the 6 x 5 lattice blocks of a 133 x 111 patch are 248 workgroups: one per CU)
+    const batch_channel &ch = tab.ch[blockIdx.z];
+    const int bx = (ch.patch_w + TILE - 1) / TILE + 1, by = (ch.patch_h + TILE - 1) / TILE + 1;
+    const bool keeper = blockIdx.x == 0;
+    int blk_x = (int) blockIdx.x - 1, blk_y = 0;
+    if (blk_x >= bx * by)
+        return;
+    while (blk_x >= bx) {           // (uniform; at most 31 rounds, typically < 6)
+        blk_x -= bx;
+        blk_y++;
+    }
+    fused_cycle<MODE>(ch.dirty, ch.model, row_stride, pol_stride, width, height, P, ch.psf,
+                      psf_row_stride, psf_pol_stride, psf_w, psf_h, ch.patch_w, ch.patch_h, border,
+                      ch.tile_max, ch.tile_pos, tiles_x, tiles_y, loop_gain, ch.scratch, parity,
+                      ch.log, blk_x, blk_y, keeper);
 }
 
 // ---- the whole minor-cycle loop in ONE launch ----------------------------------------------
@@ -1855,11 +1940,29 @@ struct cycle_args {
     clean_state *state;
     float *log;
     int fused;              // one launch per cycle (state is then a fused_scratch)
+    int batch;              // > 0: that many channels per launch, described by `tab` (the fields
+                            // dirty .. log, patch_width / patch_height above are then unused)
+    int batch_blocks;       // largest number of lattice blocks over the batch's channels
+    batch_table tab;
 };
 
 // One minor cycle = two dependent launches (peak + threshold test, then subtract + tile update).
 int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 {
+    if (a.batch > 0) {
+        const dim3 gb(a.batch_blocks + 1, 1, a.batch);          // + the bookkeeping workgroup
+        if (a.mode == KIMG_CLEAN_I)
+            cycle_fused_batch_kernel<KIMG_CLEAN_I><<<gb, 1024, 0, s>>>(
+                a.tab, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf_row_stride,
+                a.psf_pol_stride, a.psf_width, a.psf_height, a.border, a.tiles_x, a.tiles_y,
+                a.loop_gain, index & 1);
+        else
+            cycle_fused_batch_kernel<KIMG_CLEAN_SUMSQ><<<gb, 1024, 0, s>>>(
+                a.tab, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf_row_stride,
+                a.psf_pol_stride, a.psf_width, a.psf_height, a.border, a.tiles_x, a.tiles_y,
+                a.loop_gain, index & 1);
+        return kimg_launch_status();
+    }
     dim3 g(kimg_divup(a.patch_width, TILE) + 1, kimg_divup(a.patch_height, TILE) + 1);
     const int num_tiles = a.tiles_x * a.tiles_y;
     if (a.fused) {
@@ -1906,6 +2009,9 @@ int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 #define KIMG_GRAPH_CYCLES 64
 #endif
 constexpr int GRAPH_CYCLES = KIMG_GRAPH_CYCLES;
+// the one-launch form alternates two state / delta buffers by launch parity and must leave the
+// final state in st[0]: a replay has to be an even number of launches
+static_assert(GRAPH_CYCLES >= 2 && GRAPH_CYCLES % 2 == 0, "KIMG_GRAPH_CYCLES must be even");
 constexpr int GRAPH_CACHE = 32;     // argument sets (channels in flight x patch sizes)
 
 struct graph_entry {
@@ -1915,6 +2021,7 @@ struct graph_entry {
     hipGraphExec_t exec;
     hipEvent_t last_use;    // recorded after the last replay enqueued by a finished call
     bool used;
+    int device;             // the device `last_use` (and the graph) belongs to
 };
 graph_entry graph_cache[GRAPH_CACHE];
 std::mutex graph_mutex;         // channels imaged concurrently share the cache
@@ -1940,25 +2047,39 @@ graph_entry *cycles_graph(const cycle_args &a, hipStream_t s)
             slot = &graph_cache[i];
     if (!slot)
         return nullptr;             // every entry busy: the caller enqueues plain launches
-    hipGraph_t graph;
+    hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return nullptr;
     int rc = 0;
     for (int i = 0; i < GRAPH_CYCLES && rc == 0; i++)
         rc = enqueue_cycle(a, s, i);
-    if (hipStreamEndCapture(s, &graph) != hipSuccess || rc != 0)
+    const hipError_t ended = hipStreamEndCapture(s, &graph);
+    if (ended != hipSuccess || rc != 0) {
+        if (ended == hipSuccess && graph != nullptr)
+            (void) hipGraphDestroy(graph);      // (a launch failed during the capture)
         return nullptr;
+    }
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void) hipGraphDestroy(graph);
     if (e != hipSuccess)
         return nullptr;
-    if (slot->valid)
+    // (imagers on several devices may share this process: an event is recorded on streams of the
+    // device it was created on, so a slot taken over from another device gets a new one)
+    int device = 0;
+    (void) hipGetDevice(&device);
+    if (slot->valid) {
         (void) hipGraphExecDestroy(slot->exec);
-    else if (hipEventCreateWithFlags(&slot->last_use, hipEventDisableTiming) != hipSuccess) {
+        if (slot->device != device) {
+            (void) hipEventDestroy(slot->last_use);
+            slot->valid = false;
+        }
+    }
+    if (!slot->valid && hipEventCreateWithFlags(&slot->last_use, hipEventDisableTiming) != hipSuccess) {
         (void) hipGraphExecDestroy(exec);
         return nullptr;
     }
+    slot->device = device;
     slot->valid = true;
     slot->used = false;
     slot->users = 1;
@@ -2104,6 +2225,106 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     if (fused)
         apply_deltas_kernel<<<1, 1024, 0, s>>>(static_cast<fused_scratch *>(state), tile_max,
                                                tile_pos);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_clean_cycles_batch(const kimg_clean_channel *channels_in, int num_channels,
+                                       int64_t row_stride, int64_t pol_stride, int width,
+                                       int height, int num_polarizations, int64_t psf_row_stride,
+                                       int64_t psf_pol_stride, int psf_width, int psf_height,
+                                       int border, int mode, float loop_gain, int tiles_x,
+                                       int tiles_y, void *stream)
+{
+    KIMG_CHECK_ARG(channels_in && num_channels >= 1 && num_channels <= KIMG_CLEAN_BATCH_MAX);
+    KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && tiles_x > 0 && tiles_y > 0);
+    KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
+    hipStream_t s = (hipStream_t) stream;
+    cycle_args a;
+    memset(&a, 0, sizeof(a));       // padding bytes take part in the cache key comparison
+    int max_cycles = 0;
+    if (kimg_divup(tiles_x, 32) * kimg_divup(tiles_y, 32) > FUSED_MAX_SLOTS)
+        return KIMG_EUNSUPPORTED;
+    // The order of the channels does not matter to the results, but the captured graph is cached
+    // per argument set: channels that meet in another order (threads arriving at a rendezvous)
+    // must find the same graph, so the table is kept sorted by image address.
+    kimg_clean_channel sorted[KIMG_CLEAN_BATCH_MAX];
+    for (int c = 0; c < num_channels; c++) {
+        int at = c;
+        while (at > 0 && sorted[at - 1].dirty > channels_in[c].dirty) {
+            sorted[at] = sorted[at - 1];
+            at--;
+        }
+        sorted[at] = channels_in[c];
+    }
+    const kimg_clean_channel *channels = sorted;
+    for (int c = 0; c < num_channels; c++) {
+        const kimg_clean_channel &ch = channels[c];
+        KIMG_CHECK_ARG(ch.dirty && ch.model && ch.psf && ch.tile_max && ch.tile_pos && ch.state
+                       && ch.log && ch.max_cycles >= 0);
+        KIMG_CHECK_ARG(ch.patch_width > 0 && ch.patch_height > 0 && ch.patch_width <= psf_width
+                       && ch.patch_height <= psf_height);
+        for (int o = 0; o < c; o++)     // channels are cleaned concurrently: no shared buffers
+            KIMG_CHECK_ARG(channels[o].dirty != ch.dirty && channels[o].state != ch.state
+                           && channels[o].tile_max != ch.tile_max && channels[o].log != ch.log);
+        const int bx = kimg_divup(ch.patch_width, TILE) + 1, by = kimg_divup(ch.patch_height, TILE) + 1;
+        if (!(bx * (by + 1) <= FUSED_MAX_BLOCKS && bx <= 32 && by <= 32))
+            return KIMG_EUNSUPPORTED;
+        a.batch_blocks = bx * by > a.batch_blocks ? bx * by : a.batch_blocks;
+        max_cycles = ch.max_cycles > max_cycles ? ch.max_cycles : max_cycles;
+        batch_channel &b = a.tab.ch[c];
+        b.dirty = ch.dirty;
+        b.model = ch.model;
+        b.psf = ch.psf;
+        b.tile_max = ch.tile_max;
+        b.tile_pos = ch.tile_pos;
+        b.scratch = static_cast<fused_scratch *>(ch.state);
+        b.log = ch.log;
+        b.patch_w = ch.patch_width;
+        b.patch_h = ch.patch_height;
+    }
+    a.batch = num_channels;
+    a.row_stride = row_stride; a.pol_stride = pol_stride; a.width = width; a.height = height;
+    a.P = num_polarizations; a.psf_row_stride = psf_row_stride; a.psf_pol_stride = psf_pol_stride;
+    a.psf_width = psf_width; a.psf_height = psf_height; a.border = border; a.mode = mode;
+    a.loop_gain = loop_gain; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.fused = 1;
+    // per channel, as kimg_clean_cycles does for the one-launch form: state, peak pixels of every
+    // tile, every owner's best two tiles
+    for (int c = 0; c < num_channels; c++) {
+        const kimg_clean_channel &ch = channels[c];
+        KIMG_HIP(hipMemsetAsync(ch.state, 0, sizeof(fused_scratch), s));
+        init_state_kernel<<<1, 1, 0, s>>>(static_cast<clean_state *>(ch.state), ch.max_cycles,
+                                          ch.threshold);
+        tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
+            ch.dirty, row_stride, pol_stride, width, height, num_polarizations, ch.tile_pos,
+            tiles_x * tiles_y, static_cast<fused_scratch *>(ch.state));
+        owner_best_kernel<<<1, 1024, 0, s>>>(ch.tile_max, tiles_x, tiles_y,
+                                             static_cast<fused_scratch *>(ch.state));
+    }
+    int rc = kimg_launch_status();
+    if (rc)
+        return rc;
+    int done = 0;
+    if (max_cycles >= GRAPH_CYCLES / 2) {
+        graph_entry *entry = cycles_graph(a, s);
+        if (entry) {
+            hipError_t e = hipSuccess;
+            for (; done < max_cycles && e == hipSuccess; done += GRAPH_CYCLES)
+                e = hipGraphLaunch(entry->exec, s);
+            graph_release(entry, s);
+            if (e != hipSuccess)
+                return -(int) e;
+            done = max_cycles;
+        }
+    }
+    // (an even number of launches: the final state is then in st[0], see kimg_clean_cycles)
+    for (int i = 0; done < max_cycles || (i & 1); done++, i++) {
+        rc = enqueue_cycle(a, s, i);
+        if (rc)
+            return rc;
+    }
+    for (int c = 0; c < num_channels; c++)
+        apply_deltas_kernel<<<1, 1024, 0, s>>>(static_cast<fused_scratch *>(channels[c].state),
+                                               channels[c].tile_max, channels[c].tile_pos);
     return kimg_launch_status();
 }
 

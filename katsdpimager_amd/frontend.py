@@ -78,7 +78,7 @@ def slice_mid_w(image_p, grid_p):
 
 def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type,
                     vis_block, major, degrid, subtract_model=False, batched_clean=True,
-                    fit_beam=False):
+                    fit_beam=False, clean_batcher=None):
     """The loop of frontend.process_channel (frontend.py:497-585) from "Compute imaging
     weights" to the end of the last major cycle.
 
@@ -92,6 +92,8 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
 
     ``batched_clean`` runs the minor cycles of one major cycle with ``Imaging.clean_cycles``
     (no host round trip per cycle); the result is identical to the per-cycle loop.
+    ``clean_batcher`` (:class:`clean.CleanBatcher`, set by :func:`process_channels`) lets those
+    cycles share their launches with the other channels in flight.
     """
     if not any(reader.len(rel_channel, s) for s in range(reader.num_w_slices(rel_channel))):
         return None
@@ -103,16 +105,17 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     mid_w = slice_mid_w(image_p, grid_p)
     with trace.range('make_psf'):
         make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
-    dirty = imager.buffer('dirty')
-    centre = dirty.shape[1] // 2
-    psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
-    dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
-    if np.any(psf_peak == 0):
-        return None
-    scale = np.reciprocal(psf_peak)
-    imager.scale_dirty(scale)
-    imager.dirty_to_psf()
-    psf_patch = imager.psf_patch()
+    with trace.range('psf_patch'):
+        dirty = imager.buffer('dirty')
+        centre = dirty.shape[1] // 2
+        psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
+        dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
+        if np.any(psf_peak == 0):
+            return None
+        scale = np.reciprocal(psf_peak)
+        imager.scale_dirty(scale)
+        imager.dirty_to_psf()
+        psf_patch = imager.psf_patch()
     out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
                psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
                peaks=[], noise=None)
@@ -129,8 +132,9 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
         with trace.range('noise_est'):
             noise = imager.noise_est()
         out['noise'] = noise
-        imager.clean_reset()
-        peak_value = imager.clean_cycle(psf_patch)
+        with trace.range('first_cycle'):
+            imager.clean_reset()
+            peak_value = imager.clean_cycle(psf_patch)
         out['peaks'].append(peak_value)
         peak_power = clean.metric_to_power(clean_p.mode, peak_value)
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
@@ -142,7 +146,11 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
         threshold_metric = clean.power_to_metric(clean_p.mode, threshold)
         if batched_clean:
             with trace.range('clean[%d]' % i):
-                values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1)
+                if clean_batcher is not None:
+                    values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1,
+                                                 batcher=clean_batcher)
+                else:
+                    values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1)
             # the reference counts the cycle that found the peak below threshold too (:579-582)
             out['minor'] += len(values) + (1 if len(values) < clean_p.minor - 1 else 0)
         else:
@@ -152,7 +160,8 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
                 if value is None:
                     break
         if i == major - 1:
-            out['noise'] = imager.noise_est()
+            with trace.range('noise_est'):
+                out['noise'] = imager.noise_est()
     return out
 
 
@@ -194,35 +203,31 @@ def get_totals(queue, image, restoring_beam):
     return [float(x) / beam_area for x in sums.get(queue)]
 
 
-def process_channels(jobs, workers=2):
+def process_channels(jobs, workers=2, batch_clean=True):
     """Image several channels of one GPU concurrently, one host thread and one HIP stream
     (command queue) per channel in flight.
 
     The reference loops over channels serially (frontend.py:749-767).  Within a channel the
     stages are dependent, and the CLEAN minor cycles are a latency-bound chain of small launches
     that leaves most of the device idle; running a second channel's gridding / FFTs next to it on
-    another stream fills those gaps.  ``jobs`` is a list of dicts of :func:`process_channel`
-    keyword arguments (each with its own ``imager``, hence its own command queue; they may share
-    a reader).  Returns the list of results in job order.
+    another stream fills those gaps, and with ``batch_clean`` the minor cycles of the channels in
+    flight share their launches (``clean.CleanBatcher``: cycle i of every channel in ONE launch;
+    results identical).  ``jobs`` is a list of dicts of :func:`process_channel` keyword arguments
+    (each with its own ``imager``, hence its own command queue; they may share a reader).  Returns
+    the list of results in job order.  For more channels than fit in memory at once see
+    :func:`process_channel_stream`.
     """
-    import concurrent.futures
     if workers <= 1 or len(jobs) <= 1:
+        process_channel_stream.last_batches = []
         return [process_channel(**job) for job in jobs]
     queues = {id(job['imager'].command_queue) for job in jobs}
     if len(queues) != len(jobs):
         raise ValueError('concurrent channels need one command queue each')
-    def run(job):
-        # the current HIP device is per host thread and new threads start on device 0: select the
-        # device of the job's command queue before anything is launched on its stream
-        import torch
-        with torch.cuda.device(job['imager'].command_queue.context.device):
-            return process_channel(**job)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-        futures = [pool.submit(run, job) for job in jobs]
-        return [f.result() for f in futures]
+    return process_channel_stream(lambda index: jobs[index], range(len(jobs)), workers=workers,
+                                  batch_clean=batch_clean)
 
 
-def process_channel_stream(make_job, channels, workers=2):
+def process_channel_stream(make_job, channels, workers=2, batch_clean=True):
     """Image ``channels`` (any number) with at most ``workers`` of them in flight AND in memory.
 
     :func:`process_channels` takes ready-made jobs, i.e. one imager per channel; a band of
@@ -231,7 +236,9 @@ def process_channel_stream(make_job, channels, workers=2):
     image it (``make_job(channel)`` or ``make_job(channel, worker)``, see
     ``parallel.image_assigned_channels``) and drops it when the channel is done, so at most
     ``workers`` imagers exist at a time -- or exactly ``workers`` for the whole band when the
-    callback re-uses one imager per ``worker`` index.  Returns the results in ``channels`` order.
+    callback re-uses one imager per ``worker`` index.  With ``batch_clean`` the minor cycles of
+    the channels in flight share their launches (see :func:`process_channels`).  Returns the
+    results in ``channels`` order.
     """
     import inspect
     import queue
@@ -246,29 +253,37 @@ def process_channel_stream(make_job, channels, workers=2):
     todo = queue.Queue()
     for item in enumerate(channels):
         todo.put(item)
+    count = max(1, min(int(workers), len(channels)))
+    batcher = None
+    if batch_clean and count > 1:
+        batcher = clean.CleanBatcher(count)
 
     def work(worker):
-        while not errors:
-            try:
-                index, channel = todo.get_nowait()
-            except queue.Empty:
-                return
-            try:
+        try:
+            while not errors:
+                try:
+                    index, channel = todo.get_nowait()
+                except queue.Empty:
+                    return
                 job = make_job(channel, worker) if takes_worker else make_job(channel)
-                imager = job.get('imager')
+                kwargs = dict(job)          # (the caller's dict is left as it is)
+                if batcher is not None and kwargs.get('batched_clean', True):
+                    kwargs.setdefault('clean_batcher', batcher)
+                imager = kwargs.get('imager')
                 if imager is not None and hasattr(imager, 'command_queue'):
                     # the current HIP device is per host thread (new threads start on device 0)
                     import torch
                     with torch.cuda.device(imager.command_queue.context.device):
-                        results[index] = process_channel(**job)
+                        results[index] = process_channel(**kwargs)
                 else:
-                    results[index] = process_channel(**job)
-                del job, imager
-            except BaseException as exc:        # noqa: B902 -- re-raised in the caller's thread
-                errors.append(exc)
-                return
+                    results[index] = process_channel(**kwargs)
+                del job, kwargs, imager
+        except BaseException as exc:        # noqa: B902 -- re-raised in the caller's thread
+            errors.append(exc)
+        finally:
+            if batcher is not None:
+                batcher.leave()         # the channels still in flight stop waiting for this thread
 
-    count = max(1, min(int(workers), len(channels)))
     if count == 1:
         work(0)
     else:
@@ -278,6 +293,11 @@ def process_channel_stream(make_job, channels, workers=2):
             t.start()
         for t in threads:
             t.join()
+    #: (channels, cycles) of every shared CLEAN launch sequence of the last call, for reports
+    process_channel_stream.last_batches = list(batcher.batches) if batcher is not None else []
     if errors:
         raise errors[0]
     return results
+
+
+process_channel_stream.last_batches = []

@@ -42,15 +42,36 @@ def enabled():
     return _lib is not None
 
 
+#: host-side timeline: when a list is installed with :func:`record_timeline`, every range also
+#: appends (thread name, range name, start, end) in ``time.perf_counter`` seconds -- what the host
+#: threads of ``frontend.process_channels`` were doing when, without a profiler
+_timeline = None
+
+
+def record_timeline(entries):
+    """Install (or, with None, remove) the list that collects host-side range timings."""
+    global _timeline
+    _timeline = entries
+
+
 @contextlib.contextmanager
 def range(name):        # noqa: A001  (the name roctx and NVTX use)
     """``with trace.range('grid'):`` -- a named range on the calling thread."""
     lib = _lib
-    if lib is None:
+    timeline = _timeline
+    if lib is None and timeline is None:
         yield
         return
-    lib.roctxRangePushA(name.encode())
+    if timeline is not None:
+        import threading
+        import time
+        t0 = time.perf_counter()
+    if lib is not None:
+        lib.roctxRangePushA(name.encode())
     try:
         yield
     finally:
-        lib.roctxRangePop()
+        if lib is not None:
+            lib.roctxRangePop()
+        if timeline is not None:
+            timeline.append((threading.current_thread().name, name, t0, time.perf_counter()))

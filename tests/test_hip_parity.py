@@ -1227,6 +1227,91 @@ def test_clean_fuzz(seed):
     np.testing.assert_array_equal(fn.buffer('model').get(q), ref_model)
 
 
+@pytest.mark.parametrize('C,P,mode,G,border', [(2, 1, 0, 256, 0.02), (4, 1, 0, 512, 0.02),
+                                               (8, 1, 0, 320, 0.0), (3, 4, 1, 200, 0.1),
+                                               (5, 2, 0, 144, 0.2)])
+def test_clean_batch_matches_single_channels(C, P, mode, G, border):
+    """kimg_clean_cycles_batch (cycle i of C channels in ONE launch, blockIdx.z = channel): every
+    channel -- its own image, PSF, patch size, threshold and cycle limit; some stop early, one asks
+    for fewer cycles -- gives BIT FOR BIT what the restated CleanHost gives for that channel alone
+    (components, dirty, model) and what the single-channel loop leaves in the tile arrays; a second
+    batched call continues where the first stopped."""
+    from katsdpimager_amd import clean, parameters
+    ctx, q = context_queue()
+    rs = np.random.RandomState(900 + C * 10 + P)
+    fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
+    cp = parameters.CleanParameters(1000, 0.1, 0.85, 5.0, mode, 0.01, 0.5, border)
+    template = clean.CleanTemplate(ctx, cp, np.float32, P)
+    queues = [q] + [ctx.create_command_queue() for _ in range(C - 1)]
+    fns, refs, patches, thresholds, cycles, singles = [], [], [], [], [], []
+    for c in range(C):
+        g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / rs.uniform(1.5, 6.0)) ** 2)
+        psf = np.empty((P, G, G), np.float32)
+        for p in range(P):
+            psf[p] = np.outer(g1, g1) + 0.01 * rs.standard_normal((G, G))
+        psf /= psf[:, G // 2, G // 2][:, None, None]
+        dirty = (0.3 * rs.standard_normal((P, G, G))).astype(np.float32)
+        for _ in range(12):
+            y, x = rs.randint(0, G, 2)
+            dirty[:, y, x] += rs.uniform(2.0, 10.0, P).astype(np.float32) * rs.choice([-1, 1])
+        fn = template.instantiate(queues[c], ip)
+        fn.ensure_all_bound()
+        single = template.instantiate(queues[c], ip)
+        single.ensure_all_bound()
+        for op in (fn, single):
+            op.buffer('dirty').set(queues[c], dirty)
+            op.buffer('psf').set(queues[c], psf)
+            op.buffer('model').zero(queues[c])
+            op.reset()
+        ref_img, ref_model = dirty.copy(), np.zeros_like(dirty)
+        ref = orc.Clean(G, border, 0.1, mode, ref_img, psf, ref_model)
+        ref.reset()
+        first = float(np.max(ref._tile_max))
+        patches.append((P, int(rs.choice([1, 9, 33, 65, 111])), int(rs.choice([1, 7, 31, 65, 133]))))
+        patches[-1] = (P, min(patches[-1][1], G), min(patches[-1][2], G))
+        thresholds.append(float(rs.choice([0.0, 0.0, 0.35 * first, 2.0 * first])))
+        cycles.append(int(rs.choice([70, 150, 33])))
+        fns.append(fn)
+        singles.append(single)
+        refs.append((ref, ref_img, ref_model))
+    assert all(clean.batch_supported(f, p_) for f, p_ in zip(fns, patches))
+
+    def check_round(got):
+        for c in range(C):
+            ref, ref_img, ref_model = refs[c]
+            want = []
+            for _ in range(cycles[c]):
+                v, pos, pix = ref(patches[c], thresholds[c])
+                if v is None:
+                    break
+                want.append((v, ref.last_pos, np.array(pix)))
+            assert len(got[c]) == len(want), (c, patches[c], thresholds[c], cycles[c])
+            for a, b in zip(got[c], want):
+                assert a[0] == b[0] and tuple(a[1]) == tuple(b[1])
+                np.testing.assert_array_equal(a[2], b[2])
+            np.testing.assert_array_equal(fns[c].buffer('dirty').get(queues[c]), ref_img)
+            np.testing.assert_array_equal(fns[c].buffer('model').get(queues[c]), ref_model)
+            alone = singles[c].run_cycles(patches[c], thresholds[c], cycles[c])
+            assert len(alone) == len(want)
+            np.testing.assert_array_equal(fns[c].buffer('tile_max').get(queues[c]),
+                                          singles[c].buffer('tile_max').get(queues[c]))
+            np.testing.assert_array_equal(fns[c].buffer('tile_pos').get(queues[c]),
+                                          singles[c].buffer('tile_pos').get(queues[c]))
+    check_round(clean.run_cycles_batch(fns, patches, thresholds, cycles))
+    # a second call goes on from the state the first left (lower thresholds, another queue)
+    thresholds = [0.0] * C
+    cycles = [40] * C
+    check_round(clean.run_cycles_batch(fns, patches, thresholds, cycles, queues[-1]))
+    with pytest.raises(ValueError):
+        clean.run_cycles_batch(fns + fns, patches * 2, thresholds * 2, cycles * 2)
+    big = (P, G, G)
+    if not clean.batch_supported(fns[0], big):
+        from katsdpimager_amd import _lib
+        with pytest.raises(_lib.KimgError):
+            clean.run_cycles_batch(fns[:2], [big, big], thresholds[:2], cycles[:2])
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_grid_image_weights_fuzz(seed):
     """Seeded random sizes through grid -> image, image -> grid and the weights pipeline against

@@ -673,7 +673,7 @@ def test_process_channel_stream_bounds_live_jobs(monkeypatch):
             peak[0] = max(peak[0], len(live))
         return Job(channel=channel)
 
-    def fake_process_channel(channel):
+    def fake_process_channel(channel, clean_batcher=None):
         _time.sleep(0.002)
         if channel == 77:
             raise RuntimeError('boom')
@@ -688,6 +688,83 @@ def test_process_channel_stream_bounds_live_jobs(monkeypatch):
     assert frontend.process_channel_stream(make_job, [], workers=2) == []
     got = parallel.image_assigned_channels(make_job, 7, workers=3)
     assert got == {c: 2 * c for c in range(7)}
+
+
+def test_clean_batcher_rendezvous(monkeypatch):
+    """clean.CleanBatcher (host logic only; the device loop is faked): channels that arrive
+    together share one enqueue, a patch too large for the one-launch form runs alone, a thread
+    that leaves is not waited for, and a lone arrival proceeds after the timeout."""
+    import threading
+    import time as _time
+    from katsdpimager_amd import clean
+    launched = []
+
+    class FakeClean:
+        def __init__(self, name, key='a'):
+            self.name, self.key, self.command_queue = name, key, object()
+
+        def _batch_key(self):
+            return self.key
+
+        def run_cycles(self, patch, threshold, max_cycles, collect=True):
+            launched.append(('solo', self.name))
+            self.how = 'solo'
+
+        how = 'batched'
+
+        def _collect_cycles(self):
+            return [(self.how, self.name)]
+
+    class FakeQueue:
+        def finish(self):
+            pass
+
+    def fake_enqueue(cleans, patches, thresholds, max_cycles, queue=None):
+        launched.append(('batch', tuple(c.name for c in cleans)))
+        return FakeQueue()
+    monkeypatch.setattr(clean, 'enqueue_cycles_batch', fake_enqueue)
+    monkeypatch.setattr(clean, 'batch_supported', lambda c, patch: patch[1] <= 500)
+
+    def run(batcher, items, delays=None):
+        out = {}
+
+        def work(i, item):
+            if delays:
+                _time.sleep(delays[i])
+            out[item[0].name] = batcher.run_cycles(*item)
+        threads = [threading.Thread(target=work, args=(i, it)) for i, it in enumerate(items)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(10)
+            assert not t.is_alive()
+        return out
+    small = (1, 111, 133)
+    b = clean.CleanBatcher(3, timeout=5.0)
+    cl = [FakeClean(n) for n in 'xyz']
+    out = run(b, [(c, small, 0.0, 100) for c in cl], [0.0, 0.01, 0.02])
+    assert out == {n: [('batched', n)] for n in 'xyz'}
+    assert [k for k, _ in launched] == ['batch'] and sorted(launched[0][1]) == list('xyz')
+    assert b.batches == [(3, 100)]
+    # a large patch and a different image shape go alone; the two compatible ones share
+    launched.clear()
+    items = [(FakeClean('p'), small, 0.0, 10), (FakeClean('q'), (1, 711, 675), 0.0, 10),
+             (FakeClean('r', key='b'), small, 0.0, 10)]
+    out = run(b, items)
+    assert out == {'p': [('solo', 'p')], 'q': [('solo', 'q')], 'r': [('solo', 'r')]}
+    # one party left: the remaining two do not wait for it
+    launched.clear()
+    b.leave()
+    t0 = _time.monotonic()
+    out = run(b, [(FakeClean('m'), small, 0.0, 7), (FakeClean('n'), small, 0.0, 9)])
+    assert _time.monotonic() - t0 < 2.0 and launched == [('batch', ('m', 'n'))] or \
+        launched == [('batch', ('n', 'm'))]
+    assert b.batches[-1] == (2, 9)
+    # a lone arrival among two parties proceeds after the timeout, alone
+    b2 = clean.CleanBatcher(2, timeout=0.05)
+    launched.clear()
+    assert b2.run_cycles(FakeClean('w'), small, 0.0, 5) == [('solo', 'w')]
+    assert b2.run_cycles(FakeClean('w'), small, 0.0, 0) == []
 
 
 def _loader_arrays(rows=600, channels=3, pols=2, antennas=5, seed=8):
