@@ -1114,8 +1114,11 @@ size_t lds_bytes(int P, int NW, int W, int OV, int row, int tables = 1)
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+// (512 until round 3; 384 measures 3-4 % faster on launches of ~7 M records -- a W-slice of the
+// re-ordered resident store, where a wave only gets four or five chunks and the tail of the launch
+// is one chunk long -- and the same on 50 M-record launches, whose chunks the cap below sets)
 #ifndef KIMG_INTERLEAVE_MIN_CHUNK
-#define KIMG_INTERLEAVE_MIN_CHUNK 512
+#define KIMG_INTERLEAVE_MIN_CHUNK 384
 #endif
 #ifndef KIMG_INTERLEAVE_MAX_PARTS
 #define KIMG_INTERLEAVE_MAX_PARTS 16
@@ -1131,7 +1134,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
            unsigned char *padded = nullptr, size_t tab_max_offset = 0,
            unsigned long long *queue = nullptr)
 {
-    constexpr int SUB = P == 1 ? 4 : 2;       // pipeline depth bounded by the VGPR budget
+    constexpr int SUB = (P == 1 && NW <= 12) ? 4 : 2;       // pipeline depth bounded by the VGPR budget
     const size_t lds = TG ? lds_bytes(P, NW, 0, 0, ROW) : lds_bytes(P, NW, W, OV, ROW, TWO ? 2 : 1);
     unsigned *tab_max = nullptr;
     if (TG) {
@@ -1317,6 +1320,11 @@ int kimg_grid_mfma(void *grid, int64_t grid_row_stride, int64_t grid_pol_stride,
                         GO(2, 64, 8, false, true);
                 } else if (pn == 1) {
                     // 12-wave blocks, one per CU (LDS-bound), when the doubled table leaves room
+#ifdef KIMG_GRID_NW16
+                    if (lds_bytes(1, 16, w_planes, oversample, 64) <= LDS_LIMIT)
+                        GO(1, 64, 16, false, false);
+                    else
+#endif
                     if (lds_bytes(1, 12, w_planes, oversample, 64) <= LDS_LIMIT)
                         GO(1, 64, 12, false, false);
                     else if (lds_bytes(1, 8, w_planes, oversample, 64) <= LDS_LIMIT)

@@ -528,6 +528,68 @@ def test_c5_dirty_image_of_a_sub_band_vs_oracle():
     assert relerr(got[inner], want[inner]) < 1e-4
 
 
+def test_c1_true_size_two_w_slices_vs_oracle():
+    """BASELINE config 1 at its TRUE size -- 1024^2 image, 8 W-planes, Stokes I, here with two W
+    slices so that the second one is imaged at w != 0 -- one 1 M-visibility block of a simulated
+    64-antenna track set: device preprocessing -> resident store (re-ordered, unmerged) ->
+    make_weights + make_dirty over both slices, against the oracle on the same stored records:
+    `orc.grid` per slice (1e-5), then `orc.grid_to_image` of both slices accumulated (1e-5
+    taper-weighted, 1e-4 on the inner image)."""
+    import torch
+    from katsdpimager_amd import accel, frontend, imaging, parameters, preprocess, weight
+    from helpers import tapered_relerr
+    import synth
+    ctx, q = context_queue()
+    G = 1024
+    obs = synth.make_observation(G, 1_048_576, 8, 1, device=ctx.device, w_slices=2, seed=9)
+    synth.add_point_sources(obs, 25, seed=3, noise=0.05)
+    ipd, gpd, apd = synth.make_parameters(obs, 1, 28, degrid=True)
+    assert gpd.w_slices == 2 and gpd.w_planes == 8
+    n = obs.n_vis
+    d_uvw = accel.DeviceArray(ctx, (n, 3), np.float32, tensor=obs.uvw)
+    d_wts = accel.DeviceArray(ctx, (1, n, 1), np.float32, tensor=obs.weights[None].contiguous())
+    d_vis = accel.DeviceArray(ctx, (1, n, 1), np.complex64, tensor=obs.raw_vis[None].contiguous())
+    torch.cuda.synchronize()
+    coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], 1 << 20, merge=False)
+    coll.add(d_uvw, d_wts, d_vis, None, None, np.identity(1, np.complex64), None)
+    coll.close()
+    reader = coll.reader()
+    lens = [reader.len(0, s_) for s_ in range(2)]
+    assert min(lens) > 20000 and sum(lens) == coll.num_output      # both slices populated
+    cp = parameters.CleanParameters(100, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
+    wparm = parameters.WeightParameters(weight.WeightType.NATURAL, 0.0)
+    template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
+    block = max(lens)
+    im = template.instantiate(q, ipd, gpd, block, 0, 1)
+    im.ensure_all_bound()
+    frontend.make_weights(reader, 0, im, wparm.weight_type, block)
+    mid_w = frontend.slice_mid_w(ipd, gpd)
+    assert mid_w[0] == 0.0 and mid_w[1] > 0.0
+    frontend.make_dirty(reader, 0, 'vis', im, mid_w, block, True)
+    got = im.get_buffer('dirty')
+    Gg = im.buffer('grid').shape[1]
+    kernel = im._gridder.convolve_kernel
+    k1d = kernel.taper(G).astype(np.float32)
+    want = np.zeros((1, G, G), np.float32)
+    lo = (G - Gg) // 2
+    for s_ in range(2):
+        rec = next(iter(reader.iter_slice(0, s_, block)))
+        grid_ = np.zeros((1, Gg, Gg), np.complex64)
+        orc.grid(kernel.data, grid_, np.ones((1, Gg, Gg), np.float32), np.ascontiguousarray(rec.uv),
+                 np.ascontiguousarray(rec.sub_uv), np.ascontiguousarray(rec.w_plane),
+                 np.ascontiguousarray(rec.vis))
+        if s_ == 1:
+            # (the imager's grid buffer holds the last slice gridded)
+            assert relerr(im.get_buffer('grid'), grid_) < 1e-5
+        full = np.zeros((1, G, G), np.complex64)
+        full[:, lo:lo + Gg, lo:lo + Gg] = grid_
+        orc.grid_to_image(full, want, k1d, float(ipd.pixel_size), -0.5 * G * float(ipd.pixel_size),
+                          float(mid_w[s_]))
+    assert tapered_relerr(got, want, k1d) < 1e-5
+    inner = np.s_[:, G // 8:-G // 8, G // 8:-G // 8]
+    assert relerr(got[inner], want[inner]) < 1e-4
+
+
 def test_c2_orders_binned_vs_track_order():
     """Config 2 geometry, 4 M visibilities: the same visibilities in track order (window kernel as
     is), time-major and shuffled (both binned by `auto`) give the same grid; the loader-shaped,

@@ -21,6 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import synth                                                    # noqa: E402
+from katsdpimager_amd import _lib as _kl
+if os.environ.get('KIMG_VARIANT_LIB'):
+    _kl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build_variants',
+                                'libkimg_%s.so' % os.environ['KIMG_VARIANT_LIB'])
 from katsdpimager_amd import accel, grid                        # noqa: E402
 
 
