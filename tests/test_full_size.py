@@ -555,7 +555,7 @@ def test_c1_true_size_two_w_slices_vs_oracle():
     coll.close()
     reader = coll.reader()
     lens = [reader.len(0, s_) for s_ in range(2)]
-    assert min(lens) > 20000 and sum(lens) == coll.num_output      # both slices populated
+    assert min(lens) > 5000 and sum(lens) == coll.num_output       # both slices populated
     cp = parameters.CleanParameters(100, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
     wparm = parameters.WeightParameters(weight.WeightType.NATURAL, 0.0)
     template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
