@@ -991,29 +991,46 @@ def major_cycle_loop(args, ctx, q, obs, extras=False, arith='fp32', add_sources=
     out['visibilities'] = n
     out['arith'] = arith
     del im
-    if extras:
-        out['extras'] = major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm)
+    if arith == 'fp32':
+        keep = {}
+        out['store_driven'] = store_driven(args, ctx, q, obs, template, ipd, gpd, cp, wparm, keep)
+        if extras:
+            out['extras'] = major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm,
+                                              keep['reader'])
     return out
 
 
-def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm):
-    """The same channel from raw inputs: device preprocessing into the HBM-resident
-    store (8f-2), then the store-driven driver katsdpimager_amd.frontend.process_channel; and four
-    channels with 1-4 of them in flight."""
+def store_driven(args, ctx, q, obs, template, ipd, gpd, cp, wparm, keep=None):
+    """BASELINE config 5 the way the product runs it: raw visibilities -> device preprocessing
+     -> HBM-resident store (8f-2; re-ordered and merged once when it is closed) ->
+    frontend.process_channel (weights, PSF, 2 major cycles of up to 1000 minor cycles, degridding).
+    The same with the store left in arrival order is timed next to it (`arrival_order_*`: what
+    round 2 ran)."""
     import torch
-    from katsdpimager_amd import accel, frontend, imaging, parameters, preprocess
+    from katsdpimager_amd import accel, frontend, preprocess, trace
     P = args.polarizations
     out = {}
     n = obs.n_vis
+    import synth
     raw_vis = torch.where((obs.uvw[:, 2] < 0)[:, None], torch.conj(obs.vis), obs.vis)
     raw_vis = torch.where(torch.isfinite(raw_vis.real), raw_vis, torch.zeros_like(raw_vis))
-    d_uvw = accel.DeviceArray(ctx, (n, 3), np.float32, tensor=obs.uvw)
-    d_wts = accel.DeviceArray(ctx, (1, n, P), np.float32, tensor=obs.weights[None].contiguous())
-    d_vis = accel.DeviceArray(ctx, (1, n, P), np.complex64, tensor=raw_vis[None].contiguous())
+    # in the order the reference's loaders deliver: blocks of 256 dumps, each sorted by baseline
+    # (loader_ms.py:465-468; tools/synth.order_loader_blocks)
+    b, t, nb, T = synth._track_indices(obs)
+    dumps = 256
+    order = torch.argsort((t // dumps) * (nb * dumps) + b * dumps + (t % dumps))
+    del b, t
+    d_uvw = accel.DeviceArray(ctx, (n, 3), np.float32, tensor=obs.uvw[order].contiguous())
+    d_wts = accel.DeviceArray(ctx, (1, n, P), np.float32, tensor=obs.weights[order][None].contiguous())
+    d_vis = accel.DeviceArray(ctx, (1, n, P), np.complex64, tensor=raw_vis[order][None].contiguous())
+    del order, raw_vis
+    out['input_order'] = 'loader blocks of {} dumps, baseline-sorted'.format(dumps)
     ident = np.identity(P, np.complex64)
     torch.cuda.synchronize()
-    for label, bs in (('preprocess_16x_buffer_Mvis_per_s', 16 * args.vis_block),
-                      ('preprocess_Mvis_per_s', args.vis_block)):
+    sizes = [('preprocess_Mvis_per_s', args.vis_block)]
+    if args.extras:
+        sizes.insert(0, ('preprocess_16x_buffer_Mvis_per_s', 16 * args.vis_block))
+    for label, bs in sizes:
         for rep in range(2):            # the first pass warms up the kernels and the allocator
             coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], bs)
             q.finish()
@@ -1022,23 +1039,55 @@ def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm):
             q.finish()
             dt = time.perf_counter() - t0
         out[label] = round(n / dt / 1e6, 1)
-    coll.close()
-    reader = coll.reader()
-    out['preprocess_kept_fraction'] = round(coll.num_output / coll.num_input, 4)
+    plain = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], args.vis_block, reorder=False)
+    plain.add(d_uvw, d_wts, d_vis, None, None, ident, None)
+    plain.close()
+    q.finish()
+    t0 = time.perf_counter()
+    coll.close()                        # the once-per-channel re-order + whole-slice merge
+    q.finish()
+    out['store_reorder_ms_once_per_channel'] = round((time.perf_counter() - t0) * 1e3, 3)
+    out['input_visibilities'] = n
+    out['records_after_compress'] = int(coll.num_output)
+    out['records_stored'] = int(coll.num_stored)
     out['store_MB'] = round(coll.nbytes() / 1e6, 1)
+    for label, c in (('arrival_order', plain), ('store_order', coll)):
+        reader = c.reader()
+        block = max(reader.len(0, s) for s in range(reader.num_w_slices(0)))
+        im = template.instantiate(q, ipd, gpd, block, 0, 2)
+        im.ensure_all_bound()
+        for rep in range(2):
+            entries = []
+            trace.record_timeline(entries if rep else None)
+            q.finish()
+            t0 = time.perf_counter()
+            stats = frontend.process_channel(reader, 0, im, ipd, gpd, cp, wparm.weight_type,
+                                             block, 2, True)
+            q.finish()
+            dt = time.perf_counter() - t0
+        trace.record_timeline(None)
+        stages = {}
+        for _, name, a, b in entries:
+            key = name.split('[')[0]
+            stages[key] = stages.get(key, 0.0) + (b - a) * 1e3
+        out[label + '_total_ms'] = round(dt * 1e3, 3)
+        out[label + '_minor_cycles'] = int(stats['minor']) if stats else None
+        # host-side time of the driver's stages (a stage that ends in a read-back also waits for
+        # the device work enqueued before it)
+        out[label + '_stage_ms'] = {k: round(v, 3) for k, v in stages.items()}
+        del im
+    if keep is not None:
+        keep['reader'] = coll.reader()
+    return out
+
+
+def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm, reader):
+    """Four channels with 1-4 of them in flight (frontend.process_channels: one host thread and one
+    stream per channel, the CLEAN cycles of the channels in flight sharing their launches)."""
+    import torch
+    from katsdpimager_amd import frontend, imaging, parameters
+    out = {}
     block = max(reader.len(0, s) for s in range(reader.num_w_slices(0)))
-    im = template.instantiate(q, ipd, gpd, block, 0, 2)
-    im.ensure_all_bound()
-    for rep in range(2):
-        q.finish()
-        t0 = time.perf_counter()
-        stats = frontend.process_channel(reader, 0, im, ipd, gpd, cp, wparm.weight_type,
-                                         block, 2, True)
-        q.finish()
-        dt = time.perf_counter() - t0
-    out['store_driver_total_ms'] = round(dt * 1e3, 3)
-    out['store_driver_minor_cycles'] = int(stats['minor']) if stats else None
-    del im
     # Four channels (here: the same stored channel imaged four times) with 1, 2, 3 and 4 of them in
     # flight on their own streams; CLEAN thresholds forced low so that every major cycle runs its
     # full 1000 minor cycles, as in the staged loop above.

@@ -206,6 +206,10 @@ int kimg_fill(float *data, int64_t count, float value, void *stream);
  *       slice.  Outputs are in the gridder's layout: out_uv int16 [M][4] = (u, v, sub_u, sub_v),
  *       out_w_plane int16 [M], out_weights [M][P], out_vis [M][P], and counts uint64 [w_slices]
  *       (device) = run length per slice, M = sum(counts).  Output arrays need room for N records.
+ *       merge_window > 0: runs never cross a multiple of merge_window records -- the call then
+ *       compresses num_vis / merge_window of the reference's buffers (preprocess.cpp:431-509: every
+ *       buffer is compressed on its own) in ONE pass over the device, with the results the
+ *       per-buffer calls would have given, concatenated per slice.  0 = one buffer.
  *       workspace: kimg_preprocess_workspace_bytes(N, P) bytes of device memory.
  *   kimg_real_to_complex: dst[i] = (src[i], 0): feeds weights as visibilities for the PSF pass
  *       (frontend.py:511) from a device-resident store.
@@ -220,7 +224,8 @@ size_t kimg_preprocess_workspace_bytes(int64_t num_vis, int num_polarizations);
 int kimg_preprocess_compress(int num_polarizations, int64_t num_vis, int w_slices,
                              const int16_t *key, const float *weights, const void *vis,
                              int16_t *out_uv, int16_t *out_w_plane, float *out_weights, void *out_vis,
-                             uint64_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+                             uint64_t *counts, int64_t merge_window, void *workspace,
+                             size_t workspace_bytes, void *stream);
 int kimg_real_to_complex(void *dst, const float *src, int64_t count, void *stream);
 
 /* ---- once-per-channel re-ordering of a stored W-slice (csrc/store.hip).  No launch site of the

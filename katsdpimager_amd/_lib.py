@@ -38,7 +38,7 @@ PROTOTYPES = {
     'kimg_fill': (c_int, [P, L, F, P]),
     'kimg_preprocess_convert': (c_int, [I, I, L, P, P, P, P, P, P, P, F, I, I, I, F, P, P, P, P]),
     'kimg_preprocess_workspace_bytes': (ctypes.c_size_t, [L, I]),
-    'kimg_preprocess_compress': (c_int, [I, L, I, P, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
+    'kimg_preprocess_compress': (c_int, [I, L, I, P, P, P, P, P, P, P, P, L, P, ctypes.c_size_t, P]),
     'kimg_real_to_complex': (c_int, [P, P, L, P]),
     'kimg_store_reorder_workspace_bytes': (c_size_t, [L]),
     'kimg_store_reorder': (c_int, [I, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -260,13 +260,16 @@ struct pp_max_op {
 struct pp_head_flag {
     const int *pv;
     const short *key;
+    int window;         // merging never crosses a multiple of `window` records (0: no cuts)
     __host__ __device__ int operator()(int i) const
     {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (pv[i] != i)
             return 0;                           // flagged record
         const int prev = i > 0 ? pv[i - 1] : -1;
-        if (prev < 0)
+        // (the first unflagged record of a window starts a run whatever came before: the windows
+        // are the reference's buffers, each compressed on its own, preprocess.cpp:431-509)
+        if (prev < 0 || (window > 0 && prev < i - i % window))
             return 1;
         const int *a = reinterpret_cast<const int *>(key + 6 * (int64_t) i);
         const int *b = reinterpret_cast<const int *>(key + 6 * (int64_t) prev);
@@ -467,7 +470,7 @@ int convert_q(int Q, int64_t n, const float *uvw, const float *weights, const fl
 }
 
 template <int P>
-int compress_impl(int64_t n, int w_slices, const short *key, const float *w, const float2 *vis,
+int compress_impl(int64_t n, int w_slices, int window, const short *key, const float *w, const float2 *vis,
                   short *out_uv, short *out_wplane, float *out_w, float2 *out_vis,
                   unsigned long long *counts, pp_workspace &ws, hipStream_t stream)
 {
@@ -481,7 +484,7 @@ int compress_impl(int64_t n, int w_slices, const short *key, const float *w, con
     KIMG_HIP(hipcub::DeviceScan::InclusiveScan(ws.cub, cb, valid_index, pv, pp_max_op(), (int) n,
                                                stream));
     hipcub::TransformInputIterator<int, pp_head_flag, hipcub::CountingInputIterator<int>>
-        head_flag(index, pp_head_flag{pv, key});
+        head_flag(index, pp_head_flag{pv, key, window});
     cb = ws.cub_bytes;
     KIMG_HIP(hipcub::DeviceScan::InclusiveSum(ws.cub, cb, head_flag, ipos, (int) n, stream));
     if (!single)
@@ -564,11 +567,13 @@ extern "C" int kimg_preprocess_compress(
     int num_pols, int64_t num_vis, int w_slices,
     const int16_t *key, const float *weights, const void *vis,
     int16_t *out_uv, int16_t *out_w_plane, float *out_weights, void *out_vis,
-    uint64_t *counts, void *workspace, size_t workspace_bytes, void *stream_)
+    uint64_t *counts, int64_t merge_window, void *workspace, size_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KIMG_CHECK_ARG(num_pols >= 1 && num_pols <= 4);
     KIMG_CHECK_ARG(num_vis >= 0 && num_vis < ((int64_t) 1 << 31));
+    KIMG_CHECK_ARG(merge_window >= 0 && merge_window < ((int64_t) 1 << 31));
+    const int window = (int) merge_window;
     KIMG_CHECK_ARG(w_slices >= 1 && w_slices <= 32767 && counts != nullptr);
     if (num_vis == 0) {
         KIMG_HIP(hipMemsetAsync(counts, 0, sizeof(uint64_t) * w_slices, stream));
@@ -583,10 +588,10 @@ extern "C" int kimg_preprocess_compress(
     float2 *ov = static_cast<float2 *>(out_vis);
     unsigned long long *c = reinterpret_cast<unsigned long long *>(counts);
     switch (num_pols) {
-    case 1: return compress_impl<1>(num_vis, w_slices, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
-    case 2: return compress_impl<2>(num_vis, w_slices, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
-    case 3: return compress_impl<3>(num_vis, w_slices, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
-    default: return compress_impl<4>(num_vis, w_slices, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
+    case 1: return compress_impl<1>(num_vis, w_slices, window, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
+    case 2: return compress_impl<2>(num_vis, w_slices, window, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
+    case 3: return compress_impl<3>(num_vis, w_slices, window, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
+    default: return compress_impl<4>(num_vis, w_slices, window, key, weights, v, out_uv, out_w_plane, out_weights, ov, c, ws, stream);
     }
 }
 

@@ -202,6 +202,9 @@ class VisibilityCollectorDevice:
         preprocess.cpp:431-509); also the largest block ``iter_slice_device`` can serve.
     """
 
+    #: records per pass of the device kernels (a whole number of buffers; see __init__)
+    MAX_BATCH = 1 << 24
+
     def __init__(self, command_queue, image_parameters, grid_parameters, buffer_size,
                  reorder=True, merge=True):
         if len(image_parameters) != len(grid_parameters):
@@ -231,13 +234,28 @@ class VisibilityCollectorDevice:
              for _ in range(gp.w_slices)]
             for gp in self.grid_parameters]
         self._lib = lib()
-        B = self.buffer_size
+        # Buffers are the reference's unit of compression (merging never crosses one,
+        # preprocess.cpp:431-509); the device passes run over up to MAX_BATCH records = several
+        # buffers at a time (kimg_preprocess_compress, merge_window = buffer_size: same records as
+        # buffer-by-buffer calls, but the ~10 us of fixed cost of each of the seven launches is
+        # paid once per batch: 9 -> 20 G inputs/s with buffers of 1 Mi)
+        self._batch = 0                 # records the staging arrays hold (grown by add())
+        if int(self._lib.kimg_preprocess_workspace_bytes(self.buffer_size, P)) == 0:
+            raise ValueError('unsupported buffer_size / polarizations')
+
+    def _ensure_staging(self, num_vis):
+        """Staging arrays for passes of up to MAX_BATCH records, never more than the call needs."""
+        buffers = max(1, min(self.MAX_BATCH // self.buffer_size, -(-num_vis // self.buffer_size)))
+        B = self.buffer_size * buffers
+        if B <= self._batch:
+            return
+        P = self.num_polarizations
         ctx = self.context
         self._key = accel.DeviceArray(ctx, (B, 6), np.int16, queue=self.queue)
         self._cw = accel.DeviceArray(ctx, (B, P), np.float32, queue=self.queue)
         self._cvis = accel.DeviceArray(ctx, (B, P), np.complex64, queue=self.queue)
-        # two sets of compress outputs + slice counts: the host reads the counts of buffer i
-        # (needed to place its records) while the device already works on buffer i + 1
+        # two sets of compress outputs + slice counts: the host reads the counts of pass i
+        # (needed to place its records) while the device already works on pass i + 1
         max_slices = max(gp.w_slices for gp in self.grid_parameters)
         torch = accel._torch()
         self._sets = []
@@ -251,9 +269,8 @@ class VisibilityCollectorDevice:
             host = torch.empty((max_slices,), dtype=torch.int64).pin_memory()
             self._sets.append((out, counts, host, torch.cuda.Event()))
         self._ws_bytes = int(self._lib.kimg_preprocess_workspace_bytes(B, P))
-        if self._ws_bytes == 0:
-            raise ValueError('unsupported buffer_size / polarizations')
         self._ws = accel.DeviceArray(ctx, (self._ws_bytes,), np.uint8, queue=self.queue)
+        self._batch = B
 
     @property
     def num_channels(self):
@@ -303,6 +320,7 @@ class VisibilityCollectorDevice:
             raise ValueError('Array has incorrect size')
         stokes = self._matrix(mueller_stokes, (P, 4) if d_fa1 is not None else (P, Q))
         circular = self._matrix(mueller_circular, (4, Q))
+        self._ensure_staging(N)
         stream = self.queue.handle
         f32 = np.dtype(np.float32).itemsize
         torch = accel._torch()
@@ -324,8 +342,8 @@ class VisibilityCollectorDevice:
         for ch in range(C):
             gp = self.grid_parameters[ch]
             cell = float(self.image_parameters[ch].cell_size)
-            for i0 in range(0, N, self.buffer_size):
-                n = min(N, i0 + self.buffer_size) - i0
+            for i0 in range(0, N, self._batch):
+                n = min(N, i0 + self._batch) - i0
                 row = (ch * N + i0) * Q
                 cur = self._sets[step % 2]
                 step += 1
@@ -341,7 +359,8 @@ class VisibilityCollectorDevice:
                 check(self._lib.kimg_preprocess_compress(
                     P, n, gp.w_slices, self._key.ptr, self._cw.ptr, self._cvis.ptr,
                     out['uv'].ptr, out['w_plane'].ptr, out['weights'].ptr, out['vis'].ptr,
-                    counts.ptr, self._ws.ptr, self._ws_bytes, stream), 'kimg_preprocess_compress')
+                    counts.ptr, self.buffer_size if n > self.buffer_size else 0,
+                    self._ws.ptr, self._ws_bytes, stream), 'kimg_preprocess_compress')
                 with torch.cuda.stream(self.queue.stream):
                     host.copy_(counts.tensor, non_blocking=True)
                     event.record(self.queue.stream)

@@ -167,9 +167,11 @@ def test_preprocess_argument_validation():
     # feed angles without mueller_circular
     assert L.kimg_preprocess_convert(4, 4, 0, None, None, None, 8, 8, m.ctypes.data, None,
                                      400.0, 1, 128, 8, 1.0, None, None, None, None) == -10001
-    assert L.kimg_preprocess_compress(5, 0, 1, None, None, None, None, None, None, None, 8,
+    assert L.kimg_preprocess_compress(5, 0, 1, None, None, None, None, None, None, None, 8, 0,
                                       None, 0, None) == -10001
-    assert L.kimg_preprocess_compress(1, 10, 1, None, None, None, None, None, None, None, 8,
+    assert L.kimg_preprocess_compress(1, 10, 1, None, None, None, None, None, None, None, 8, 0,
+                                      None, 0, None) == -10001
+    assert L.kimg_preprocess_compress(1, 10, 1, None, None, None, None, None, None, None, 8, -4,
                                       None, 0, None) == -10001
     assert L.kimg_real_to_complex(None, None, -1, None) == -10001
     assert L.kimg_real_to_complex(None, None, 0, None) == 0

@@ -31,3 +31,11 @@ if po:
             k, b['records'], b['grid_ms'], b['records_per_s_M'], b['roofline']['frac'], b['degrid_ms'],
             b['degrid_records_per_s_M'],
             '  reorder %.3f ms' % b['reorder_ms_once_per_channel'] if 'reorder_ms_once_per_channel' in b else ''))
+sd = d.get('major_cycle_loop', {}).get('store_driven')
+if sd:
+    print('store-driven C5: %d inputs -> %d stored; preprocess %.0f Mvis/s; reorder %.3f ms; process_channel %.2f ms in store order (%s cycles), %.2f ms in arrival order' % (
+        sd['input_visibilities'], sd['records_stored'], sd['preprocess_Mvis_per_s'],
+        sd['store_reorder_ms_once_per_channel'], sd['store_order_total_ms'], sd['store_order_minor_cycles'],
+        sd['arrival_order_total_ms']))
+    print('   stages (store order):', sd['store_order_stage_ms'])
+    print('   stages (arrival)    :', sd['arrival_order_stage_ms'])
