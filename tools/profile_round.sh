@@ -12,6 +12,11 @@ R=${1:-r02}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 HEAD="python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-secondary"
+# 0. the same command unprofiled, on this lease (boxes differ by several per cent: the profiled
+#    steady state below is to be compared with THIS line, not with another box's)
+$HEAD > $OUT/unprofiled.log 2>&1
+grep -h "^{\"metric\"" $OUT/unprofiled.log | tail -1 > $OUT/${R}_bench_unprofiled.json
+echo "unprofiled rc=$?"
 if [ "$2" != "stats-only" ]; then
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum" \
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
