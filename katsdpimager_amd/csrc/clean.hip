@@ -411,36 +411,54 @@ __global__ __launch_bounds__(256) void cycle_subtract_update_kernel(
 // ---- one launch per minor cycle ----------------------------------------------------------
 // The two-launch cycle above is a chain of dependent memory round trips with a kernel boundary
 // in the middle.  Here every workgroup of the subtract/update launch finds the global peak
-// ITSELF, so the cycle is one launch with no communication between its workgroups:
-//   * all workgroups read the same inputs -- per owner thread its best two tiles (`owner_best`)
-//     and the tile record the previous cycle rewrote, if any (a "delta") -- and therefore pick
-//     the same peak;
-//   * each then subtracts the PSF from its own lattice block, rescans it, and writes the new tile
-//     record to the OTHER delta table (double-buffered by cycle parity), never to the base arrays,
-//     so that slower workgroups of the same launch still see the inputs unchanged;
-//   * one more workgroup (the "keeper") folds the previous cycle's deltas into the base arrays
-//     (readers override those entries with the delta values anyway, so it does not matter which
-//     version they see), refreshes the best-two of the owners concerned, and writes the log
-//     entry, the model pixel and the next state.
+// ITSELF, so the cycle is one launch with no communication between its workgroups.
+//
+// What a launch needs to know the peak.  Every tile is either one the LAST cycle rewrote -- its new
+// record is a "delta": at most (patch / 32 + 2)^2 of them (30 for the 133 x 111 patch of a measured
+// PSF), written by the lattice workgroups of the last launch into the slot of their lattice
+// position -- or it is not, and the best of THOSE was worked out, off the critical path, during the
+// last launch (`rest`).  So a workgroup's first round trip is 48 bytes of state and one delta per
+// thread of its first few waves, every candidate arrives with its record (position, pixel values: no
+// dependent load), and the peak is one block reduction away: 1.25 us after the first instruction.
+// (Rounds 1-2: every workgroup read a 48-byte delta slot and a 16-byte best-two record per THREAD,
+// 64 KB, and then fetched its candidate's record: 1.9 us.)
+//
+// Workgroups of a launch, per channel:
+//   * lattice workgroups, one per 32 x 32 block of the tile lattice that the PSF patch can touch:
+//     peak, then subtract the PSF from the block, rescan it, and write the new tile record to the
+//     OTHER delta table (double-buffered by launch parity), never to the base arrays, so that
+//     slower workgroups of the same launch still see the inputs unchanged;
+//   * the "keeper": peak, then the log entry, the model pixel, the next state -- and `rest` for the
+//     next launch: the best tile outside THIS cycle's lattice, from a table of every owner's best
+//     three tiles (thread (b, a) of 1024 owns the tiles with (ty % 32, tx % 32) = (b, a); a patch
+//     spans fewer than 32 tiles either way, so a cycle rewrites at most one tile per owner) that is
+//     exact up to the cycle before last, plus the last cycle's delta of the owner, if any: three
+//     known tiles always decide the best two after one of them changed;
+//   * the "folder": folds the last cycle's deltas into the base arrays (plain stores nobody in this
+//     launch reads back) and into the owners' table -- a rescan of the 16 (64 at 8192^2) tile maxima
+//     of every owner that has one -- written to the OTHER copy of the table, for the next launch's
+//     keeper.  Nobody waits for it within the launch.
+// The keeper's chain (state + table, peak, candidate, record || reduction, store) and the folder's
+// (deltas, rescans, stores) are each about as long as a lattice workgroup's; in round 3's first
+// version one workgroup did both and was twice as long as the lattice workgroups (time stamps:
+// 6.4 against 3.2 us), which made the cycle slower than before, not faster.
 // Tile records carry the pixel values at the tile's peak (tile_pix), which saves the dependent
 // load of the peak pixel.  Selection and arithmetic are those of the two-launch form, bit for bit.
-// Measured at 4096^2: 6.5 us per cycle for 25 lattice blocks, 7.1 for 225; with more workgroups
-// than CUs 10.1 (256 blocks) and 11.6 (441), against 9.0-10.0 for two launches: the one-launch
-// form is used while its workgroups fit the 256 CUs.
-constexpr int FUSED_MAX_BLOCKS = 256;     // workgroups of a launch incl. the bookkeeping row: one per CU
+constexpr int FUSED_MAX_BLOCKS = 256;     // workgroups of a launch incl. the two bookkeepers: one per CU
 constexpr int FUSED_ROUND = 16;           // tile maxima per thread and round of a rescan
 constexpr int FUSED_MAX_SLOTS = 4 * FUSED_ROUND;     // 32x32-tile groups: up to 8192^2 pixels
 
-// A tile record rewritten by one cycle and consumed by the next, stored at the slot of the thread
-// that owns the tile in the peak search (see cycle_fused_kernel).  `tag` = 2 + the cycle that wrote
-// it: a record is live for exactly the cycle after (0 = never written; the table is cleared per call).
+// A tile record rewritten by one cycle and consumed by the next, stored at the slot 32 * (lattice
+// row) + (lattice column) of the workgroup that wrote it.  `tag` = 2 + the cycle that wrote it: a
+// record is live for exactly the cycle after (0 = never written; the table is cleared per call).
 struct __attribute__((aligned(16))) delta_t {
     int tag;
     int tile;
     float value;
     int y, x;
     float pix[4];
-    int pad[3];
+    int owner;              // the thread (32 * (ty % 32) + tx % 32) that owns the tile
+    int pad[2];
 };
 
 struct fused_state {
@@ -449,43 +467,40 @@ struct fused_state {
     int pad[12];
 };
 
-// The best two tiles among those a thread owns, ordered by (larger value, lower tile index);
-// value -1 = none.  Two, because when one owned tile gets a new value the owner's new BEST is
-// then known without looking at the other tiles: it is the better of the new record and of the
-// best of the others, which is the first of the two that is not the rewritten tile.
-// (16-byte aligned and moved as ONE 16-byte access: the keeper workgroup of a launch rewrites an
-// owner's record while lattice workgroups of the same launch read it; either version is fine for
-// them, a mix of the two would not be.)
-struct __attribute__((aligned(16))) owner_best_t {
-    float v1;
-    int t1;
-    float v2;
-    int t2;
+// The best three tiles among those a thread owns, ordered by (larger value, lower tile index);
+// value -1 = none.  Three, because when ONE owned tile gets a new value the owner's best TWO are
+// then known without looking at its other tiles (they are no better than the third), and two are
+// what the keeper needs: the best tile outside the current cycle's lattice, which holds at most
+// one tile of the owner.
+struct __attribute__((aligned(16))) owner3_t {
+    float v[3];
+    int t[3];
+    int pad[2];
 };
-static_assert(sizeof(owner_best_t) == 16, "one 16-byte access");
+static_assert(sizeof(owner3_t) == 32, "two 16-byte accesses");
 
-__device__ inline owner_best_t load_owner_best(const owner_best_t *p)
-{
-    const int4 w = *reinterpret_cast<const int4 *>(p);
-    owner_best_t b;
-    b.v1 = __int_as_float(w.x);
-    b.t1 = w.y;
-    b.v2 = __int_as_float(w.z);
-    b.t2 = w.w;
-    return b;
-}
-
-__device__ inline void store_owner_best(owner_best_t *p, const owner_best_t &b)
-{
-    *reinterpret_cast<int4 *>(p) = make_int4(__float_as_int(b.v1), b.t1, __float_as_int(b.v2), b.t2);
-}
+// The best tile among those the LAST cycle did not rewrite (before the first cycle: among all), with
+// its record.
+struct __attribute__((aligned(16))) rest_t {
+    float value;            // -1: no such tile
+    int tile;
+    int y, x;
+    float pix[4];
+};
+static_assert(sizeof(rest_t) == 32, "two 16-byte accesses");
 
 struct fused_scratch {
     fused_state st[2];
     delta_t deltas[2][1024];
-    owner_best_t owner_best[1024];
+    rest_t rest[2];
+    owner3_t owner3[2][1024];
     // float tile_pix[tiles][4] follows
 };
+
+__device__ inline bool better_tile(float va, int ta, float vb, int tb)
+{
+    return va > vb || (va == vb && ta < tb);
+}
 
 // The tiles owned by thread (b, a) = (tid >> 5, tid & 31) of a 1024-thread block: (ty, tx) with
 // ty % 32 == b and tx % 32 == a, visited as "slots" = 32x32-tile groups in row-major order (i.e.
@@ -525,11 +540,18 @@ struct owned_tiles {
         return i;
     }
 
-    // The best two owned tiles, with tile `ptile` (if >= 0) taking the value `pvalue` instead of
-    // the stored one.
-    __device__ owner_best_t best(const float *tile_max, int ptile, float pvalue)
+    // The best three owned tiles, with tile `ptile` (if >= 0) taking the value `pvalue` instead of
+    // the stored one.  All of a round's loads are issued together; slots come in increasing tile
+    // order, so strict comparisons keep the lowest index among equals.
+    __device__ owner3_t best(const float *tile_max, int ptile, float pvalue)
     {
-        owner_best_t b = {-1.0f, 0, -1.0f, 0};
+        owner3_t b;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            b.v[k] = -1.0f;
+            b.t[k] = 0;
+        }
+        b.pad[0] = b.pad[1] = 0;
         for (int r = 0; r * FUSED_ROUND < slots; r++) {
             int ti[FUSED_ROUND];
             float v[FUSED_ROUND];
@@ -539,19 +561,25 @@ struct owned_tiles {
                 ti[k] = next(ok[k]);
                 v[k] = tile_max[ti[k]];
             }
-            // slots come in increasing tile order, so a strict comparison keeps the lowest index
 #pragma unroll
             for (int k = 0; k < FUSED_ROUND; k++) {
                 const float val = ti[k] == ptile ? pvalue : v[k];
                 if (r * FUSED_ROUND + k < slots && ok[k]) {
-                    if (val > b.v1) {
-                        b.v2 = b.v1;
-                        b.t2 = b.t1;
-                        b.v1 = val;
-                        b.t1 = ti[k];
-                    } else if (val > b.v2) {
-                        b.v2 = val;
-                        b.t2 = ti[k];
+                    if (val > b.v[0]) {
+                        b.v[2] = b.v[1];
+                        b.t[2] = b.t[1];
+                        b.v[1] = b.v[0];
+                        b.t[1] = b.t[0];
+                        b.v[0] = val;
+                        b.t[0] = ti[k];
+                    } else if (val > b.v[1]) {
+                        b.v[2] = b.v[1];
+                        b.t[2] = b.t[1];
+                        b.v[1] = val;
+                        b.t[1] = ti[k];
+                    } else if (val > b.v[2]) {
+                        b.v[2] = val;
+                        b.t[2] = ti[k];
                     }
                 }
             }
@@ -559,6 +587,20 @@ struct owned_tiles {
         return b;
     }
 };
+
+// (the whole-loop kernel further down keeps an owner's best two in registers)
+struct owner_best_t {
+    float v1;
+    int t1;
+    float v2;
+    int t2;
+};
+
+__device__ inline owner_best_t best_two(const owner3_t &b)
+{
+    owner_best_t o = {b.v[0], b.t[0], b.v[1], b.t[1]};
+    return o;
+}
 
 __device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *tile_pos,
                                    float *tile_pix)
@@ -573,15 +615,20 @@ __device__ inline void apply_delta(const delta_t &d, float *tile_max, int32_t *t
 
 #ifdef KIMG_CLEAN_STAMPS
 #define STAMP(i) do { if (bid == 0 && tid == 0) stamps[i] = (int) wall_clock64(); } while (0)
+#define KSTAMP(i) do { if (role == ROLE_KEEPER && tid == 0) stamps[i] = (int) wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define KSTAMP(i) do { } while (0)
 #endif
 
+constexpr int ROLE_LATTICE = 0, ROLE_KEEPER = 1, ROLE_FOLDER = 2;
+
 // The kernel is one chain of dependent steps executed once, so what counts is the latency of
-// every step on the chain (global round trips ~0.8 us, LDS round trips and barriers ~0.1 us),
-// not throughput: reductions use DPP and one LDS exchange, state words travel as one 16-byte load.
+// every step on the chain (global round trips ~0.8 us, LDS round trips and barriers ~0.1 us, and --
+// with sixteen waves on a CU -- 0.75 us per hundred instructions of per-thread work), not
+// throughput: reductions use DPP and one LDS exchange, state words travel as one 16-byte load.
 // The cycle of one channel, executed by the workgroup that serves lattice block (blk_x, blk_y) of
-// its PSF patch, or by the channel's bookkeeping workgroup (`keeper`).  Two kernels call it: one
+// its PSF patch, or by one of the channel's two bookkeeping workgroups.  Two kernels call it: one
 // channel per launch (cycle_fused_kernel) and several channels per launch (cycle_fused_batch_kernel).
 template <int MODE>
 __device__ __attribute__((always_inline)) inline void fused_cycle(
@@ -589,7 +636,7 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
     int P, const float *__restrict__ psf, int64_t psf_row_stride, int64_t psf_pol_stride,
     int psf_w, int psf_h, int patch_w, int patch_h, int border, float *tile_max,
     int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain,
-    fused_scratch *scratch, int parity, float *log, int blk_x, int blk_y, bool keeper)
+    fused_scratch *scratch, int parity, float *log, int blk_x, int blk_y, int role)
 {
     __shared__ key_t s_keys[16];
     __shared__ int s_pos[2];
@@ -600,79 +647,100 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
     delta_t *dout = scratch->deltas[parity ^ 1];
     float *tile_pix = reinterpret_cast<float *>(scratch + 1);
     const int tid = threadIdx.x;
+    const bool keeper = role == ROLE_KEEPER;
 #ifdef KIMG_CLEAN_STAMPS
-    const int bid = (!keeper && blk_x == 0 && blk_y == 0) ? 0 : 1;   // stamps: one lattice block
+    const int bid = (role == ROLE_LATTICE && blk_x == 0 && blk_y == 0) ? 0 : 1;   // stamps: one lattice block
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
+    KSTAMP(0);
 
-    // ---- round trip 1: state, this thread's delta, this thread's best tiles ------------------
-    // Thread (b, a) owns the tiles with (ty % 32, tx % 32) = (b, a) (`owned_tiles`).  A PSF patch
-    // spans fewer than 32 tiles either way, so a cycle rewrites at most one tile per owner: the
-    // delta table has one slot per thread and needs no search, and `owner_best` (each owner's best
-    // two tiles) turns into the owner's candidate without touching the tile maxima.
+    // ---- round trip 1: state, best of the rest, the records the last cycle rewrote ----------------
     const int4 st = *reinterpret_cast<const int4 *>(cur);      // count, done, limit, threshold
     const int count = st.x, done = st.y, limit = st.z;
     const float threshold = __int_as_float(st.w);
-    const delta_t d = din[tid];
-    const owner_best_t ob = load_owner_best(&scratch->owner_best[tid]);
+    const int lat_x = (patch_w + TILE - 1) / TILE + 1, lat_y = (patch_h + TILE - 1) / TILE + 1;
+    const bool slot = (tid & 31) < lat_x && (tid >> 5) < lat_y;
+    delta_t d;
+    d.tag = 0;
+    if (slot)
+        d = din[tid];
+    const rest_t rest = scratch->rest[parity];
     if (done) {
         if (keeper && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, st.w);
         return;
     }
-    const bool live = d.tag == count + 1;
-    const int ptile = live ? d.tile : -1;
+    const bool live = slot && d.tag == count + 1;
     STAMP(1);
-    float bv = ob.v1;
-    int bi = ob.t1;
-    if (live) {
-        // best of the owner's other tiles, then the rewritten one against it
-        const bool first = ob.t1 == d.tile && ob.v1 >= 0.0f;
-        const float ov = first ? ob.v2 : ob.v1;
-        const int ot = first ? ob.t2 : ob.t1;
-        const bool take = ov < 0.0f || d.value > ov || (d.value == ov && d.tile < ot);
-        bv = take ? d.value : ov;
-        bi = take ? d.tile : ot;
+    // The bookkeeping workgroups get the last cycle's records by OWNER through LDS (a second copy of
+    // the table in memory, indexed by owner, was measured: 48 KB more to fetch cold cost more than
+    // the two barriers), and their owners' best three -- 32 KB, requested only now, so that the
+    // state and the deltas do not queue behind them; they arrive during the reduction below.
+    __shared__ delta_t s_delta[1024];
+    delta_t mine;           // the last cycle's record of the one tile of THIS owner it rewrote, if any
+    mine.tag = 0;
+    int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
+    if (role != ROLE_LATTICE) {
+        s_delta[tid].tag = 0;
+        lds_barrier();
+        if (live)
+            s_delta[d.owner] = d;
+        lds_barrier();
+        mine = s_delta[tid];
+        const int4 *p3 = reinterpret_cast<const int4 *>(&scratch->owner3[parity][tid]);
+        w0 = p3[0];
+        w1 = p3[1];
     }
-    if (keeper && __any(live)) {
-        // off the critical path of the lattice workgroups: fold the previous cycle's records into
-        // the base arrays (readers of this launch override those entries with the deltas, so it
-        // does not matter which version they see) and bring the owners' best-two up to date
-        owned_tiles walk(tid, tiles_x, tiles_y);
-        const owner_best_t nb = walk.best(tile_max, ptile, d.value);
-        if (live) {
+    const bool pending = mine.tag == count + 1;
+    if (role == ROLE_FOLDER) {
+        owner3_t own3;
+        own3.v[0] = __int_as_float(w0.x);
+        own3.v[1] = __int_as_float(w0.y);
+        own3.v[2] = __int_as_float(w0.z);
+        own3.t[0] = w0.w;
+        own3.t[1] = w1.x;
+        own3.t[2] = w1.y;
+        // Nobody waits for this workgroup within the launch.  Base arrays: the records of the last
+        // cycle; owners' table: the exact best three of every owner up to the last cycle, into the
+        // copy the next launch's keeper reads.
+        if (live)
             apply_delta(d, tile_max, tile_pos, tile_pix);
-            store_owner_best(&scratch->owner_best[tid], nb);
+        if (pending) {
+            owned_tiles walk(tid, tiles_x, tiles_y);
+            own3 = walk.best(tile_max, mine.tile, mine.value);
         }
+        int4 *q3 = reinterpret_cast<int4 *>(&scratch->owner3[parity ^ 1][tid]);
+        q3[0] = make_int4(__float_as_int(own3.v[0]), __float_as_int(own3.v[1]),
+                          __float_as_int(own3.v[2]), own3.t[0]);
+        q3[1] = make_int4(own3.t[1], own3.t[2], 0, 0);
+        return;
     }
-    // The record of this thread's candidate is fetched now, before it is known whether the
-    // candidate wins: the loads overlap the block reduction instead of following it.
-    const bool mine_delta = bi == ptile;
-    int2 cpos = make_int2(d.y, d.x);
-    float4 cpix = make_float4(d.pix[0], d.pix[1], d.pix[2], d.pix[3]);
-    if (bv >= 0.0f && !mine_delta) {
-        cpos = *reinterpret_cast<const int2 *>(tile_pos + 2 * bi);
-        cpix = *reinterpret_cast<const float4 *>(tile_pix + 4 * bi);
-    }
-    const key_t mykey = bv < 0.0f ? 0 : make_key(bv, bi);
-    const key_t best = block_max_key(mykey, s_keys);
+    KSTAMP(1);
+    const key_t mykey = live ? make_key(d.value, d.tile) : 0;
+    // (a barrier that orders LDS only: the keeper's table loads are still in flight)
+    key_t best = block_max_key_lds(mykey, s_keys);
+    // (the rest never contains a tile that has a delta: keys of different tiles differ)
+    const key_t rest_key = rest.value >= 0.0f ? make_key(rest.value, rest.tile) : 0;
+    const bool from_rest = rest_key > best;
+    if (from_rest)
+        best = rest_key;
     STAMP(2);
+    KSTAMP(2);
     const float value = __uint_as_float((unsigned) (best >> 32));
     if (best == 0 || value < threshold || count >= limit) {     // clean.py:1065-1066
         if (keeper && tid == 0)
             *reinterpret_cast<int4 *>(next) = make_int4(count, 1, limit, st.w);
         return;
     }
-    if (mykey == best) {        // exactly one thread: every tile has one owner
-        s_pos[0] = cpos.x;
-        s_pos[1] = cpos.y;
-        s_pix[0] = cpix.x;
-        s_pix[1] = cpix.y;
-        s_pix[2] = cpix.z;
-        s_pix[3] = cpix.w;
+    if (from_rest ? tid == 0 : mykey == best) {     // exactly one thread
+        s_pos[0] = from_rest ? rest.y : d.y;
+        s_pos[1] = from_rest ? rest.x : d.x;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            s_pix[p] = from_rest ? rest.pix[p] : d.pix[p];
     }
-    __syncthreads();
+    lds_barrier();
     const int py = s_pos[0], px = s_pos[1];
     if (value == 0.0f) {
         // a tile without any positive metric won: its record holds the (x0, y0) start position
@@ -689,11 +757,80 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
     for (int p = 0; p < 4; p++)
         scale[p] = loop_gain * s_pix[p];                            // clean.py:1044
     STAMP(3);
+    const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
+    // floor division: the lattice extends into the border with negative indices
+    const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
+    const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
     if (keeper) {
+        owner3_t own3;
+        own3.v[0] = __int_as_float(w0.x);
+        own3.v[1] = __int_as_float(w0.y);
+        own3.v[2] = __int_as_float(w0.z);
+        own3.t[0] = w0.w;
+        own3.t[1] = w1.x;
+        own3.t[2] = w1.y;
+        // (the model pixel is fetched now and used at the very end: its round trip must not hold
+        // the first wave, and with it the reduction below, back)
+        float *mp = model + (tid < P ? tid : 0) * pol_stride + (int64_t) py * row_stride + px;
+        float mod = 0.0f;
+        if (tid < P)
+            mod = *mp;
+        // The best of the rest for the NEXT launch: the best tile outside THIS cycle's lattice.  An
+        // owner's candidates are its best three up to the cycle before last, with the tile the last
+        // cycle rewrote (if any) at its new value, without the one tile of its own that this
+        // cycle's lattice contains: whatever two of them are set aside, a tile of the three
+        // remains, and no other tile of the owner is better than it.
+        const int txc = bx0 + (((tid & 31) - bx0) & 31), tyc = by0 + (((tid >> 5) - by0) & 31);
+        const bool in_lattice = txc < bx0 + lat_x && tyc < by0 + lat_y && txc >= 0 && txc < tiles_x
+                                && tyc >= 0 && tyc < tiles_y;
+        const int excluded = in_lattice ? tyc * tiles_x + txc : -1;
+        const int ptile = pending ? mine.tile : -1;
+        float cv = -1.0f;
+        int ct = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (own3.v[k] >= 0.0f && own3.t[k] != ptile && own3.t[k] != excluded
+                && (cv < 0.0f || better_tile(own3.v[k], own3.t[k], cv, ct))) {
+                cv = own3.v[k];
+                ct = own3.t[k];
+            }
+        if (pending && ptile != excluded && (cv < 0.0f || better_tile(mine.value, ptile, cv, ct))) {
+            cv = mine.value;
+            ct = ptile;
+        }
+        // the candidate's record is fetched before it is known whether the candidate wins: the
+        // load overlaps the block reduction instead of following it (the record of the tile the
+        // last cycle rewrote is in `mine`: the folder may not have stored it yet)
+        int2 cpos = make_int2(mine.y, mine.x);
+        float4 cpix = make_float4(mine.pix[0], mine.pix[1], mine.pix[2], mine.pix[3]);
+        if (cv >= 0.0f && ct != ptile) {
+            cpos = *reinterpret_cast<const int2 *>(tile_pos + 2 * ct);
+            cpix = *reinterpret_cast<const float4 *>(tile_pix + 4 * ct);
+        }
+        const key_t ckey = cv >= 0.0f ? make_key(cv, ct) : 0;
+        KSTAMP(3);
+        // (barriers that order LDS only: __syncthreads() would wait for the record loads)
+        lds_barrier();                          // (s_keys is free again)
+        const key_t rbest = block_max_key_lds(ckey, s_keys);
+        KSTAMP(4);
+        rest_t *rout = &scratch->rest[parity ^ 1];
+        if (rbest == 0) {
+            if (tid == 0)
+                rout->value = -1.0f;
+        } else if (ckey == rbest) {
+            rest_t r;
+            r.value = cv;
+            r.tile = ct;
+            r.y = cpos.x;
+            r.x = cpos.y;
+            r.pix[0] = cpix.x;
+            r.pix[1] = cpix.y;
+            r.pix[2] = cpix.z;
+            r.pix[3] = cpix.w;
+            *rout = r;
+        }
         if (tid < P) {
             float *entry = log + (int64_t) count * (3 + P);
-            float *mp = model + tid * pol_stride + (int64_t) py * row_stride + px;
-            const float mod = *mp;
             if (tid == 0) {
                 entry[0] = value;
                 entry[1] = __int_as_float(py);
@@ -703,13 +840,18 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
             entry[3 + tid] = scale[tid];
             *mp = mod + scale[tid];                                 // clean.py:1047
         }
+#ifdef KIMG_CLEAN_STAMPS
+        if (cpix.x == 12345.678f)
+            stamps[7] = 1;                      // (forces the record load to complete before the stamp)
+        KSTAMP(5);
+        if (tid == 0)
+            for (int i = 0; i < 6; i++)
+                next->pad[6 + i] = stamps[i];
+#endif
         return;
     }
 
-    // ---- round trip 3: this block's pixels -----------------------------------------------
-    const int x0 = px - patch_w / 2, y0 = py - patch_h / 2;      // clean.py:1024-1027
-    const int bx0 = (x0 - border) >= 0 ? (x0 - border) / TILE : -((border - x0 + TILE - 1) / TILE);
-    const int by0 = (y0 - border) >= 0 ? (y0 - border) / TILE : -((border - y0 + TILE - 1) / TILE);
+    // ---- round trip 2: this block's pixels -----------------------------------------------
     const int tx = bx0 + blk_x, ty = by0 + blk_y;
     const int ox = tx * TILE + border, oy = ty * TILE + border;
     const int psf_dx = psf_w / 2 - px, psf_dy = psf_h / 2 - py;
@@ -753,7 +895,7 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
 #ifdef KIMG_CLEAN_STAMPS
     STAMP(5);
     if (bid == 0 && tid == 0)
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 6; i++)
             next->pad[i] = stamps[i];
 #endif
     if (tb == 0 ? tid == 0 : tid == widx) {
@@ -777,7 +919,9 @@ __device__ __attribute__((always_inline)) inline void fused_cycle(
             for (int p = 0; p < 4; p++)
                 o.pix[p] = dv[p];
         }
-        dout[(ty & 31) * 32 + (tx & 31)] = o;
+        o.owner = (ty & 31) * 32 + (tx & 31);
+        o.pad[0] = o.pad[1] = 0;
+        dout[blk_y * 32 + blk_x] = o;
     }
 }
 
@@ -789,20 +933,23 @@ __global__ __launch_bounds__(1024) void cycle_fused_kernel(
     int32_t *tile_pos, int tiles_x, int tiles_y, float loop_gain,
     fused_scratch *scratch, int parity, float *log)
 {
-    // The last row of the grid holds the one workgroup that does the bookkeeping instead of a
-    // lattice block (its other members have nothing to do).
-    const bool keeper = blockIdx.y == gridDim.y - 1;
-    if (keeper && blockIdx.x != 0)
-        return;
+    // The FIRST row of the grid (dispatched first) holds the two bookkeeping workgroups instead of
+    // lattice blocks (its other members have nothing to do; a lattice is at least two blocks wide).
+    int role = ROLE_LATTICE;
+    if (blockIdx.y == 0) {
+        if (blockIdx.x > 1)
+            return;
+        role = blockIdx.x == 0 ? ROLE_KEEPER : ROLE_FOLDER;
+    }
     fused_cycle<MODE>(dirty, model, row_stride, pol_stride, width, height, P, psf, psf_row_stride,
                       psf_pol_stride, psf_w, psf_h, patch_w, patch_h, border, tile_max, tile_pos,
                       tiles_x, tiles_y, loop_gain, scratch, parity, log, (int) blockIdx.x,
-                      (int) blockIdx.y, keeper);
+                      (int) blockIdx.y - 1, role);
 }
 
 // ---- several channels per launch -------------------------------------------------------------
-// A minor cycle is a latency chain (kernel boundary 2.1 us + cold first load 1 us + ~3 us of
-// dependent work) that occupies ~30 of the 256 CUs.  Channels of a band are independent and have
+// A minor cycle is a latency chain (kernel boundary 2.1 us + ~3 us of dependent work) that
+// occupies 32 of the 256 CUs.  Channels of a band are independent and have
 // images of the same shape, so cycle i of up to KIMG_CLEAN_BATCH_MAX channels runs as ONE launch:
 // blockIdx.z is the channel, whose pointers, patch size and (through its own state words)
 // threshold, cycle limit and stop flag are its own; a finished channel's workgroups return after
@@ -828,14 +975,14 @@ __global__ __launch_bounds__(1024) void cycle_fused_batch_kernel(
     int64_t psf_row_stride, int64_t psf_pol_stride, int psf_w, int psf_h, int border, int tiles_x,
     int tiles_y, float loop_gain, int parity)
 {
-    // grid = (largest number of lattice blocks of any channel + 1, 1, channels): block 0 of a
-    // channel keeps its books, blocks 1 .. bx * by serve its lattice row by row; no workgroup is
+    // grid = (largest number of lattice blocks of any channel + 2, 1, channels): blocks 0 and 1 of a
+    // channel keep its books, blocks 2 .. bx * by + 1 serve its lattice row by row; no workgroup is
     // launched only to find that it has nothing to do unless the channels' patches differ in size
-    // (8 channels with the 6 x 5 lattice blocks of a 133 x 111 patch are 248 workgroups: one per CU)
+    // (8 channels with the 6 x 5 lattice blocks of a 133 x 111 patch are 256 workgroups: one per CU)
     const batch_channel &ch = tab.ch[blockIdx.z];
     const int bx = (ch.patch_w + TILE - 1) / TILE + 1, by = (ch.patch_h + TILE - 1) / TILE + 1;
-    const bool keeper = blockIdx.x == 0;
-    int blk_x = (int) blockIdx.x - 1, blk_y = 0;
+    const int role = blockIdx.x == 0 ? ROLE_KEEPER : blockIdx.x == 1 ? ROLE_FOLDER : ROLE_LATTICE;
+    int blk_x = (int) blockIdx.x - 2, blk_y = 0;
     if (blk_x >= bx * by)
         return;
     while (blk_x >= bx) {           // (uniform; at most 31 rounds, typically < 6)
@@ -845,7 +992,7 @@ __global__ __launch_bounds__(1024) void cycle_fused_batch_kernel(
     fused_cycle<MODE>(ch.dirty, ch.model, row_stride, pol_stride, width, height, P, ch.psf,
                       psf_row_stride, psf_pol_stride, psf_w, psf_h, ch.patch_w, ch.patch_h, border,
                       ch.tile_max, ch.tile_pos, tiles_x, tiles_y, loop_gain, ch.scratch, parity,
-                      ch.log, blk_x, blk_y, keeper);
+                      ch.log, blk_x, blk_y, role);
 }
 
 // ---- the whole minor-cycle loop in ONE launch ----------------------------------------------
@@ -952,7 +1099,7 @@ __global__ __launch_bounds__(1024) void cycle_persistent_kernel(
     owner_best_t ob;
     {
         owned_tiles walk(tid, tiles_x, tiles_y);
-        ob = walk.best(s_tile_max, -1, 0.0f);
+        ob = best_two(walk.best(s_tile_max, -1, 0.0f));
     }
     // (position, peak pixels) of this owner's best tile, kept in registers: the peak search then
     // needs no memory access at all
@@ -1046,7 +1193,7 @@ __global__ __launch_bounds__(1024) void cycle_persistent_kernel(
                         tile_pix[4 * d.tile + p] = d.pix[p];
                 }
                 owned_tiles walk(tid, tiles_x, tiles_y);
-                ob = walk.best(s_tile_max, -1, 0.0f);
+                ob = best_two(walk.best(s_tile_max, -1, 0.0f));
                 if (ob.v1 >= 0.0f) {
                     if (ob.t1 == d.tile) {
                         best_rec.y = d.y;
@@ -1670,13 +1817,36 @@ __global__ __launch_bounds__(256) void tile_pix_kernel(
         tile_pix[4 * t + p] = (ok && p < P) ? dirty[p * pol_stride + (int64_t) y * row_stride + x] : 0.0f;
 }
 
-// Every owner's best tile (see cycle_fused_kernel); once per kimg_clean_cycles call.
+// Every owner's best three tiles (into the copy of the table the first launch's keeper reads) and
+// the best tile of all with its record, the first launch's `rest` (see fused_cycle); once per
+// kimg_clean_cycles call, after tile_pix_kernel.
 __global__ __launch_bounds__(1024) void owner_best_kernel(const float *__restrict__ tile_max,
+                                                          const int32_t *__restrict__ tile_pos,
                                                           int tiles_x, int tiles_y,
                                                           fused_scratch *scratch)
 {
+    __shared__ key_t s_keys[16];
+    const float *tile_pix = reinterpret_cast<const float *>(scratch + 1);
     owned_tiles walk(threadIdx.x, tiles_x, tiles_y);
-    scratch->owner_best[threadIdx.x] = walk.best(tile_max, -1, 0.0f);
+    const owner3_t b = walk.best(tile_max, -1, 0.0f);
+    scratch->owner3[0][threadIdx.x] = b;
+    const key_t key = b.v[0] >= 0.0f ? make_key(b.v[0], b.t[0]) : 0;
+    const key_t best = block_max_key(key, s_keys);
+    rest_t *rout = &scratch->rest[0];
+    if (best == 0) {
+        if (threadIdx.x == 0)
+            rout->value = -1.0f;
+    } else if (key == best) {
+        rest_t r;
+        r.value = b.v[0];
+        r.tile = b.t[0];
+        r.y = tile_pos[2 * b.t[0]];
+        r.x = tile_pos[2 * b.t[0] + 1];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            r.pix[p] = tile_pix[4 * b.t[0] + p];
+        *rout = r;
+    }
 }
 
 // Fold the deltas of the last cycle into the base tile arrays (the state left by an even number
@@ -1950,7 +2120,7 @@ struct cycle_args {
 int enqueue_cycle(const cycle_args &a, hipStream_t s, int index)
 {
     if (a.batch > 0) {
-        const dim3 gb(a.batch_blocks + 1, 1, a.batch);          // + the bookkeeping workgroup
+        const dim3 gb(a.batch_blocks + 2, 1, a.batch);          // + the two bookkeeping workgroups
         if (a.mode == KIMG_CLEAN_I)
             cycle_fused_batch_kernel<KIMG_CLEAN_I><<<gb, 1024, 0, s>>>(
                 a.tab, a.row_stride, a.pol_stride, a.width, a.height, a.P, a.psf_row_stride,
@@ -2190,7 +2360,7 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
         return kimg_launch_status();
     }
     if (fused)
-        owner_best_kernel<<<1, 1024, 0, s>>>(tile_max, tiles_x, tiles_y,
+        owner_best_kernel<<<1, 1024, 0, s>>>(tile_max, tile_pos, tiles_x, tiles_y,
                                              static_cast<fused_scratch *>(state));
     cycle_args a;
     memset(&a, 0, sizeof(a));       // padding bytes take part in the cache key comparison
@@ -2297,7 +2467,7 @@ extern "C" int kimg_clean_cycles_batch(const kimg_clean_channel *channels_in, in
         tile_pix_kernel<<<kimg_divup(tiles_x * tiles_y, 256), 256, 0, s>>>(
             ch.dirty, row_stride, pol_stride, width, height, num_polarizations, ch.tile_pos,
             tiles_x * tiles_y, static_cast<fused_scratch *>(ch.state));
-        owner_best_kernel<<<1, 1024, 0, s>>>(ch.tile_max, tiles_x, tiles_y,
+        owner_best_kernel<<<1, 1024, 0, s>>>(ch.tile_max, ch.tile_pos, tiles_x, tiles_y,
                                              static_cast<fused_scratch *>(ch.state));
     }
     int rc = kimg_launch_status();
