@@ -125,7 +125,7 @@ class NoiseEst(accel.Operation):
 
     The reference's GPU class bisects the float bit pattern to ~1e-4 relative accuracy with
     ~30 ranking passes; this one finds the EXACT median (as the reference's host path,
-    clean.py:938-943) with a 4-pass byte-wise radix select plus one counting pass.
+    clean.py:938-943) with a 4-pass byte-wise radix select that resolves the two middle ranks side by side.
     Slots: **dirty** [P][H][W]; **rank** uint32 [256] (histogram scratch).
     """
 

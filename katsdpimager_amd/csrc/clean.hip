@@ -1892,13 +1892,10 @@ __global__ __launch_bounds__(256) void psf_patch_kernel(
 // ---- noise estimate: radix select on the bit pattern of |x| ------------------------------
 __global__ __launch_bounds__(256) void abs_histogram_kernel(
     const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
-    int height, int P, int border, int pass, uint32_t prefix, uint32_t *__restrict__ hist,
-    const uint32_t *__restrict__ dev_prefix)
+    int height, int P, int border, int pass, uint32_t prefix, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t local[256];
     local[threadIdx.x] = 0;
-    if (dev_prefix)
-        prefix = *dev_prefix;       // (kimg_noise_est: the prefix is chosen on the device)
     __syncthreads();
     const int shift = 8 * pass;
     // Run-length accumulation: in the first pass (sign-less exponent byte) nearly every pixel
@@ -1945,11 +1942,8 @@ __global__ __launch_bounds__(256) void abs_histogram_kernel(
 
 __global__ __launch_bounds__(256) void abs_count_le_kernel(
     const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
-    int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out,
-    const uint32_t *__restrict__ dev_value)
+    int height, int P, int border, uint32_t value_bits, uint32_t *__restrict__ out)
 {
-    if (dev_value)
-        value_bits = *dev_value;
     uint32_t count = 0, next = 0xffffffffu;
     constexpr int ROWS = 8;
     const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
@@ -2520,8 +2514,7 @@ extern "C" int kimg_abs_histogram(const float *image, int64_t row_stride, int64_
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
     abs_histogram_kernel<<<region_grid(width - 2 * border, height - 2 * border, 2048), 256, 0, s>>>(
-        image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist,
-        nullptr);
+        image, row_stride, pol_stride, width, height, num_polarizations, border, pass, prefix, hist);
     return kimg_launch_status();
 }
 
@@ -2539,58 +2532,166 @@ extern "C" int kimg_abs_count_le(const float *image, int64_t row_stride, int64_t
     const uint32_t bits = conv.u;
     abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 4096), 256, 0, s>>>(
         image, row_stride, pol_stride, width, height, num_polarizations, border,
-        bits & 0x7fffffffu, out, nullptr);
+        bits & 0x7fffffffu, out);
     return kimg_launch_status();
 }
 
 // ---- whole noise estimate without host round trips ------------------------------------------
 namespace {
 
+// The two middle ranks ((n-1)/2 and n/2: the same element for odd n) are resolved side by side,
+// so the upper one costs no pass of its own: while both still lie behind the same bytes one
+// histogram serves the pair, and from the pass after they part each has its own.
+// Workgroups add their histogram into one of NOISE_SLOTS copies: atomics on one address are
+// served one after the other (~30 ns each), and 2048 workgroups behind the same few bins of the
+// exponent byte were most of a pass.
+constexpr int NOISE_SLOTS = 32;
 struct noise_state {
-    uint32_t prefix;        // bytes of the k-th smallest |x| chosen so far
-    uint32_t k;             // rank still to resolve inside the current prefix
-    uint32_t count_le;      // number of |x| <= lower median (kimg_abs_count_le's out[0])
-    uint32_t next_bits;     // smallest |x| above it
-    uint32_t hist[256];
+    uint32_t prefix[2];     // bytes of the rank's |x| chosen so far
+    uint32_t k[2];          // rank still to resolve inside the current prefix
+    uint32_t hist[2][NOISE_SLOTS][256];
 };
 
-// Pick the byte whose bin holds rank k, descend into it, clear the histogram for the next pass.
-__global__ __launch_bounds__(256) void radix_select_kernel(noise_state *st)
+// One radix-select pass over the interior: histogram of byte `pass` of |x|'s bit pattern among
+// the pixels whose higher bytes equal the rank's prefix.  TOP: the first pass (the sign-less
+// exponent byte, every pixel counts).
+template<bool TOP>
+__global__ __launch_bounds__(256) void abs_histogram2_kernel(
+    const float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width,
+    int height, int P, int border, int pass, noise_state *__restrict__ st)
+{
+    __shared__ uint32_t local[2][256];
+    local[0][threadIdx.x] = 0;
+    local[1][threadIdx.x] = 0;
+    const uint32_t prefix0 = st->prefix[0], prefix1 = st->prefix[1];
+    const bool split = !TOP && prefix0 != prefix1;
+    __syncthreads();
+    const int shift = TOP ? 24 : 8 * pass;
+    // TOP: the exponent byte of a noise-like image takes three or four neighbouring values, and
+    // 64 LDS atomics on one address are served one after the other; each thread counts the four
+    // values up to the largest of its wave's first row in registers instead (anything else --
+    // an image with a wide dynamic range -- still goes to the LDS histogram directly).
+    uint32_t base = 0, near[4] = {0, 0, 0, 0};
+    bool have_base = false;
+    constexpr int ROWS = 4;
+    const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool x_ok = x < width - border;
+    for (int p = 0; p < P; p++)
+        for (int y0 = border + blockIdx.y; y0 < height - border; y0 += gridDim.y * ROWS) {
+            uint32_t keys[ROWS];
+            bool ok[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + r * gridDim.y;
+                ok[r] = x_ok && y < height - border;
+                keys[r] = ok[r] ? __float_as_uint(image[p * pol_stride + (int64_t) y * row_stride + x])
+                                      & 0x7fffffffu : 0u;
+            }
+            if (TOP && !have_base) {
+                base = ok[0] ? keys[0] >> 24 : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    base = max(base, (uint32_t) __shfl_xor((int) base, off, WAVE));
+                have_base = true;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const uint32_t key = keys[r];
+                const uint32_t bin = (key >> shift) & 255u;
+                if (TOP) {
+                    const uint32_t d = base - bin;
+                    if (ok[r]) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            near[j] += d == (uint32_t) j;
+                        if (d > 3u)
+                            atomicAdd(&local[0][bin], 1u);
+                    }
+                } else {
+                    const uint32_t upper = key >> (shift + 8);
+                    // a mantissa byte: the bins of neighbouring pixels differ
+                    if (ok[r] && upper == prefix0)
+                        atomicAdd(&local[0][bin], 1u);
+                    if (split && ok[r] && upper == prefix1)
+                        atomicAdd(&local[1][bin], 1u);
+                }
+            }
+        }
+    if (TOP) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (near[j])
+                atomicAdd(&local[0][base - j], near[j]);
+    }
+    __syncthreads();
+    const int slot = (blockIdx.y * gridDim.x + blockIdx.x) % NOISE_SLOTS;
+    if (local[0][threadIdx.x])
+        atomicAdd(&st->hist[0][slot][threadIdx.x], local[0][threadIdx.x]);
+    if (local[1][threadIdx.x])
+        atomicAdd(&st->hist[1][slot][threadIdx.x], local[1][threadIdx.x]);
+}
+
+// Pick, for each of the two ranks, the byte whose bin holds it, descend into it, clear the
+// histograms for the next pass.
+__global__ __launch_bounds__(256) void radix_select2_kernel(noise_state *st, bool last,
+                                                            float median_to_rms, float *out)
 {
     __shared__ uint32_t cum[256];
     const int t = threadIdx.x;
-    const uint32_t mine = st->hist[t];
-    cum[t] = mine;
+    const bool split = st->prefix[0] != st->prefix[1];
+    const uint32_t k[2] = {st->k[0], st->k[1]};
+    const uint32_t prefix[2] = {st->prefix[0], st->prefix[1]};
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = t >= off ? cum[t - off] : 0;
-        __syncthreads();
-        cum[t] += add;
-        __syncthreads();
+    uint32_t total[2] = {0, 0};
+    for (int r = 0; r < 2; r++)
+        for (int slot = 0; slot < NOISE_SLOTS; slot++) {
+            total[r] += st->hist[r][slot][t];
+            st->hist[r][slot][t] = 0;
+        }
+    for (int r = 0; r < 2; r++) {
+        if (r == 0 || split) {
+            const uint32_t mine = total[r];
+            __syncthreads();
+            cum[t] = mine;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                const uint32_t add = t >= off ? cum[t - off] : 0;
+                __syncthreads();
+                cum[t] += add;
+                __syncthreads();
+            }
+        }
+        const uint32_t mine = total[split ? r : 0];
+        const uint32_t below = cum[t] - mine;
+        if (below <= k[r] && k[r] < cum[t]) {       // exactly one bin
+            st->k[r] = k[r] - below;
+            st->prefix[r] = (prefix[r] << 8) | (uint32_t) t;
+        }
     }
-    const uint32_t k = st->k, prefix = st->prefix;
-    const uint32_t below = cum[t] - mine;
-    __syncthreads();
-    st->hist[t] = 0;
-    if (below <= k && k < cum[t]) {         // exactly one bin
-        st->k = k - below;
-        st->prefix = (prefix << 8) | (uint32_t) t;
-        st->count_le = 0;
-        st->next_bits = 0xffffffffu;
+    if (last) {
+        __threadfence_block();
+        __syncthreads();
+        if (t == 0) {
+            const volatile uint32_t *chosen = st->prefix;
+            const float lo = __uint_as_float(chosen[0]);
+            const float hi = __uint_as_float(chosen[1]);
+            const float median = (lo + hi) / 2.0f;      // np.median of float32 data (clean.py:942)
+            *out = median * median_to_rms;
+        }
     }
 }
 
-__global__ void noise_init_kernel(noise_state *st, uint32_t k) { st->k = k; }
-
-__global__ void noise_result_kernel(const noise_state *st, uint32_t n, float median_to_rms,
-                                    float *out)
+// Clear the histograms and set the two ranks.
+__global__ __launch_bounds__(1024) void noise_init_kernel(noise_state *st, uint32_t k0, uint32_t k1)
 {
-    const float lo = __uint_as_float(st->prefix);
-    float hi = lo;
-    if (n % 2 == 0 && st->count_le <= n / 2)   // the upper middle element is the next value up
-        hi = __uint_as_float(st->next_bits);
-    const float median = (lo + hi) / 2.0f;      // np.median of float32 data (clean.py:942)
-    *out = median * median_to_rms;
+    uint32_t *words = &st->hist[0][0][0];
+    for (int i = threadIdx.x; i < 2 * NOISE_SLOTS * 256; i += blockDim.x)
+        words[i] = 0;
+    if (threadIdx.x == 0) {
+        st->prefix[0] = st->prefix[1] = 0;
+        st->k[0] = k0;
+        st->k[1] = k1;
+    }
 }
 
 } // namespace
@@ -2608,19 +2709,16 @@ extern "C" int kimg_noise_est(const float *image, int64_t row_stride, int64_t po
     const uint32_t n = (uint32_t) n64;
     hipStream_t s = (hipStream_t) stream;
     noise_state *st = static_cast<noise_state *>(scratch);
-    KIMG_HIP(hipMemsetAsync(st, 0, sizeof(noise_state), s));
-    noise_init_kernel<<<1, 1, 0, s>>>(st, (n - 1) / 2);      // lower median, clean.py:938-943
+    noise_init_kernel<<<1, 1024, 0, s>>>(st, (n - 1) / 2, n / 2);    // the middle pair, clean.py:938-943
     const dim3 gh = region_grid(width - 2 * border, height - 2 * border, 2048);
     for (int pass = 3; pass >= 0; pass--) {
-        abs_histogram_kernel<<<gh, 256, 0, s>>>(image, row_stride, pol_stride, width, height,
-                                                num_polarizations, border, pass, 0, st->hist,
-                                                &st->prefix);
-        radix_select_kernel<<<1, 256, 0, s>>>(st);
+        if (pass == 3)
+            abs_histogram2_kernel<true><<<gh, 256, 0, s>>>(
+                image, row_stride, pol_stride, width, height, num_polarizations, border, pass, st);
+        else
+            abs_histogram2_kernel<false><<<gh, 256, 0, s>>>(
+                image, row_stride, pol_stride, width, height, num_polarizations, border, pass, st);
+        radix_select2_kernel<<<1, 256, 0, s>>>(st, pass == 0, median_to_rms, out);
     }
-    if (n % 2 == 0)
-        abs_count_le_kernel<<<region_grid(width - 2 * border, height - 2 * border, 4096), 256, 0, s>>>(
-            image, row_stride, pol_stride, width, height, num_polarizations, border, 0,
-            &st->count_le, &st->prefix);
-    noise_result_kernel<<<1, 1, 0, s>>>(st, n, median_to_rms, out);
     return kimg_launch_status();
 }

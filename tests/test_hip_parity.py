@@ -1566,9 +1566,22 @@ def test_noise_est_device_selection(H, W, P, border):
     from katsdpimager_amd import clean
     ctx, q = context_queue()
     rs = np.random.RandomState(H * 7 + W + P)
-    for case in range(4):
+    for case in range(7):
         img = rs.standard_normal((P, H, W)).astype(np.float32)
-        if case == 1:
+        if case == 4:
+            # the two middle elements part at the first byte: exactly half of the interior is zero
+            bp = int(round(border * min(H, W)))
+            inner = img[:, bp:H - bp, bp:W - bp]
+            flat = np.abs(inner).ravel() + np.float32(1e3)
+            flat[rs.permutation(flat.size)[:flat.size // 2]] = 0.0
+            inner[...] = flat.reshape(inner.shape)
+        elif case == 5:
+            img[...] = np.float32(-2.5)                # one value only
+        elif case == 6:
+            # ... and at the last byte: two neighbouring bit patterns, half and half
+            vals = np.array([1.0, np.nextafter(np.float32(1.0), np.float32(2.0))], np.float32)
+            img = vals[rs.randint(0, 2, img.shape)] * rs.choice([-1, 1], img.shape).astype(np.float32)
+        elif case == 1:
             img = np.round(img * 3) / 3               # many exact ties around the median
         elif case == 2:
             img[rs.random_sample(img.shape) < 0.6] = 0.0       # the median itself is zero
