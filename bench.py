@@ -1111,6 +1111,18 @@ def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm, reader):
         out['four_channels_%d_in_flight_clean_batches' % workers] = [
             list(b) for b in frontend.process_channel_stream.last_batches]
     out['four_channels_minor_cycles'] = [int(r['minor']) for r in res]
+    # A longer stream (12 channels, one imager per worker thread), channels in step against taking
+    # turns at the throughput-bound stages (CleanBatcher phased): wall time per channel.
+    for workers in (2, 4):
+        for stagger in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            frontend.process_channel_stream(lambda channel, worker: jobs[worker], range(12),
+                                            workers=workers, stagger=stagger)
+            torch.cuda.synchronize()
+            out['stream_12_channels_%d_in_flight_%s_ms_per_channel' % (
+                workers, 'turns' if stagger else 'in_step')] = round(
+                    (time.perf_counter() - t0) * 1e3 / 12, 2)
     return out
 
 

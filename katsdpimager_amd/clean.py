@@ -558,27 +558,75 @@ class CleanBatcher:
     have reached theirs (or ``timeout`` seconds have passed: nobody waits for a channel that
     has no cycles to run in this major cycle); the channels present are then CLEANed together with
     :func:`enqueue_cycles_batch`, each thread reads its own results back.  ``parties`` = channels in
-    flight; a thread that will not come back calls :meth:`leave`."""
+    flight; a thread that will not come back calls :meth:`leave`.
 
-    def __init__(self, parties, timeout=0.02):
+    ``phased``: the threads also pass their throughput-bound stages (weights, gridding, FFTs,
+    prediction) through :meth:`device_phase`, one channel at a time.  Channels that all start at
+    once otherwise stay in step for good -- they share the device while gridding, reach CLEAN
+    together, and the device idles through the latency-bound cycles of all of them; taking turns
+    puts one channel's gridding next to the others' cycles.  The rendezvous then waits only for
+    the threads that are on their way from a device phase to their cycles (not for one that is
+    gridding, loading or CLEANing), and with ``overlap`` a batch does not wait for the batch
+    before it either (each runs on the stream of its first channel).
+    """
+
+    def __init__(self, parties, timeout=0.02, phased=False, overlap=True):
         import threading
         self._cond = threading.Condition()
         self._parties = int(parties)
         self._timeout = float(timeout)
         self._waiting = []
+        self.phased = bool(phased)
+        self._overlap = bool(overlap)
+        self._phase_lock = threading.Lock()
+        self._expected = set()      # threads between the end of a device phase and their cycles
+        self._cleaning = 0          # channels whose cycles are running
         #: (number of channels, cycles asked for) of every launch sequence so far, for tests / reports
         self.batches = []
 
     def leave(self):
+        import threading
         with self._cond:
             self._parties -= 1
-            if self._waiting and len(self._waiting) >= self._parties:
-                self._launch()
+            self._expected.discard(threading.get_ident())
             self._cond.notify_all()
 
+    def idle(self):
+        """The calling thread is not on its way to its cycles (its channel is finished)."""
+        import threading
+        with self._cond:
+            self._expected.discard(threading.get_ident())
+            self._cond.notify_all()
+
+    def device_phase(self):
+        """Context manager around a throughput-bound stage: one channel at a time."""
+        import contextlib
+        import threading
+
+        @contextlib.contextmanager
+        def phase():
+            me = threading.get_ident()
+            with self._cond:
+                self._expected.discard(me)
+                self._cond.notify_all()     # (nobody waits for a thread that is gridding)
+            with self._phase_lock:
+                try:
+                    yield
+                finally:
+                    with self._cond:
+                        self._expected.add(me)
+        return phase()
+
+    def _may_launch(self):
+        """With the lock held: is there nobody left to wait for?"""
+        if self.phased:
+            return not self._expected and (self._overlap or not self._cleaning)
+        return len(self._waiting) >= self._parties
+
     def _launch(self):
-        """With the lock held: enqueue everything that is waiting."""
+        """With the lock held (released while the device works): run everything that is waiting."""
         entries, self._waiting = self._waiting, []
+        self._cleaning += len(entries)
         groups = {}
         for e in entries:
             if batch_supported(e['clean'], e['patch']):
@@ -586,25 +634,40 @@ class CleanBatcher:
             else:
                 e['solo'] = True
         from . import _lib
+        parts = []
         for group in groups.values():
             for i in range(0, len(group), _lib.CLEAN_BATCH_MAX):
                 part = group[i:i + _lib.CLEAN_BATCH_MAX]
                 if len(part) == 1:
                     part[0]['solo'] = True
-                    continue
+                else:
+                    parts.append(part)
+        for e in entries:
+            if e['solo']:
+                e['ready'] = True       # (runs in its own thread, next to the batches)
+        self._cond.notify_all()
+        self._cond.release()
+        try:
+            for part in parts:
                 try:
-                    # (the host waits for the batch here, with the other threads parked: see
+                    # (the host waits for the batch here, with its threads parked: see
                     # enqueue_cycles_batch for why their queues are not made to wait instead)
                     enqueue_cycles_batch([e['clean'] for e in part], [e['patch'] for e in part],
                                          [e['threshold'] for e in part],
                                          [e['max_cycles'] for e in part],
                                          part[0]['clean'].command_queue).finish()
-                    self.batches.append((len(part), max(e['max_cycles'] for e in part)))
+                    part[0]['batch'] = (len(part), max(e['max_cycles'] for e in part))
                 except Exception as exc:        # noqa: B902 -- handed to the threads concerned
                     for e in part:
                         e['error'] = exc
-        for e in entries:
-            e['ready'] = True
+        finally:
+            self._cond.acquire()
+        for part in parts:
+            if 'batch' in part[0]:
+                self.batches.append(part[0]['batch'])
+            self._cleaning -= len(part)
+            for e in part:
+                e['ready'] = True
         self._cond.notify_all()
 
     def run_cycles(self, clean, psf_patch, threshold, max_cycles, arrays=False):
@@ -615,24 +678,32 @@ class CleanBatcher:
         if max_cycles <= 0:
             return (np.zeros(0, np.float32), np.zeros((0, 2), np.int32),
                     np.zeros((0, clean.buffer('dirty').shape[0]), np.float32)) if arrays else []
+        import threading
         entry = dict(clean=clean, patch=psf_patch, threshold=threshold, max_cycles=max_cycles,
                      ready=False, solo=False, error=None)
         with self._cond:
+            self._expected.discard(threading.get_ident())
             self._waiting.append(entry)
-            if len(self._waiting) >= self._parties:
-                self._launch()
+            self._cond.notify_all()
             deadline = time.monotonic() + self._timeout
             while not entry['ready']:
-                remaining = deadline - time.monotonic()
-                if remaining <= 0:
-                    if self._waiting and self._waiting[0] is entry:
-                        self._launch()          # the longest waiter stops waiting for the others
-                        break
-                    deadline = time.monotonic() + self._timeout
+                if self._waiting and self._waiting[0] is entry:
+                    # the longest waiter leads: when nobody is left to wait for, or after
+                    # `timeout` without the others
+                    remaining = deadline - time.monotonic()
+                    if self._may_launch() or remaining <= 0:
+                        self._launch()
+                        continue
+                else:
                     remaining = self._timeout
                 self._cond.wait(remaining)
         if entry['error'] is not None:
             raise entry['error']
         if entry['solo']:
-            clean.run_cycles(psf_patch, threshold, max_cycles, collect=False)
+            try:
+                clean.run_cycles(psf_patch, threshold, max_cycles, collect=False)
+            finally:
+                with self._cond:
+                    self._cleaning -= 1
+                    self._cond.notify_all()
         return clean._collect_cycle_arrays() if arrays else clean._collect_cycles()

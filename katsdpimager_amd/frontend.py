@@ -97,44 +97,64 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     """
     if not any(reader.len(rel_channel, s) for s in range(reader.num_w_slices(rel_channel))):
         return None
+    import contextlib
+    if clean_batcher is not None and getattr(clean_batcher, 'phased', False):
+        try:
+            # the channels in flight take turns at their throughput-bound stages
+            return _process_channel_stages(
+                reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type, vis_block,
+                major, degrid, subtract_model, batched_clean, fit_beam, clean_batcher,
+                clean_batcher.device_phase)
+        finally:
+            clean_batcher.idle()        # (nobody waits for this thread until its next stage)
+    return _process_channel_stages(
+        reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type, vis_block, major,
+        degrid, subtract_model, batched_clean, fit_beam, clean_batcher, contextlib.nullcontext)
+
+
+def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type,
+                            vis_block, major, degrid, subtract_model, batched_clean, fit_beam,
+                            clean_batcher, device_phase):
     num_pols = len(image_p.fixed.polarizations)
-    imager.clear_model()
-    with trace.range('make_weights'):
-        weights_noise, normalized_noise = make_weights(reader, rel_channel, imager, weight_type,
-                                                       vis_block)
-    mid_w = slice_mid_w(image_p, grid_p)
-    with trace.range('make_psf'):
-        make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
-    with trace.range('psf_patch'):
-        dirty = imager.buffer('dirty')
-        centre = dirty.shape[1] // 2
-        psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
-        dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
-        if np.any(psf_peak == 0):
-            return None
-        scale = np.reciprocal(psf_peak)
-        imager.scale_dirty(scale)
-        imager.dirty_to_psf()
-        psf_patch = imager.psf_patch()
-    out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
-               psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
-               peaks=[], noise=None)
-    if fit_beam:
-        from . import beam
-        psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
-        out['restoring_beam'] = beam.fit_beam(psf_core)
+    with device_phase():
+        imager.clear_model()
+        with trace.range('make_weights'):
+            weights_noise, normalized_noise = make_weights(reader, rel_channel, imager,
+                                                           weight_type, vis_block)
+        mid_w = slice_mid_w(image_p, grid_p)
+        with trace.range('make_psf'):
+            make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
+        with trace.range('psf_patch'):
+            dirty = imager.buffer('dirty')
+            centre = dirty.shape[1] // 2
+            psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
+            dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
+            if np.any(psf_peak == 0):
+                return None
+            scale = np.reciprocal(psf_peak)
+            imager.scale_dirty(scale)
+            imager.dirty_to_psf()
+            psf_patch = imager.psf_patch()
+        out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
+                   psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
+                   peaks=[], noise=None)
+        if fit_beam:
+            from . import beam
+            psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
+            out['restoring_beam'] = beam.fit_beam(psf_core)
     for i in range(major):
-        with trace.range('make_dirty[%d]' % i):
-            make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
-                       i != 0, subtract_model)
-        imager.scale_dirty(scale)
-        out['major'] += 1
-        with trace.range('noise_est'):
-            noise = imager.noise_est()
-        out['noise'] = noise
-        with trace.range('first_cycle'):
-            imager.clean_reset()
-            peak_value = imager.clean_cycle(psf_patch)
+        with device_phase():
+            with trace.range('make_dirty[%d]' % i):
+                make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
+                           i != 0, subtract_model)
+            imager.scale_dirty(scale)
+            out['major'] += 1
+            with trace.range('noise_est'):
+                noise = imager.noise_est()
+            out['noise'] = noise
+            with trace.range('first_cycle'):
+                imager.clean_reset()
+                peak_value = imager.clean_cycle(psf_patch)
         out['peaks'].append(peak_value)
         peak_power = clean.metric_to_power(clean_p.mode, peak_value)
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
@@ -203,7 +223,7 @@ def get_totals(queue, image, restoring_beam):
     return [float(x) / beam_area for x in sums.get(queue)]
 
 
-def process_channels(jobs, workers=2, batch_clean=True):
+def process_channels(jobs, workers=2, batch_clean=True, stagger=None):
     """Image several channels of one GPU concurrently, one host thread and one HIP stream
     (command queue) per channel in flight.
 
@@ -224,10 +244,10 @@ def process_channels(jobs, workers=2, batch_clean=True):
     if len(queues) != len(jobs):
         raise ValueError('concurrent channels need one command queue each')
     return process_channel_stream(lambda index: jobs[index], range(len(jobs)), workers=workers,
-                                  batch_clean=batch_clean)
+                                  batch_clean=batch_clean, stagger=stagger)
 
 
-def process_channel_stream(make_job, channels, workers=2, batch_clean=True):
+def process_channel_stream(make_job, channels, workers=2, batch_clean=True, stagger=None):
     """Image ``channels`` (any number) with at most ``workers`` of them in flight AND in memory.
 
     :func:`process_channels` takes ready-made jobs, i.e. one imager per channel; a band of
@@ -256,7 +276,7 @@ def process_channel_stream(make_job, channels, workers=2, batch_clean=True):
     count = max(1, min(int(workers), len(channels)))
     batcher = None
     if batch_clean and count > 1:
-        batcher = clean.CleanBatcher(count)
+        batcher = clean.CleanBatcher(count, phased=bool(stagger))
 
     def work(worker):
         try:

@@ -769,6 +769,104 @@ def test_clean_batcher_rendezvous(monkeypatch):
     assert b2.run_cycles(FakeClean('w'), small, 0.0, 0) == []
 
 
+def test_clean_batcher_phased(monkeypatch):
+    """CleanBatcher(phased=True): the throughput-bound stages run one channel at a time
+    (device_phase), and the rendezvous waits only for threads on their way from such a stage to
+    their cycles -- not for one that is inside (or queueing for) a stage, nor for one that
+    declared itself idle."""
+    import threading
+    import time as _time
+    from katsdpimager_amd import clean
+    launched = []
+
+    class FakeClean:
+        def __init__(self, name):
+            self.name, self.command_queue = name, object()
+
+        def _batch_key(self):
+            return 'k'
+
+        def run_cycles(self, patch, threshold, max_cycles, collect=True):
+            launched.append(('solo', self.name))
+
+        def _collect_cycles(self):
+            return [self.name]
+
+    class FakeQueue:
+        def finish(self):
+            pass
+
+    def fake_enqueue(cleans, patches, thresholds, max_cycles, queue=None):
+        launched.append(('batch', tuple(sorted(c.name for c in cleans))))
+        return FakeQueue()
+    monkeypatch.setattr(clean, 'enqueue_cycles_batch', fake_enqueue)
+    monkeypatch.setattr(clean, 'batch_supported', lambda c, patch: True)
+    small = (1, 111, 133)
+    b = clean.CleanBatcher(2, timeout=5.0, phased=True)
+    inside, release, order = threading.Event(), threading.Event(), []
+
+    def gridding():
+        with b.device_phase():
+            order.append('a in')
+            inside.set()
+            release.wait(5)
+            order.append('a out')
+        b.run_cycles(FakeClean('a'), small, 0.0, 3)
+    ta = threading.Thread(target=gridding)
+    ta.start()
+    assert inside.wait(5)
+    # 'a' is inside its stage: 'b' does not wait for it (the timeout is 5 s)
+    t0 = _time.monotonic()
+    assert b.run_cycles(FakeClean('b'), small, 0.0, 3) == ['b']
+    assert _time.monotonic() - t0 < 2.0 and launched == [('solo', 'b')]
+    # the stages exclude each other
+    entered = []
+
+    def second_stage():
+        with b.device_phase():
+            entered.append(_time.monotonic())
+    tb = threading.Thread(target=second_stage)
+    tb.start()
+    _time.sleep(0.05)
+    assert not entered
+    release.set()
+    ta.join(5)
+    tb.join(5)
+    assert entered and not ta.is_alive() and not tb.is_alive()
+    assert launched[-1] == ('solo', 'a') and order == ['a in', 'a out']
+    # a thread that left a stage is waited for: the two share their launches
+    launched.clear()
+    out = {}
+
+    def staged(name, delay):
+        with b.device_phase():
+            pass
+        _time.sleep(delay)
+        out[name] = b.run_cycles(FakeClean(name), small, 0.0, 4)
+    threads = [threading.Thread(target=staged, args=(n, d)) for n, d in (('c', 0.0), ('d', 0.2))]
+    threads[1].start()          # 'd' is through its stage (and expected) before 'c' arrives
+    _time.sleep(0.05)
+    threads[0].start()
+    for t in threads:
+        t.join(5)
+        assert not t.is_alive()
+    assert launched == [('batch', ('c', 'd'))] and out == {'c': ['c'], 'd': ['d']}
+    assert b.batches == [(2, 4)]
+    # ... unless it says it is not coming
+    launched.clear()
+
+    def staged_then_idle():
+        with b.device_phase():
+            pass
+        b.idle()
+    t = threading.Thread(target=staged_then_idle)
+    t.start()
+    t.join(5)
+    t0 = _time.monotonic()
+    assert b.run_cycles(FakeClean('e'), small, 0.0, 2) == ['e']
+    assert _time.monotonic() - t0 < 2.0 and launched == [('solo', 'e')]
+
+
 def _loader_arrays(rows=600, channels=3, pols=2, antennas=5, seed=8):
     from katsdpimager_amd import loader, polarization
     rs = np.random.RandomState(seed)
