@@ -292,6 +292,24 @@ int kimg_image_to_real_layer(float *layer, int64_t layer_row_stride, const float
                              float lm_scale, float lm_bias, void *stream);
 int kimg_half_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
                             const void *half_layer, int layer_size, void *stream);
+/* The whole of GridToImage.__call__ / ImageToGrid.__call__ (image.py:609-673, :676-740) for one
+ * polarization at w = 0 in two launches, with transforms of the library's own (layer sizes that
+ * are powers of two, 16 .. 8192): only the Gg/2 + 1 columns of the half layer the grid reaches
+ * are transformed, the fold / padding and the image correction are the prologue and epilogue of
+ * the transform kernels, and what passes between the two launches is (Gg/2 + 1) x G cells in
+ * `workspace` (16-byte aligned, kimg_grid_image_real_workspace_bytes; the layer buffer will do).
+ * Results equal the route above up to the rounding of the transform.
+ *   kimg_grid_image_real_supported: 1 when the two functions take these sizes, else 0. */
+int kimg_grid_image_real_supported(int layer_size, int grid_size);
+size_t kimg_grid_image_real_workspace_bytes(int layer_size, int grid_size);
+int kimg_grid_to_image_real(float *image, int64_t image_row_stride, int layer_size,
+                            const void *grid, int64_t grid_row_stride, int grid_size,
+                            const float *kernel1d, float lm_scale, float lm_bias,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int grid_size,
+                            const float *image, int64_t image_row_stride, int layer_size,
+                            const float *kernel1d, float lm_scale, float lm_bias,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
  * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */

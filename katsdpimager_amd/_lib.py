@@ -47,6 +47,10 @@ PROTOTYPES = {
     'kimg_real_layer_to_image': (c_int, [P, L, P, L, I, P, F, F, P]),
     'kimg_image_to_real_layer': (c_int, [P, L, P, L, I, P, F, F, P]),
     'kimg_half_layer_to_grid': (c_int, [P, L, I, P, I, P]),
+    'kimg_grid_image_real_supported': (c_int, [I, I]),
+    'kimg_grid_image_real_workspace_bytes': (c_size_t, [I, I]),
+    'kimg_grid_to_image_real': (c_int, [P, L, I, P, L, I, P, F, F, P, c_size_t, P]),
+    'kimg_image_to_grid_real': (c_int, [P, L, I, P, L, I, P, F, F, P, c_size_t, P]),
     'kimg_layer_to_grid': (c_int, [P, L, I, P, I, P]),
     'kimg_layer_to_image': (c_int, [P, L, P, I, P, F, F, F, P]),
     'kimg_image_to_layer': (c_int, [P, P, L, I, P, F, F, F, P]),

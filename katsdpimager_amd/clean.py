@@ -414,11 +414,19 @@ class Clean(accel.OperationSequence):
         self.ensure_all_bound()
         self._find_peak()
         q = self.command_queue
-        peak_value = self.buffer('peak_value').get(q)
+        # value, position and pixel in one read-back (three would be three host round trips)
+        import torch
+        parts = [self.buffer(name) for name in ('peak_value', 'peak_pos', 'peak_pixel')]
+        for part in parts:
+            part.used_on(q)
+        with torch.cuda.stream(q.stream):
+            both = torch.cat([parts[0].tensor, parts[1].tensor.view(torch.float32),
+                              parts[2].tensor]).cpu().numpy()
+        peak_value = both[:1]
         if peak_value[0] < threshold:
             return None, None, None
-        peak_pos = tuple(int(x) for x in self.buffer('peak_pos').get(q))
-        peak_pixel = self.buffer('peak_pixel').get(q)
+        peak_pos = tuple(int(x) for x in both[1:3].view(np.int32))
+        peak_pixel = both[3:].copy()
         model_pixel = np.float32(self.template.clean_parameters.loop_gain) * peak_pixel
         self._subtract_psf(peak_pos, psf_patch)
         x0 = peak_pos[1] - psf_patch[2] // 2

@@ -33,15 +33,9 @@ __global__ __launch_bounds__(256) void grid_to_layer_kernel(
 // w = 0): Re F^-1[g] = F^-1[h] with h(k) = (g(k) + conj g(-k)) / 2, and h is Hermitian, so half
 // of it -- columns 0 .. G/2 -- feeds a complex-to-real transform of half the size (the
 // "opportunity" noted at image.py:561-566 of the reference).  half[ly][lx], row length G/2 + 1.
-__global__ __launch_bounds__(256) void grid_to_half_layer_kernel(
-    float2 *__restrict__ half_layer, int G, const float2 *__restrict__ grid,
-    int64_t grid_row_stride, int Gg)
+__device__ inline float2 half_layer_value(const float2 *__restrict__ grid, int64_t grid_row_stride,
+                                          int Gg, int G, int lx, int ly)
 {
-    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ly = blockIdx.y;
-    const int W = G / 2 + 1;
-    if (lx >= W)
-        return;
     const int half = Gg / 2;
     const int cx = lx < G - half ? lx : lx - G;
     const int cy = ly < G - half ? ly : ly - G;
@@ -55,7 +49,19 @@ __global__ __launch_bounds__(256) void grid_to_half_layer_kernel(
     const int my = mly < G - half ? mly : mly - G;
     if (mx >= -half && mx < half && my >= -half && my < half)
         b = grid[(int64_t) (my + half) * grid_row_stride + (mx + half)];
-    half_layer[(int64_t) ly * W + lx] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    return make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+}
+
+__global__ __launch_bounds__(256) void grid_to_half_layer_kernel(
+    float2 *__restrict__ half_layer, int G, const float2 *__restrict__ grid,
+    int64_t grid_row_stride, int Gg)
+{
+    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ly = blockIdx.y;
+    const int W = G / 2 + 1;
+    if (lx >= W)
+        return;
+    half_layer[(int64_t) ly * W + lx] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
 }
 
 __global__ __launch_bounds__(256) void layer_to_grid_kernel(
@@ -240,6 +246,222 @@ __global__ __launch_bounds__(256) void apply_primary_beam_kernel(
     int64_t addr = (int64_t) blockIdx.y * row_stride + x;
     for (int p = 0; p < num_pols; p++, addr += pol_stride)
         image[addr] = beam < threshold ? replacement : image[addr] / beam;
+}
+
+// ---- grid <-> image at w = 0 with transforms of our own ------------------------------------
+// The library route above is six launches (pad + fold, transpose, column transforms, transpose,
+// row transforms, image correction) over a layer of G x (G/2 + 1) cells, of which only the
+// (Gg/2 + 1) columns the grid reaches are not zero.  Here: one launch of column transforms for
+// those columns only, reading the grid directly (fold and padding on the fly), and one launch of
+// row transforms, two real rows per complex transform, with the image correction as its
+// epilogue; what passes between them is (Gg/2 + 1) x G cells (20 MB at 4096 / 1244).
+// Transforms: in-LDS radix-4 decimation in time (one radix-2 stage when log2 G is odd) on
+// bit-reversed input, one workgroup per transform, twiddles from a table.
+constexpr int FFT_THREADS = 256;
+
+__device__ inline float2 cmul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+__device__ inline int bit_reverse(int i, int log2G) { return (int) (__brev((unsigned) i) >> (32 - log2G)); }
+
+// tw[n] = e^{2 pi i n / G}, n < G / 2
+__global__ __launch_bounds__(256) void twiddle_kernel(float2 *__restrict__ tw, int G)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= G / 2)
+        return;
+    double s, c;
+    sincospi(2.0 * (double) n / (double) G, &s, &c);
+    tw[n] = make_float2((float) c, (float) s);
+}
+
+// x: G cells in bit-reversed order on entry, the transform (sign + for INVERSE, unnormalised) in
+// natural order on return.  Called by the whole workgroup; starts and ends with a barrier.
+template<bool INVERSE>
+__device__ inline void lds_fft(float2 *x, const float2 *tw, int G, int log2G)
+{
+    int q = 1, shift = 0;
+    for (; 4 * q <= G; q *= 4, shift += 2) {
+        __syncthreads();
+        const int step1 = G >> (shift + 1), step2 = G >> (shift + 2);
+        for (int t = threadIdx.x; t < G / 4; t += FFT_THREADS) {
+            const int j = t & (q - 1);
+            const int base = ((t >> shift) << (shift + 2)) + j;
+            float2 w1 = tw[j * step1], w2 = tw[j * step2];
+            if (!INVERSE) {
+                w1.y = -w1.y;
+                w2.y = -w2.y;
+            }
+            const float2 a0 = x[base], a1 = cmul(w1, x[base + q]);
+            const float2 a2 = x[base + 2 * q], a3 = cmul(w1, x[base + 3 * q]);
+            const float2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
+            const float2 b2 = cmul(w2, cadd(a2, a3));
+            const float2 t3 = cmul(w2, csub(a2, a3));
+            // the twiddle of the second pair is w2 times e^{+-i pi / 2}
+            const float2 b3 = INVERSE ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
+            x[base] = cadd(b0, b2);
+            x[base + 2 * q] = csub(b0, b2);
+            x[base + q] = cadd(b1, b3);
+            x[base + 3 * q] = csub(b1, b3);
+        }
+    }
+    if (q < G) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < G / 2; t += FFT_THREADS) {
+            float2 w = tw[t];
+            if (!INVERSE)
+                w.y = -w.y;
+            const float2 a0 = x[t], a1 = cmul(w, x[t + q]);
+            x[t] = cadd(a0, a1);
+            x[t + q] = csub(a0, a1);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ inline void fft_lds_setup(float2 *x, float2 *tw, const float2 *__restrict__ twiddle, int G,
+                                     bool clear)
+{
+    for (int i = threadIdx.x; i < G / 2; i += FFT_THREADS)
+        tw[i] = twiddle[i];
+    if (clear)
+        for (int i = threadIdx.x; i < G; i += FFT_THREADS)
+            x[i] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+}
+
+// Column lx of the half layer (never stored): T[lx][sy] = sum_ly half_layer[ly][lx] e^{2 pi i ly sy / G}
+__global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
+    float2 *__restrict__ T, const float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + G;
+    fft_lds_setup(x, tw, twiddle, G, true);
+    const int lx = blockIdx.x, half = Gg / 2;
+    // the rows the grid (or its mirror image) reaches: centred -half .. half
+    const int rows = 2 * half == G ? G : Gg + 1;
+    for (int r = threadIdx.x; r < rows; r += FFT_THREADS) {
+        const int cy = r - half;
+        const int ly = cy < 0 ? cy + G : cy;
+        x[bit_reverse(ly, log2G)] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
+    }
+    lds_fft<true>(x, tw, G, log2G);
+    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
+        T[(int64_t) lx * G + sy] = x[sy];
+}
+
+__device__ inline int fft_shift(int i, int half) { return i < half ? i + half : i - half; }
+
+// Rows sy1 = 2 * blockIdx.x and sy1 + 1 of the real transform: both Hermitian sequences in one
+// complex transform (z = row1 + i row2 comes out with row1 in its real part, row2 in its
+// imaginary part), then real_layer_to_image_kernel's arithmetic.
+__global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
+    float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    float lm_scale, float lm_bias)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + G;
+    fft_lds_setup(x, tw, twiddle, G, true);
+    const int sy1 = 2 * blockIdx.x, half = Gg / 2;
+    for (int n = threadIdx.x; n <= half; n += FFT_THREADS) {
+        // (t.x, t.y) = T[n][sy1], (t.z, t.w) = T[n][sy1 + 1]
+        const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + sy1);
+        if (n == 0 || 2 * n == G) {
+            x[bit_reverse(n, log2G)] = make_float2(t.x, t.z);       // (real up to rounding)
+        } else {
+            x[bit_reverse(n, log2G)] = make_float2(t.x - t.w, t.y + t.z);
+            x[bit_reverse(G - n, log2G)] = make_float2(t.x + t.w, t.z - t.y);
+        }
+    }
+    lds_fft<true>(x, tw, G, log2G);
+    const int hG = G / 2;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = fft_shift(sy1 + r, hG);
+        const float m = lm_coord(y, lm_scale, lm_bias);
+        const float m2 = m * m;
+        const float ky = kernel1d[y];
+        float *row = image + (int64_t) y * image_row_stride;
+        for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+            const int xx = fft_shift(sx, hG);
+            const float rotated = r ? x[sx].y : x[sx].x;
+            const float l = lm_coord(xx, lm_scale, lm_bias);
+            const float l2 = l * l;
+            const float n = sqrtf(1.0f - (m2 + l2));
+            const float taper = ky * kernel1d[xx];
+            row[xx] += (rotated * n) / taper;
+        }
+    }
+}
+
+// image -> grid, rows: two real layer rows (image_to_real_layer_kernel's arithmetic) as one
+// complex sequence, forward transform, the two half spectra taken apart;
+// T[lx][sy] for lx = 0 .. Gg / 2.
+__global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
+    float2 *__restrict__ T, const float *__restrict__ image, int64_t image_row_stride, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    float lm_scale, float lm_bias)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + G;
+    fft_lds_setup(x, tw, twiddle, G, false);
+    const int sy1 = 2 * blockIdx.x, half = Gg / 2, hG = G / 2;
+    const int y1 = fft_shift(sy1, hG), y2 = fft_shift(sy1 + 1, hG);
+    const float ma = lm_coord(y1, lm_scale, lm_bias), mb = lm_coord(y2, lm_scale, lm_bias);
+    const float ma2 = ma * ma, mb2 = mb * mb;
+    const float ka = kernel1d[y1], kb = kernel1d[y2];
+    for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+        const int xx = fft_shift(sx, hG);
+        const float l = lm_coord(xx, lm_scale, lm_bias);
+        const float l2 = l * l;
+        const float kx = kernel1d[xx];
+        const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
+        const float va = image[(int64_t) y1 * image_row_stride + xx] / ((ka * kx) * na);
+        const float vb = image[(int64_t) y2 * image_row_stride + xx] / ((kb * kx) * nb);
+        x[bit_reverse(sx, log2G)] = make_float2(va, vb);
+    }
+    lds_fft<false>(x, tw, G, log2G);
+    for (int lx = threadIdx.x; lx <= half; lx += FFT_THREADS) {
+        const float2 z = x[lx], zm = x[lx ? G - lx : 0];
+        // row a: (z + conj zm) / 2, row b: (z - conj zm) / 2i
+        const float4 out = make_float4(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y),
+                                       0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
+        *reinterpret_cast<float4 *>(T + (int64_t) lx * G + sy1) = out;
+    }
+}
+
+// image -> grid, columns: F[ly][lx] = sum_sy T[lx][sy] e^{-2 pi i ly sy / G}; grid column
+// half + lx from it, column half - lx from its mirror image (half_layer_to_grid_kernel).
+__global__ __launch_bounds__(FFT_THREADS) void i2g_columns_kernel(
+    float2 *__restrict__ grid, int64_t grid_row_stride, const float2 *__restrict__ T, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + G;
+    fft_lds_setup(x, tw, twiddle, G, false);
+    const int lx = blockIdx.x, half = Gg / 2;
+    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
+        x[bit_reverse(sy, log2G)] = T[(int64_t) lx * G + sy];
+    lds_fft<false>(x, tw, G, log2G);
+    for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS) {
+        const int cy = gy - half;
+        const int ly = cy < 0 ? cy + G : cy;
+        if (lx < half)
+            grid[(int64_t) gy * grid_row_stride + half + lx] = x[ly];
+        if (lx == half && 2 * half == G) {
+            grid[(int64_t) gy * grid_row_stride] = x[ly];       // the Nyquist column is its own mirror
+        } else if (lx > 0) {
+            const float2 v = x[ly ? G - ly : 0];
+            grid[(int64_t) gy * grid_row_stride + half - lx] = make_float2(v.x, -v.y);
+        }
+    }
 }
 
 } // namespace
@@ -494,5 +716,126 @@ extern "C" int kimg_image_nansum(const float *image, int64_t row_stride, int64_t
     int by = height < 128 ? height : 128;
     dim3 grid(kimg_divup(width, 256), by, num_polarizations);
     image_nansum_kernel<<<grid, 256, 0, s>>>(image, row_stride, pol_stride, width, height, sums);
+    return kimg_launch_status();
+}
+
+// ---- grid <-> image at w = 0, own transforms ------------------------------------------------
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct twiddle_entry { int device, size; float2 *table; };
+std::mutex twiddle_mutex;
+std::vector<twiddle_entry> twiddle_tables;
+
+// The table for transforms of G cells on the current device: made once (and the stream waited
+// for, so that every other stream may read it), never freed.
+int twiddle_table(int G, hipStream_t s, const float2 **out)
+{
+    int device = 0;
+    KIMG_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(twiddle_mutex);
+    for (const twiddle_entry &e : twiddle_tables)
+        if (e.device == device && e.size == G) {
+            *out = e.table;
+            return 0;
+        }
+    float2 *table = nullptr;
+    KIMG_HIP(hipMalloc((void **) &table, sizeof(float2) * (size_t) (G / 2)));
+    twiddle_kernel<<<kimg_divup(G / 2, 256), 256, 0, s>>>(table, G);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void) hipFree(table);
+        return -(int) e;
+    }
+    twiddle_tables.push_back(twiddle_entry{device, G, table});
+    *out = table;
+    return 0;
+}
+
+int fft_log2(int G)
+{
+    int k = 0;
+    while ((1 << k) < G)
+        k++;
+    return k;
+}
+
+template<typename Kernel>
+int fft_lds_attribute(Kernel kernel, size_t lds)
+{
+    if (lds > 64 * 1024)
+        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    return 0;
+}
+
+} // namespace
+
+extern "C" int kimg_grid_image_real_supported(int layer_size, int grid_size)
+{
+    return layer_size >= 16 && layer_size <= 8192 && (layer_size & (layer_size - 1)) == 0
+        && grid_size >= 2 && grid_size % 2 == 0 && grid_size <= layer_size;
+}
+
+extern "C" size_t kimg_grid_image_real_workspace_bytes(int layer_size, int grid_size)
+{
+    if (!kimg_grid_image_real_supported(layer_size, grid_size))
+        return 0;
+    return sizeof(float2) * (size_t) (grid_size / 2 + 1) * (size_t) layer_size;
+}
+
+extern "C" int kimg_grid_to_image_real(float *image, int64_t image_row_stride, int layer_size,
+                                       const void *grid, int64_t grid_row_stride, int grid_size,
+                                       const float *kernel1d, float lm_scale, float lm_bias,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    KIMG_CHECK_ARG(image && grid && kernel1d && workspace);
+    KIMG_CHECK_ARG(kimg_grid_image_real_supported(layer_size, grid_size));
+    KIMG_CHECK_ARG(image_row_stride >= layer_size && grid_row_stride >= grid_size);
+    KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_real_workspace_bytes(layer_size, grid_size));
+    KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
+    hipStream_t s = (hipStream_t) stream;
+    const int G = layer_size, log2G = fft_log2(G);
+    const float2 *tw = nullptr;
+    int rc = twiddle_table(G, s, &tw);
+    if (rc)
+        return rc;
+    const size_t lds = sizeof(float2) * (size_t) (G + G / 2);
+    if ((rc = fft_lds_attribute(&g2i_columns_kernel, lds)) || (rc = fft_lds_attribute(&g2i_rows_kernel, lds)))
+        return rc;
+    float2 *T = static_cast<float2 *>(workspace);
+    g2i_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
+        T, static_cast<const float2 *>(grid), grid_row_stride, grid_size, G, log2G, tw);
+    g2i_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
+        image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int grid_size,
+                                       const float *image, int64_t image_row_stride, int layer_size,
+                                       const float *kernel1d, float lm_scale, float lm_bias,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    KIMG_CHECK_ARG(image && grid && kernel1d && workspace);
+    KIMG_CHECK_ARG(kimg_grid_image_real_supported(layer_size, grid_size));
+    KIMG_CHECK_ARG(image_row_stride >= layer_size && grid_row_stride >= grid_size);
+    KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_real_workspace_bytes(layer_size, grid_size));
+    KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
+    hipStream_t s = (hipStream_t) stream;
+    const int G = layer_size, log2G = fft_log2(G);
+    const float2 *tw = nullptr;
+    int rc = twiddle_table(G, s, &tw);
+    if (rc)
+        return rc;
+    const size_t lds = sizeof(float2) * (size_t) (G + G / 2);
+    if ((rc = fft_lds_attribute(&i2g_rows_kernel, lds)) || (rc = fft_lds_attribute(&i2g_columns_kernel, lds)))
+        return rc;
+    float2 *T = static_cast<float2 *>(workspace);
+    i2g_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
+        T, image, image_row_stride, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+    i2g_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
+        static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, log2G, tw);
     return kimg_launch_status();
 }

@@ -286,14 +286,17 @@ class GridImageTemplate:
     (image.py:561-606).  The grid need not be Hermitian.
 
     ``tuning={'real_transform': False}`` switches off the complex-to-real route that grid -> image
-    takes for w = 0 (see :class:`GridToImage`)."""
+    takes for w = 0 (see :class:`GridToImage`); ``{'own_transform': False}`` keeps that route on
+    the library's 2-D plans where it would otherwise run the two-launch transforms of
+    ``kimg_grid_to_image_real`` / ``kimg_image_to_grid_real`` (layer sizes that are powers of two)."""
 
     def __init__(self, context, real_dtype, tuning=None):
         types.require_float32(real_dtype, 'GridImageTemplate')
         tuning = tuning or {}
-        if set(tuning) - {'real_transform'}:
+        if set(tuning) - {'real_transform', 'own_transform'}:
             raise ValueError('bad GridImageTemplate tuning {}'.format(tuning))
         self.real_transform = bool(tuning.get('real_transform', True))
+        self.own_transform = bool(tuning.get('own_transform', True))
         self.context = context
         self.real_dtype = np.dtype(real_dtype)
         self.layer_to_image = LayerToImageTemplate(context, real_dtype)
@@ -330,6 +333,13 @@ class _GridImage(accel.Operation):
     def set_w(self, w):
         self._layer_image.set_w(w)
 
+    def _own_transform(self):
+        """Whether the w = 0 route runs on the library's own transforms."""
+        G = self.buffer('layer').shape[0]
+        Gg = self.buffer('grid').shape[1]
+        return (self.template.real_transform and self.template.own_transform
+                and bool(lib().kimg_grid_image_real_supported(G, Gg)))
+
 
 class GridToImage(_GridImage):
     """Per polarization: centred grid -> corner-DC layer (zero padded), inverse FFT,
@@ -349,9 +359,17 @@ class GridToImage(_GridImage):
             # w = 0: the phase factor is 1 and only the real part of the transform is used, which
             # is the transform of the grid's Hermitian part: half the layer, a complex-to-real
             # transform in place (real rows of G + 2 floats), half the traffic all the way
-            self._real_plan = self._fft.real_plan()
             image = self.buffer('image')
             li = self._layer_image
+            if self._own_transform():
+                for pol in range(P):
+                    check(lib().kimg_grid_to_image_real(
+                        _pol_ptr(image, pol), G, G, _pol_ptr(grid, pol), Gg, Gg,
+                        self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias, layer.ptr,
+                        layer.tensor.numel() * layer.tensor.element_size(), q.handle),
+                        'kimg_grid_to_image_real')
+                return
+            self._real_plan = self._fft.real_plan()
             for pol in range(P):
                 check(lib().kimg_grid_to_half_layer(layer.ptr, G, _pol_ptr(grid, pol), Gg, Gg,
                                                     q.handle), 'kimg_grid_to_half_layer')
@@ -385,9 +403,17 @@ class ImageToGrid(_GridImage):
             # w = 0: the layer is real; real-to-complex transform in place, the grid's other half
             # from F(-k) = conj F(k)
             q = self.command_queue
-            self._real_plan = self._fft.real_plan()
             image = self.buffer('image')
             li = self._layer_image
+            if self._own_transform():
+                for pol in range(P):
+                    check(lib().kimg_image_to_grid_real(
+                        _pol_ptr(grid, pol), Gg, Gg, _pol_ptr(image, pol), G, G,
+                        self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias, layer.ptr,
+                        layer.tensor.numel() * layer.tensor.element_size(), q.handle),
+                        'kimg_image_to_grid_real')
+                return
+            self._real_plan = self._fft.real_plan()
             for pol in range(P):
                 check(lib().kimg_image_to_real_layer(
                     layer.ptr, G + 2, _pol_ptr(image, pol), G, G, self.buffer('kernel1d').ptr,

@@ -593,20 +593,16 @@ class Imaging(accel.OperationSequence):
         del self._pending_components[:]
         self._components = value
 
-    def _record(self, peak_pos, model_pixel):
-        comps = self._model_components
-        if peak_pos in comps:
-            comps[peak_pos] = comps[peak_pos] + model_pixel
-        else:
-            comps[peak_pos] = model_pixel
-
     @_serial
     def clean_cycle(self, psf_patch, threshold=0.0):
         """One minor cycle; returns the peak metric or None (imaging.py:389-396)."""
         self._ready()
         peak_value, peak_pos, model_pixel = self._clean(psf_patch, threshold)
         if peak_pos is not None:
-            self._record(peak_pos, model_pixel)
+            # (kept with the pending arrays: folding a thousand components of the last major
+            # cycle into the dictionary here would stall the first cycle of this one)
+            self._pending_components.append(
+                (np.array([peak_pos], np.int32), np.asarray(model_pixel)[np.newaxis]))
         return peak_value
 
     @_serial

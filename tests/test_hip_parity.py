@@ -624,23 +624,34 @@ def test_grid_to_image_smaller_grid():
     assert relerr(i2g.buffer('grid').get(q), gi.middle(full_grid, small.shape)) < 1e-5
 
 
+#: tuning of image.GridImageTemplate for the three routes grid <-> image has at w = 0
+_W0_ROUTES = {'own': {}, 'library': {'own_transform': False}, 'c2c': {'real_transform': False}}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('G,Gg,P', [(96, 40, 2), (64, 64, 1), (128, 126, 3), (4096, 2486, 1)])
+@pytest.mark.parametrize('G,Gg,P', [(96, 40, 2), (64, 64, 1), (128, 126, 3), (4096, 2486, 1),
+                                    (16, 2, 1), (16, 16, 2), (32, 6, 1), (512, 154, 2),
+                                    (2048, 620, 1), (2048, 2048, 1), (8192, 2486, 1)])
 def test_grid_to_image_real_transform_route(G, Gg, P):
     """w = 0: GridToImage takes the Hermitian part of the (zero-padded) grid through a
-    complex-to-real transform of half the size.  Against the oracle (= the reference's host path on
-    the padded grid) and against the complex-to-complex route of the same operator, with
-    accumulation; grids as large as the image (the -G/2 row and column have no mirror) and smaller."""
+    complex-to-real transform of half the size -- with the library's own two-launch transforms
+    where the layer size is a power of two ('own'), else on the FFT library's plan ('library').
+    Both against the oracle (= the reference's host path on the padded grid) and against the
+    complex-to-complex route of the same operator, with accumulation; grids as large as the image
+    (the -G/2 row and column have no mirror) and smaller, even and odd log2 of the size."""
     from katsdpimager_amd import image
+    from katsdpimager_amd._lib import lib
     ctx, q = context_queue()
     rs = gi.RandomState(G + Gg)
     small = rs.complex_uniform(-1, 1, (P, Gg, Gg)).astype(np.complex64)
     k1d = rs.uniform(1.0, 2.0, G).astype(np.float32)
     lm_scale = 0.3 / G
     lm_bias = -0.5 * G * lm_scale
+    own = bool(lib().kimg_grid_image_real_supported(G, Gg))
+    assert own == (G & (G - 1) == 0)
     got = {}
-    for real in (True, False):
-        template = image.GridImageTemplate(ctx, np.float32, {'real_transform': real})
+    for route, tuning in _W0_ROUTES.items():
+        template = image.GridImageTemplate(ctx, np.float32, tuning)
         g2i = template.instantiate_grid_to_image(q, (P, Gg, Gg), lm_scale, lm_bias,
                                                  template.make_fft_plan((G, G)))
         g2i.ensure_all_bound()
@@ -650,24 +661,28 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
         g2i.set_w(0.0)
         g2i()
         g2i()                                   # accumulates
-        got[real] = g2i.buffer('image').get(q)
-        assert (g2i._real_plan is not None) == real
-    peak = np.abs(got[False]).max()
-    assert np.abs(got[True] - got[False]).max() <= 2e-6 * peak
+        got[route] = g2i.buffer('image').get(q)
+        assert g2i._own_transform() == (own and route == 'own')
+        assert (g2i._real_plan is not None) == (route == 'library' or (route == 'own' and not own))
+        del g2i
+    peak = np.abs(got['c2c']).max()
+    for route in ('own', 'library'):
+        assert np.abs(got[route] - got['c2c']).max() <= 2e-6 * peak, route
     if G <= 128:
         full = np.zeros((P, G, G), np.complex64)
         gi.middle(full, small.shape)[:] = small
         expected = np.zeros((P, G, G), np.float32)
         orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, 0.0)
         orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, 0.0)
-        assert relerr(got[True], expected) < 1e-5
+        for route in ('own', 'library'):
+            assert relerr(got[route], expected) < 1e-5, route
     with pytest.raises(ValueError):
         image.GridImageTemplate(ctx, np.float32, {'real': True})
     # and back (ImageToGrid at w = 0: real layer, real-to-complex transform, F(-k) = conj F(k))
     model = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
     back = {}
-    for real in (True, False):
-        template = image.GridImageTemplate(ctx, np.float32, {'real_transform': real})
+    for route, tuning in _W0_ROUTES.items():
+        template = image.GridImageTemplate(ctx, np.float32, tuning)
         i2g = template.instantiate_image_to_grid(q, (P, Gg, Gg), lm_scale, lm_bias,
                                                  template.make_fft_plan((G, G)))
         i2g.ensure_all_bound()
@@ -676,13 +691,16 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
         i2g.buffer('grid').zero(q)
         i2g.set_w(0.0)
         i2g()
-        back[real] = i2g.buffer('grid').get(q)
-        assert (i2g._real_plan is not None) == real
-    peak = np.abs(back[False]).max()
-    assert np.abs(back[True] - back[False]).max() <= 2e-6 * peak
+        back[route] = i2g.buffer('grid').get(q)
+        assert (i2g._real_plan is not None) == (route == 'library' or (route == 'own' and not own))
+        del i2g
+    peak = np.abs(back['c2c']).max()
+    for route in ('own', 'library'):
+        assert np.abs(back[route] - back['c2c']).max() <= 2e-6 * peak, route
     if G <= 128:
         full_grid, _ = orc.image_to_grid(model, k1d, lm_scale, lm_bias, 0.0)
-        assert relerr(back[True], gi.middle(full_grid, small.shape)) < 1e-5
+        for route in ('own', 'library'):
+            assert relerr(back[route], gi.middle(full_grid, small.shape)) < 1e-5, route
 
 
 def test_image_streams():
