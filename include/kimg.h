@@ -298,13 +298,15 @@ int kimg_half_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
  * are transformed, the fold / padding and the image correction are the prologue and epilogue of
  * the transform kernels, and what passes between the two launches is (Gg/2 + 1) x G cells in
  * `workspace` (16-byte aligned, kimg_grid_image_real_workspace_bytes; the layer buffer will do).
- * Results equal the route above up to the rounding of the transform.
+ * Results equal the route above up to the rounding of the transform.  accumulate = 0: the image
+ * is written, not added to (what the reference gets by zeroing it first, imaging.py:258-261:
+ * saves the fill and the read).
  *   kimg_grid_image_real_supported: 1 when the two functions take these sizes, else 0. */
 int kimg_grid_image_real_supported(int layer_size, int grid_size);
 size_t kimg_grid_image_real_workspace_bytes(int layer_size, int grid_size);
 int kimg_grid_to_image_real(float *image, int64_t image_row_stride, int layer_size,
                             const void *grid, int64_t grid_row_stride, int grid_size,
-                            const float *kernel1d, float lm_scale, float lm_bias,
+                            const float *kernel1d, float lm_scale, float lm_bias, int accumulate,
                             void *workspace, size_t workspace_bytes, void *stream);
 int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int grid_size,
                             const float *image, int64_t image_row_stride, int layer_size,

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void apply_primary_beam_kernel(
 // epilogue; what passes between them is (Gg/2 + 1) x G cells (20 MB at 4096 / 1244).
 // Transforms: in-LDS radix-4 decimation in time (one radix-2 stage when log2 G is odd) on
 // bit-reversed input, one workgroup per transform, twiddles from a table.
-constexpr int FFT_THREADS = 256;
+constexpr int FFT_THREADS = 512;
+constexpr int FFT_UNROLL = 2;       // butterflies a thread has in flight (4096 cells: all it has)
 
 __device__ inline float2 cmul(float2 a, float2 b)
 {
@@ -269,14 +270,40 @@ __device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x
 
 __device__ inline int bit_reverse(int i, int log2G) { return (int) (__brev((unsigned) i) >> (32 - log2G)); }
 
-// tw[n] = e^{2 pi i n / G}, n < G / 2
+// LDS index of cell i: one cell of padding per 32, so that the strided accesses of the first
+// stages (and the bit-reversed scatter before them) spread over the banks.
+__device__ __host__ inline int fft_pad(int i) { return i + (i >> 5); }
+
+// Twiddles, one contiguous run per stage (a table indexed j * G / 4q would be read with strides
+// that put all 64 lanes on one bank): for the radix-4 stage of quarter length q = 1, 4, 16 ...
+// q cells e^{2 pi i j / 4q} from offset (q - 1) / 3 (the stage's other twiddle is their square),
+// and G / 2 cells e^{2 pi i j / G} for the radix-2 stage that ends an odd log2 G.
+__host__ __device__ inline int fft_twiddle_count(int G)
+{
+    int q = 1;
+    while (4 * q <= G)
+        q *= 4;
+    return (q - 1) / 3 + (q < G ? G / 2 : 0);
+}
+
 __global__ __launch_bounds__(256) void twiddle_kernel(float2 *__restrict__ tw, int G)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= G / 2)
+    if (n >= fft_twiddle_count(G))
         return;
+    int q = 1, offset = 0;
+    while (4 * q <= G && n >= offset + q) {
+        offset += q;
+        q *= 4;
+    }
+    double angle;
+    if (4 * q <= G) {
+        angle = (double) (n - offset) / (double) (4 * q);
+    } else {
+        angle = (double) (n - offset) / (double) G;
+    }
     double s, c;
-    sincospi(2.0 * (double) n / (double) G, &s, &c);
+    sincospi(2.0 * angle, &s, &c);
     tw[n] = make_float2((float) c, (float) s);
 }
 
@@ -288,27 +315,44 @@ __device__ inline void lds_fft(float2 *x, const float2 *tw, int G, int log2G)
     int q = 1, shift = 0;
     for (; 4 * q <= G; q *= 4, shift += 2) {
         __syncthreads();
-        const int step1 = G >> (shift + 1), step2 = G >> (shift + 2);
-        for (int t = threadIdx.x; t < G / 4; t += FFT_THREADS) {
-            const int j = t & (q - 1);
-            const int base = ((t >> shift) << (shift + 2)) + j;
-            float2 w1 = tw[j * step1], w2 = tw[j * step2];
-            if (!INVERSE) {
-                w1.y = -w1.y;
-                w2.y = -w2.y;
+        for (int t0 = threadIdx.x; t0 < G / 4; t0 += FFT_UNROLL * FFT_THREADS) {
+            float2 a[FFT_UNROLL][4], w2[FFT_UNROLL];
+            int at[FFT_UNROLL][4];
+#pragma unroll
+            for (int u = 0; u < FFT_UNROLL; u++) {
+                const int t = t0 + u * FFT_THREADS;
+                if (t < G / 4) {
+                    const int j = t & (q - 1);
+                    const int base = ((t >> shift) << (shift + 2)) + j;
+                    w2[u] = tw[j];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        at[u][k] = fft_pad(base + k * q);
+                        a[u][k] = x[at[u][k]];
+                    }
+                }
             }
-            const float2 a0 = x[base], a1 = cmul(w1, x[base + q]);
-            const float2 a2 = x[base + 2 * q], a3 = cmul(w1, x[base + 3 * q]);
-            const float2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
-            const float2 b2 = cmul(w2, cadd(a2, a3));
-            const float2 t3 = cmul(w2, csub(a2, a3));
-            // the twiddle of the second pair is w2 times e^{+-i pi / 2}
-            const float2 b3 = INVERSE ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
-            x[base] = cadd(b0, b2);
-            x[base + 2 * q] = csub(b0, b2);
-            x[base + q] = cadd(b1, b3);
-            x[base + 3 * q] = csub(b1, b3);
+#pragma unroll
+            for (int u = 0; u < FFT_UNROLL; u++) {
+                if (t0 + u * FFT_THREADS < G / 4) {
+                    if (!INVERSE)
+                        w2[u].y = -w2[u].y;
+                    const float2 w1 = cmul(w2[u], w2[u]);
+                    const float2 a0 = a[u][0], a1 = cmul(w1, a[u][1]);
+                    const float2 a2 = a[u][2], a3 = cmul(w1, a[u][3]);
+                    const float2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
+                    const float2 b2 = cmul(w2[u], cadd(a2, a3));
+                    const float2 t3 = cmul(w2[u], csub(a2, a3));
+                    // the twiddle of the second pair is w2 times e^{+-i pi / 2}
+                    const float2 b3 = INVERSE ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
+                    x[at[u][0]] = cadd(b0, b2);
+                    x[at[u][2]] = csub(b0, b2);
+                    x[at[u][1]] = cadd(b1, b3);
+                    x[at[u][3]] = csub(b1, b3);
+                }
+            }
         }
+        tw += q;
     }
     if (q < G) {
         __syncthreads();
@@ -316,23 +360,39 @@ __device__ inline void lds_fft(float2 *x, const float2 *tw, int G, int log2G)
             float2 w = tw[t];
             if (!INVERSE)
                 w.y = -w.y;
-            const float2 a0 = x[t], a1 = cmul(w, x[t + q]);
-            x[t] = cadd(a0, a1);
-            x[t + q] = csub(a0, a1);
+            const int i0 = fft_pad(t), i1 = fft_pad(t + q);
+            const float2 a0 = x[i0], a1 = cmul(w, x[i1]);
+            x[i0] = cadd(a0, a1);
+            x[i1] = csub(a0, a1);
         }
     }
     __syncthreads();
 }
 
+// LDS of the transform kernels: the (padded) cells, then the twiddles
+__host__ __device__ inline int fft_lds_cells(int G) { return fft_pad(G) + 1; }
+
 __device__ inline void fft_lds_setup(float2 *x, float2 *tw, const float2 *__restrict__ twiddle, int G,
                                      bool clear)
 {
-    for (int i = threadIdx.x; i < G / 2; i += FFT_THREADS)
+    const int count = fft_twiddle_count(G);
+    for (int i = threadIdx.x; i < count; i += FFT_THREADS)
         tw[i] = twiddle[i];
     if (clear)
-        for (int i = threadIdx.x; i < G; i += FFT_THREADS)
+        for (int i = threadIdx.x; i < fft_lds_cells(G); i += FFT_THREADS)
             x[i] = make_float2(0.0f, 0.0f);
     __syncthreads();
+}
+
+__device__ inline int fft_shift(int i, int half) { return i < half ? i + half : i - half; }
+
+// Workgroups are dealt to the 8 XCDs in turn; neighbouring rows share the cache lines of T (a
+// row pair is 16 bytes of each) and neighbouring columns those of the grid, so give every XCD
+// (and its L2) a contiguous run of them.
+__device__ inline int xcd_contiguous(int block, int blocks)
+{
+    const int xcd = block % 8, each = blocks / 8, extra = blocks % 8;
+    return xcd * each + min(xcd, extra) + block / 8;
 }
 
 // Column lx of the half layer (never stored): T[lx][sy] = sum_ly half_layer[ly][lx] e^{2 pi i ly sy / G}
@@ -341,43 +401,42 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
     int log2G, const float2 *__restrict__ twiddle)
 {
     extern __shared__ float2 fft_lds[];
-    float2 *x = fft_lds, *tw = fft_lds + G;
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, twiddle, G, true);
-    const int lx = blockIdx.x, half = Gg / 2;
+    const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     // the rows the grid (or its mirror image) reaches: centred -half .. half
     const int rows = 2 * half == G ? G : Gg + 1;
     for (int r = threadIdx.x; r < rows; r += FFT_THREADS) {
         const int cy = r - half;
         const int ly = cy < 0 ? cy + G : cy;
-        x[bit_reverse(ly, log2G)] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
+        x[fft_pad(bit_reverse(ly, log2G))] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
     }
     lds_fft<true>(x, tw, G, log2G);
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        T[(int64_t) lx * G + sy] = x[sy];
+        T[(int64_t) lx * G + sy] = x[fft_pad(sy)];
 }
-
-__device__ inline int fft_shift(int i, int half) { return i < half ? i + half : i - half; }
 
 // Rows sy1 = 2 * blockIdx.x and sy1 + 1 of the real transform: both Hermitian sequences in one
 // complex transform (z = row1 + i row2 comes out with row1 in its real part, row2 in its
 // imaginary part), then real_layer_to_image_kernel's arithmetic.
+template<bool ACCUMULATE>
 __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
     float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
     int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias)
 {
     extern __shared__ float2 fft_lds[];
-    float2 *x = fft_lds, *tw = fft_lds + G;
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, twiddle, G, true);
-    const int sy1 = 2 * blockIdx.x, half = Gg / 2;
+    const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int n = threadIdx.x; n <= half; n += FFT_THREADS) {
         // (t.x, t.y) = T[n][sy1], (t.z, t.w) = T[n][sy1 + 1]
         const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + sy1);
         if (n == 0 || 2 * n == G) {
-            x[bit_reverse(n, log2G)] = make_float2(t.x, t.z);       // (real up to rounding)
+            x[fft_pad(bit_reverse(n, log2G))] = make_float2(t.x, t.z);       // (real up to rounding)
         } else {
-            x[bit_reverse(n, log2G)] = make_float2(t.x - t.w, t.y + t.z);
-            x[bit_reverse(G - n, log2G)] = make_float2(t.x + t.w, t.z - t.y);
+            x[fft_pad(bit_reverse(n, log2G))] = make_float2(t.x - t.w, t.y + t.z);
+            x[fft_pad(bit_reverse(G - n, log2G))] = make_float2(t.x + t.w, t.z - t.y);
         }
     }
     lds_fft<true>(x, tw, G, log2G);
@@ -391,12 +450,13 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
         float *row = image + (int64_t) y * image_row_stride;
         for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
             const int xx = fft_shift(sx, hG);
-            const float rotated = r ? x[sx].y : x[sx].x;
+            const float rotated = r ? x[fft_pad(sx)].y : x[fft_pad(sx)].x;
             const float l = lm_coord(xx, lm_scale, lm_bias);
             const float l2 = l * l;
             const float n = sqrtf(1.0f - (m2 + l2));
             const float taper = ky * kernel1d[xx];
-            row[xx] += (rotated * n) / taper;
+            const float v = (rotated * n) / taper;
+            row[xx] = ACCUMULATE ? row[xx] + v : v;
         }
     }
 }
@@ -410,9 +470,9 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
     float lm_scale, float lm_bias)
 {
     extern __shared__ float2 fft_lds[];
-    float2 *x = fft_lds, *tw = fft_lds + G;
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, twiddle, G, false);
-    const int sy1 = 2 * blockIdx.x, half = Gg / 2, hG = G / 2;
+    const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
     const int y1 = fft_shift(sy1, hG), y2 = fft_shift(sy1 + 1, hG);
     const float ma = lm_coord(y1, lm_scale, lm_bias), mb = lm_coord(y2, lm_scale, lm_bias);
     const float ma2 = ma * ma, mb2 = mb * mb;
@@ -425,11 +485,11 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
         const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
         const float va = image[(int64_t) y1 * image_row_stride + xx] / ((ka * kx) * na);
         const float vb = image[(int64_t) y2 * image_row_stride + xx] / ((kb * kx) * nb);
-        x[bit_reverse(sx, log2G)] = make_float2(va, vb);
+        x[fft_pad(bit_reverse(sx, log2G))] = make_float2(va, vb);
     }
     lds_fft<false>(x, tw, G, log2G);
     for (int lx = threadIdx.x; lx <= half; lx += FFT_THREADS) {
-        const float2 z = x[lx], zm = x[lx ? G - lx : 0];
+        const float2 z = x[fft_pad(lx)], zm = x[fft_pad(lx ? G - lx : 0)];
         // row a: (z + conj zm) / 2, row b: (z - conj zm) / 2i
         const float4 out = make_float4(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y),
                                        0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
@@ -444,21 +504,21 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_columns_kernel(
     int log2G, const float2 *__restrict__ twiddle)
 {
     extern __shared__ float2 fft_lds[];
-    float2 *x = fft_lds, *tw = fft_lds + G;
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, twiddle, G, false);
-    const int lx = blockIdx.x, half = Gg / 2;
+    const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        x[bit_reverse(sy, log2G)] = T[(int64_t) lx * G + sy];
+        x[fft_pad(bit_reverse(sy, log2G))] = T[(int64_t) lx * G + sy];
     lds_fft<false>(x, tw, G, log2G);
     for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS) {
         const int cy = gy - half;
         const int ly = cy < 0 ? cy + G : cy;
         if (lx < half)
-            grid[(int64_t) gy * grid_row_stride + half + lx] = x[ly];
+            grid[(int64_t) gy * grid_row_stride + half + lx] = x[fft_pad(ly)];
         if (lx == half && 2 * half == G) {
-            grid[(int64_t) gy * grid_row_stride] = x[ly];       // the Nyquist column is its own mirror
+            grid[(int64_t) gy * grid_row_stride] = x[fft_pad(ly)];      // the Nyquist column is its own mirror
         } else if (lx > 0) {
-            const float2 v = x[ly ? G - ly : 0];
+            const float2 v = x[fft_pad(ly ? G - ly : 0)];
             grid[(int64_t) gy * grid_row_stride + half - lx] = make_float2(v.x, -v.y);
         }
     }
@@ -742,8 +802,9 @@ int twiddle_table(int G, hipStream_t s, const float2 **out)
             return 0;
         }
     float2 *table = nullptr;
-    KIMG_HIP(hipMalloc((void **) &table, sizeof(float2) * (size_t) (G / 2)));
-    twiddle_kernel<<<kimg_divup(G / 2, 256), 256, 0, s>>>(table, G);
+    const int count = fft_twiddle_count(G);
+    KIMG_HIP(hipMalloc((void **) &table, sizeof(float2) * (size_t) count));
+    twiddle_kernel<<<kimg_divup(count, 256), 256, 0, s>>>(table, G);
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         (void) hipFree(table);
@@ -789,7 +850,8 @@ extern "C" size_t kimg_grid_image_real_workspace_bytes(int layer_size, int grid_
 extern "C" int kimg_grid_to_image_real(float *image, int64_t image_row_stride, int layer_size,
                                        const void *grid, int64_t grid_row_stride, int grid_size,
                                        const float *kernel1d, float lm_scale, float lm_bias,
-                                       void *workspace, size_t workspace_bytes, void *stream)
+                                       int accumulate, void *workspace, size_t workspace_bytes,
+                                       void *stream)
 {
     KIMG_CHECK_ARG(image && grid && kernel1d && workspace);
     KIMG_CHECK_ARG(kimg_grid_image_real_supported(layer_size, grid_size));
@@ -802,14 +864,20 @@ extern "C" int kimg_grid_to_image_real(float *image, int64_t image_row_stride, i
     int rc = twiddle_table(G, s, &tw);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (G + G / 2);
-    if ((rc = fft_lds_attribute(&g2i_columns_kernel, lds)) || (rc = fft_lds_attribute(&g2i_rows_kernel, lds)))
+    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
+    if ((rc = fft_lds_attribute(&g2i_columns_kernel, lds))
+        || (rc = fft_lds_attribute(&g2i_rows_kernel<true>, lds))
+        || (rc = fft_lds_attribute(&g2i_rows_kernel<false>, lds)))
         return rc;
     float2 *T = static_cast<float2 *>(workspace);
     g2i_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
         T, static_cast<const float2 *>(grid), grid_row_stride, grid_size, G, log2G, tw);
-    g2i_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
-        image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+    if (accumulate)
+        g2i_rows_kernel<true><<<G / 2, FFT_THREADS, lds, s>>>(
+            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+    else
+        g2i_rows_kernel<false><<<G / 2, FFT_THREADS, lds, s>>>(
+            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
     return kimg_launch_status();
 }
 
@@ -829,7 +897,7 @@ extern "C" int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int 
     int rc = twiddle_table(G, s, &tw);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (G + G / 2);
+    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
     if ((rc = fft_lds_attribute(&i2g_rows_kernel, lds)) || (rc = fft_lds_attribute(&i2g_columns_kernel, lds)))
         return rc;
     float2 *T = static_cast<float2 *>(workspace);

@@ -349,6 +349,13 @@ class GridToImage(_GridImage):
         super().__init__(template, command_queue, shape_grid, lm_scale, lm_bias, fft_plan,
                          template.layer_to_image, allocator)
         self._real_plan = None
+        #: set by a caller that knows the image to be all zero (``Imaging.clear_dirty``): the next
+        #: call writes the image instead of adding to it, where the route can (:meth:`can_overwrite`)
+        self.overwrite_next = False
+
+    def can_overwrite(self):
+        """Whether the next call can write the image instead of accumulating into it."""
+        return self._layer_image.w == 0 and self._own_transform()
 
     def _run(self):
         grid, layer = self.buffer('grid'), self.buffer('layer')
@@ -362,10 +369,12 @@ class GridToImage(_GridImage):
             image = self.buffer('image')
             li = self._layer_image
             if self._own_transform():
+                overwrite, self.overwrite_next = self.overwrite_next, False
                 for pol in range(P):
                     check(lib().kimg_grid_to_image_real(
                         _pol_ptr(image, pol), G, G, _pol_ptr(grid, pol), Gg, Gg,
-                        self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias, layer.ptr,
+                        self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias,
+                        0 if overwrite else 1, layer.ptr,
                         layer.tensor.numel() * layer.tensor.element_size(), q.handle),
                         'kimg_grid_to_image_real')
                 return

@@ -215,6 +215,7 @@ class Imaging(accel.OperationSequence):
                 allocator)
         self._components = {}
         self._pending_components = []
+        self._dirty_cleared = False
         operations = [
             ('weights', self._weights), ('gridder', self._gridder), ('predict', self._predict),
             ('continuum_predict', self._continuum_predict),
@@ -289,9 +290,17 @@ class Imaging(accel.OperationSequence):
         self._side_dirty = True
         return True
 
-    def _ready(self):
+    def _ready(self, keep_cleared=False):
         if not self._bound:
             self.ensure_all_bound()
+        if self._dirty_cleared and not keep_cleared:
+            self._dirty_cleared = False
+            super().buffer('dirty').zero(self.command_queue)
+
+    def buffer(self, name):
+        if name == 'dirty' and self._dirty_cleared:
+            self._ready()
+        return super().buffer(name)
 
     # ---- visibilities ---------------------------------------------------------------
     @property
@@ -363,8 +372,11 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def clear_dirty(self):
+        """imaging.py:258-261.  The fill is deferred: when the next thing to touch the image is a
+        :meth:`grid_to_image` that can write it instead of adding to it, neither the fill nor the
+        read of the zeros happens; anything else (:meth:`_ready`, :meth:`buffer`) fills first."""
         self._ready()
-        self.buffer('dirty').zero(self.command_queue)
+        self._dirty_cleared = True
 
     @_serial
     def clear_model(self):
@@ -511,8 +523,14 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def grid_to_image(self, w):
-        self._ready()
+        self._ready(keep_cleared=True)
         self._grid_to_image.set_w(w)
+        if self._dirty_cleared:
+            if self._grid_to_image.can_overwrite():
+                self._dirty_cleared = False
+                self._grid_to_image.overwrite_next = True
+            else:
+                self._ready()
         self._grid_to_image()
 
     @_serial

@@ -1129,6 +1129,53 @@ def test_restore_step():
                                atol=1e-5 * np.abs(expected).max())
 
 
+@pytest.mark.gpu
+def test_clear_dirty_deferred():
+    """Imaging.clear_dirty defers its fill: a grid_to_image that can write the image (w = 0 on the
+    library's own transforms) does so and neither fills nor reads it; any other access sees the
+    zeros.  Same images either way."""
+    from katsdpimager_amd import imaging, parameters, weight
+    ctx, q = context_queue()
+    c = gi.E2E_CONFIGS['degrid']
+    ip, gp, ap = make_params(c)
+    wp = parameters.WeightParameters(weight.WeightType(c['weight_type']), c['robustness'])
+    cp = parameters.CleanParameters(c['minor'], c['loop_gain'], c['major_gain'], c['threshold'],
+                                    c['mode'], c['psf_cutoff'], c['psf_limit'], c['border'])
+    im = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp).instantiate(
+        q, ip, gp, c['vis_block'], 0, c['major'])
+    im.ensure_all_bound()
+    G = c['pixels']
+    rs = gi.RandomState(77)
+    shape = im.buffer('grid').shape
+    im.set_buffer('grid', rs.complex_uniform(-1, 1, shape).astype(np.complex64))
+    junk = np.full((1, G, G), 7.0, np.float32)
+    zeros = np.zeros((1, G, G), np.float32)
+    im.set_buffer('dirty', junk)
+    im.clear_dirty()
+    assert im._dirty_cleared
+    np.testing.assert_array_equal(im.get_buffer('dirty'), zeros)       # (the fill happened now)
+    assert not im._dirty_cleared
+    for w in (0.0, 12.5):
+        im.set_buffer('dirty', junk)
+        im.clear_dirty()
+        im.grid_to_image(w)
+        assert not im._dirty_cleared
+        assert im._grid_to_image.can_overwrite() == (w == 0.0)
+        deferred = im.get_buffer('dirty')
+        im.set_buffer('dirty', zeros)
+        im.grid_to_image(w)
+        explicit = im.get_buffer('dirty')
+        np.testing.assert_array_equal(deferred, explicit)
+        assert np.abs(explicit).max() > 0
+        im.grid_to_image(w)                         # the second call accumulates
+        np.testing.assert_allclose(im.get_buffer('dirty'), 2 * explicit, rtol=1e-6,
+                                   atol=1e-6 * np.abs(explicit).max())
+    # the direct buffer access fills too
+    im.set_buffer('dirty', junk)
+    im.clear_dirty()
+    np.testing.assert_array_equal(im.buffer('dirty').get(q), zeros)
+
+
 @pytest.mark.parametrize('arith', ARITHS)
 @pytest.mark.parametrize('seed', range(12))
 def test_grid_degrid_fuzz(seed, arith):
