@@ -423,40 +423,60 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     P, G = args.polarizations, args.pixels
 
     # grid -> image: at w = 0 (every slice of C2 / C5) the Hermitian part of the grid goes through a
-    # complex-to-real transform of half the size (kimg_grid_to_half_layer + rocFFT C2R in place +
-    # kimg_real_layer_to_image); at w != 0 pad/shift + rocFFT C2C + layer_to_image
-    template = image.GridImageTemplate(ctx, np.float32)
-    g2i = template.instantiate_grid_to_image(
-        q, grid_buf.shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
-        template.make_fft_plan((G, G)))
-    g2i.bind(grid=grid_buf)
-    g2i.ensure_all_bound()
-    g2i.buffer('kernel1d').set(q, gridder.convolve_kernel.taper(G).astype(np.float32))
-    g2i.buffer('image').zero(q)
+    # complex-to-real transform of half the size -- for a layer size that is a power of two in two
+    # launches of the library's own (kimg_grid_to_image_real: only the columns the grid reaches,
+    # fold / padding / image correction fused), else kimg_grid_to_half_layer + rocFFT C2R in place +
+    # kimg_real_layer_to_image; at w != 0 pad/shift + rocFFT C2C + layer_to_image
     Gg = grid_buf.shape[1]
+    routes = {'own': {}, 'library': {'own_transform': False}}
+    times = {}
+    for route, tuning in routes.items():
+        template = image.GridImageTemplate(ctx, np.float32, tuning)
+        g2i = template.instantiate_grid_to_image(
+            q, grid_buf.shape, float(ip.pixel_size), -0.5 * G * float(ip.pixel_size),
+            template.make_fft_plan((G, G)))
+        g2i.bind(grid=grid_buf)
+        g2i.ensure_all_bound()
+        g2i.buffer('kernel1d').set(q, gridder.convolve_kernel.taper(G).astype(np.float32))
+        g2i.buffer('image').zero(q)
 
-    def g2i_time(w):
-        g2i.set_w(w)
-        g2i()
-        q.finish()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        def g2i_time(w, overwrite=False):
+            g2i.set_w(w)
             g2i()
-        q.finish()
-        return (time.perf_counter() - t0) / 5
-    dt = g2i_time(0.0)
-    dt_c2c = g2i_time(1.0)
+            q.finish()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                g2i.overwrite_next = overwrite
+                g2i()
+            q.finish()
+            return (time.perf_counter() - t0) / 5
+        times[route] = g2i_time(0.0)
+        if route == 'own':
+            own = g2i._own_transform()
+            dt_write = g2i_time(0.0, True) if own else None
+            dt_c2c = g2i_time(1.0)
+        del g2i
+    dt = times['own']
     out['grid_to_image_ms'] = round(dt * 1e3, 3)
-    out['grid_to_image_route'] = 'w = 0: Hermitian part + complex-to-real transform (in place, half layer)'
-    # compulsory HBM traffic per polarization of the reference's formulation (complex layer): read
-    # the grid, write + FFT the layer (2 passes, read + write each), read it again,
-    # read-modify-write the image ...
-    g2i_bytes = P * (8 * Gg * Gg + 8 * G * G + 32 * G * G + 8 * G * G + 8 * G * G)
-    out['grid_to_image_GBps'] = round(g2i_bytes / dt / 1e9, 1)
-    out['grid_to_image_frac_of_8TBps'] = round(g2i_bytes / dt / 1e9 / HBM_PEAK_GBS, 4)
-    # ... and of the route actually run (half layer: every layer term halves)
-    route_bytes = P * (8 * Gg * Gg + 4 * G * G + 16 * G * G + 4 * G * G + 8 * G * G)
+    if own:
+        out['grid_to_image_route'] = ('w = 0: own transforms, two launches (columns the grid reaches, '
+                                      'then row pairs with the image correction)')
+        out['grid_to_image_write_ms'] = round(dt_write * 1e3, 3)    # first slice: no read of the image
+        out['grid_to_image_library_plan_ms'] = round(times['library'] * 1e3, 3)
+        # HBM traffic of the route per polarization: the grid, the columns' transforms out and in,
+        # the image read and written
+        route_bytes = P * (8 * Gg * Gg + 2 * 8 * (Gg // 2 + 1) * G + 8 * G * G)
+    else:
+        out['grid_to_image_route'] = 'w = 0: Hermitian part + complex-to-real transform (in place, half layer)'
+        # half layer written, transformed (2 passes, read + write each), read; image read + written
+        route_bytes = P * (8 * Gg * Gg + 4 * G * G + 16 * G * G + 4 * G * G + 8 * G * G)
     out['grid_to_image_route_GBps'] = round(route_bytes / dt / 1e9, 1)
+    out['grid_to_image_route_frac_of_8TBps'] = round(route_bytes / dt / 1e9 / HBM_PEAK_GBS, 4)
+    # the same work in the reference's formulation (complex layer): read the grid, write + FFT the
+    # layer (2 passes, read + write each), read it again, read-modify-write the image
+    g2i_bytes = P * (8 * Gg * Gg + 8 * G * G + 32 * G * G + 8 * G * G + 8 * G * G)
+    out['grid_to_image_reference_formulation_MB'] = round(g2i_bytes / 1e6, 1)
+    out['grid_to_image_route_MB'] = round(route_bytes / 1e6, 1)
     out['grid_to_image_c2c_ms'] = round(dt_c2c * 1e3, 3)            # w != 0
     out['grid_to_image_c2c_GBps'] = round(g2i_bytes / dt_c2c / 1e9, 1)
 
