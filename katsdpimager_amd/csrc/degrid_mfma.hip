@@ -675,8 +675,11 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
     const int blocks = (int) ((num_vis + vis_per_block - 1) / vis_per_block);
     // long launches: work by the chunk (see batch_pos in the kernel)
     const int64_t waves = (int64_t) blocks * NW;
+// (512 until round 3: on a W-slice of the resident store -- 6-7 M records, three chunks of ~700 per
+// wave -- the waves' last chunks ended up to 170 us apart; 256 measures 4-6 % faster there, 384 / 192 /
+// 128 do not; a chunk's end costs the degridder no flush, only a window reload)
 #ifndef KIMG_DEGRID_MIN_CHUNK
-#define KIMG_DEGRID_MIN_CHUNK 512
+#define KIMG_DEGRID_MIN_CHUNK 256
 #endif
 #ifndef KIMG_DEGRID_MAX_PARTS
 #define KIMG_DEGRID_MAX_PARTS 32
