@@ -223,7 +223,7 @@ def get_totals(queue, image, restoring_beam):
     return [float(x) / beam_area for x in sums.get(queue)]
 
 
-def process_channels(jobs, workers=2, batch_clean=True, stagger=None):
+def process_channels(jobs, workers=4, batch_clean=True, stagger=None):
     """Image several channels of one GPU concurrently, one host thread and one HIP stream
     (command queue) per channel in flight.
 
@@ -247,7 +247,7 @@ def process_channels(jobs, workers=2, batch_clean=True, stagger=None):
                                   batch_clean=batch_clean, stagger=stagger)
 
 
-def process_channel_stream(make_job, channels, workers=2, batch_clean=True, stagger=None):
+def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stagger=None):
     """Image ``channels`` (any number) with at most ``workers`` of them in flight AND in memory.
 
     :func:`process_channels` takes ready-made jobs, i.e. one imager per channel; a band of

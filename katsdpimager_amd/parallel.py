@@ -66,7 +66,7 @@ def gather_stats(values, device='cpu'):
     return torch.cat(out, dim=0)
 
 
-def image_assigned_channels(make_job, num_channels, workers=2, runner=None):
+def image_assigned_channels(make_job, num_channels, workers=4, runner=None):
     """Image this rank's share of `num_channels` channels: channel c belongs to rank c mod world_size
     (:func:`assign_channels`); a rank with several channels keeps up to `workers` of them in flight
     on its GPU (one host thread and one HIP stream per channel in flight).
