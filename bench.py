@@ -455,6 +455,8 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
             own = g2i._own_transform()
             dt_write = g2i_time(0.0, True) if own else None
             dt_c2c = g2i_time(1.0)
+        else:
+            dt_c2c_library = g2i_time(1.0)
         del g2i
     dt = times['own']
     out['grid_to_image_ms'] = round(dt * 1e3, 3)
@@ -477,7 +479,9 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     g2i_bytes = P * (8 * Gg * Gg + 8 * G * G + 32 * G * G + 8 * G * G + 8 * G * G)
     out['grid_to_image_reference_formulation_MB'] = round(g2i_bytes / 1e6, 1)
     out['grid_to_image_route_MB'] = round(route_bytes / 1e6, 1)
-    out['grid_to_image_c2c_ms'] = round(dt_c2c * 1e3, 3)            # w != 0
+    # w != 0: complex layer (own transforms: the Gg columns the grid reaches, then every row)
+    out['grid_to_image_c2c_ms'] = round(dt_c2c * 1e3, 3)
+    out['grid_to_image_c2c_library_plan_ms'] = round(dt_c2c_library * 1e3, 3)
     out['grid_to_image_c2c_GBps'] = round(g2i_bytes / dt_c2c / 1e9, 1)
 
     # restoring-beam convolution of one polarization plane (R2C + Gaussian + C2R, beam.py:351-398)

@@ -312,6 +312,19 @@ int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int grid_size,
                             const float *image, int64_t image_row_stride, int layer_size,
                             const float *kernel1d, float lm_scale, float lm_bias,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* ... and for any w (a slice of the W stack away from w = 0: the layer is complex, image.py:781-799
+ * and :836-848 with the phase e^{+-2 pi i w (n - 1)}): the same two launches over the Gg columns the
+ * grid reaches and over pairs of rows, each row with a complex transform of its own.  Same sizes as
+ * the w = 0 pair (kimg_grid_image_real_supported); workspace Gg x G cells. */
+size_t kimg_grid_image_w_workspace_bytes(int layer_size, int grid_size);
+int kimg_grid_to_image_w(float *image, int64_t image_row_stride, int layer_size,
+                         const void *grid, int64_t grid_row_stride, int grid_size,
+                         const float *kernel1d, float lm_scale, float lm_bias, float w,
+                         int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+int kimg_image_to_grid_w(void *grid, int64_t grid_row_stride, int grid_size,
+                         const float *image, int64_t image_row_stride, int layer_size,
+                         const float *kernel1d, float lm_scale, float lm_bias, float w,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
  * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */

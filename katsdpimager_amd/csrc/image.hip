@@ -524,6 +524,151 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_columns_kernel(
     }
 }
 
+// ---- the same two-launch scheme for any w (complex layer, no Hermitian symmetry to use) -------
+// Columns: the Gg columns of the layer the grid reaches (centred -Gg/2 .. Gg/2 - 1), index c.
+// Rows: every row needs its own complex transform; a workgroup takes two neighbouring rows one
+// after the other so that it reads (or writes) T in 16-byte pieces.
+constexpr int FFT_ROW_CELLS = 8192 / FFT_THREADS;     // cells of one row of T a thread may hold
+
+__device__ inline int grid_to_layer_index(int c, int half, int G)
+{
+    const int centred = c - half;
+    return centred < 0 ? centred + G : centred;
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void g2iw_columns_kernel(
+    float2 *__restrict__ T, const float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, twiddle, G, true);
+    const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
+    for (int r = threadIdx.x; r < Gg; r += FFT_THREADS)
+        x[fft_pad(bit_reverse(grid_to_layer_index(r, half, G), log2G))] = grid[(int64_t) r * grid_row_stride + c];
+    lds_fft<true>(x, tw, G, log2G);
+    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
+        T[(int64_t) c * G + sy] = x[fft_pad(sy)];
+}
+
+// layer_to_image_kernel's arithmetic on rows sy1 = 2 * blockIdx.x and sy1 + 1
+template<bool ACCUMULATE>
+__global__ __launch_bounds__(FFT_THREADS) void g2iw_rows_kernel(
+    float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    float lm_scale, float lm_bias, float w)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, twiddle, G, true);
+    const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
+    float2 second[FFT_ROW_CELLS];
+#pragma unroll
+    for (int k = 0; k < FFT_ROW_CELLS; k++) {
+        const int c = threadIdx.x + k * FFT_THREADS;
+        if (c < Gg) {
+            const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) c * G + sy1);
+            x[fft_pad(bit_reverse(grid_to_layer_index(c, half, G), log2G))] = make_float2(t.x, t.y);
+            second[k] = make_float2(t.z, t.w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r == 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < fft_lds_cells(G); i += FFT_THREADS)
+                x[i] = make_float2(0.0f, 0.0f);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < FFT_ROW_CELLS; k++) {
+                const int c = threadIdx.x + k * FFT_THREADS;
+                if (c < Gg)
+                    x[fft_pad(bit_reverse(grid_to_layer_index(c, half, G), log2G))] = second[k];
+            }
+        }
+        lds_fft<true>(x, tw, G, log2G);
+        const int y = fft_shift(sy1 + r, hG);
+        const float m = lm_coord(y, lm_scale, lm_bias);
+        const float m2 = m * m;
+        const float ky = kernel1d[y];
+        float *row = image + (int64_t) y * image_row_stride;
+        for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+            const int xx = fft_shift(sx, hG);
+            const float2 v = x[fft_pad(sx)];
+            const float l = lm_coord(xx, lm_scale, lm_bias);
+            const float l2 = l * l;
+            const float n = sqrtf(1.0f - (m2 + l2));
+            float c, s;
+            expj2pi(w * (n - 1.0f), c, s);
+            const float rotated = v.x * c - v.y * s;
+            const float taper = ky * kernel1d[xx];
+            const float out = (rotated * n) / taper;
+            row[xx] = ACCUMULATE ? row[xx] + out : out;
+        }
+    }
+}
+
+// image_to_layer_kernel's arithmetic on two rows, forward transforms, the Gg columns kept
+__global__ __launch_bounds__(FFT_THREADS) void i2gw_rows_kernel(
+    float2 *__restrict__ T, const float *__restrict__ image, int64_t image_row_stride, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    float lm_scale, float lm_bias, float w)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, twiddle, G, false);
+    const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
+    float2 first[FFT_ROW_CELLS];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = fft_shift(sy1 + r, hG);
+        const float m = lm_coord(y, lm_scale, lm_bias);
+        const float m2 = m * m;
+        const float ky = kernel1d[y];
+        if (r == 1)
+            __syncthreads();        // (the first row's results have been taken out of x)
+        for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+            const int xx = fft_shift(sx, hG);
+            const float l = lm_coord(xx, lm_scale, lm_bias);
+            const float l2 = l * l;
+            const float n = sqrtf(1.0f - (m2 + l2));
+            float c, s;
+            expj2pi(-w * (n - 1.0f), c, s);
+            const float taper = ky * kernel1d[xx];
+            const float v = image[(int64_t) y * image_row_stride + xx] / (taper * n);
+            x[fft_pad(bit_reverse(sx, log2G))] = make_float2(v * c, v * s);
+        }
+        lds_fft<false>(x, tw, G, log2G);
+#pragma unroll
+        for (int k = 0; k < FFT_ROW_CELLS; k++) {
+            const int c = threadIdx.x + k * FFT_THREADS;
+            if (c < Gg) {
+                const float2 v = x[fft_pad(grid_to_layer_index(c, half, G))];
+                if (r == 0)
+                    first[k] = v;
+                else
+                    *reinterpret_cast<float4 *>(T + (int64_t) c * G + sy1) =
+                        make_float4(first[k].x, first[k].y, v.x, v.y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void i2gw_columns_kernel(
+    float2 *__restrict__ grid, int64_t grid_row_stride, const float2 *__restrict__ T, int Gg, int G,
+    int log2G, const float2 *__restrict__ twiddle)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, twiddle, G, false);
+    const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
+    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
+        x[fft_pad(bit_reverse(sy, log2G))] = T[(int64_t) c * G + sy];
+    lds_fft<false>(x, tw, G, log2G);
+    for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS)
+        grid[(int64_t) gy * grid_row_stride + c] = x[fft_pad(grid_to_layer_index(gy, half, G))];
+}
+
 } // namespace
 
 extern "C" int kimg_grid_to_layer(void *layer, int layer_size, const void *grid,
@@ -904,6 +1049,75 @@ extern "C" int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int 
     i2g_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
         T, image, image_row_stride, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
     i2g_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
+        static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, log2G, tw);
+    return kimg_launch_status();
+}
+
+// ---- the same for any w: complex layer ------------------------------------------------------
+extern "C" size_t kimg_grid_image_w_workspace_bytes(int layer_size, int grid_size)
+{
+    if (!kimg_grid_image_real_supported(layer_size, grid_size))
+        return 0;
+    return sizeof(float2) * (size_t) grid_size * (size_t) layer_size;
+}
+
+extern "C" int kimg_grid_to_image_w(float *image, int64_t image_row_stride, int layer_size,
+                                    const void *grid, int64_t grid_row_stride, int grid_size,
+                                    const float *kernel1d, float lm_scale, float lm_bias, float w,
+                                    int accumulate, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    KIMG_CHECK_ARG(image && grid && kernel1d && workspace);
+    KIMG_CHECK_ARG(kimg_grid_image_real_supported(layer_size, grid_size));
+    KIMG_CHECK_ARG(image_row_stride >= layer_size && grid_row_stride >= grid_size);
+    KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_w_workspace_bytes(layer_size, grid_size));
+    KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
+    hipStream_t s = (hipStream_t) stream;
+    const int G = layer_size, log2G = fft_log2(G);
+    const float2 *tw = nullptr;
+    int rc = twiddle_table(G, s, &tw);
+    if (rc)
+        return rc;
+    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
+    if ((rc = fft_lds_attribute(&g2iw_columns_kernel, lds))
+        || (rc = fft_lds_attribute(&g2iw_rows_kernel<true>, lds))
+        || (rc = fft_lds_attribute(&g2iw_rows_kernel<false>, lds)))
+        return rc;
+    float2 *T = static_cast<float2 *>(workspace);
+    g2iw_columns_kernel<<<grid_size, FFT_THREADS, lds, s>>>(
+        T, static_cast<const float2 *>(grid), grid_row_stride, grid_size, G, log2G, tw);
+    if (accumulate)
+        g2iw_rows_kernel<true><<<G / 2, FFT_THREADS, lds, s>>>(
+            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
+    else
+        g2iw_rows_kernel<false><<<G / 2, FFT_THREADS, lds, s>>>(
+            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_image_to_grid_w(void *grid, int64_t grid_row_stride, int grid_size,
+                                    const float *image, int64_t image_row_stride, int layer_size,
+                                    const float *kernel1d, float lm_scale, float lm_bias, float w,
+                                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    KIMG_CHECK_ARG(image && grid && kernel1d && workspace);
+    KIMG_CHECK_ARG(kimg_grid_image_real_supported(layer_size, grid_size));
+    KIMG_CHECK_ARG(image_row_stride >= layer_size && grid_row_stride >= grid_size);
+    KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_w_workspace_bytes(layer_size, grid_size));
+    KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
+    hipStream_t s = (hipStream_t) stream;
+    const int G = layer_size, log2G = fft_log2(G);
+    const float2 *tw = nullptr;
+    int rc = twiddle_table(G, s, &tw);
+    if (rc)
+        return rc;
+    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
+    if ((rc = fft_lds_attribute(&i2gw_rows_kernel, lds)) || (rc = fft_lds_attribute(&i2gw_columns_kernel, lds)))
+        return rc;
+    float2 *T = static_cast<float2 *>(workspace);
+    i2gw_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
+        T, image, image_row_stride, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
+    i2gw_columns_kernel<<<grid_size, FFT_THREADS, lds, s>>>(
         static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, log2G, tw);
     return kimg_launch_status();
 }

@@ -355,7 +355,7 @@ class GridToImage(_GridImage):
 
     def can_overwrite(self):
         """Whether the next call can write the image instead of accumulating into it."""
-        return self._layer_image.w == 0 and self._own_transform()
+        return self._own_transform()
 
     def _run(self):
         grid, layer = self.buffer('grid'), self.buffer('layer')
@@ -386,6 +386,18 @@ class GridToImage(_GridImage):
                 check(lib().kimg_real_layer_to_image(
                     _pol_ptr(image, pol), G, layer.ptr, G + 2, G, self.buffer('kernel1d').ptr,
                     li.lm_scale, li.lm_bias, q.handle), 'kimg_real_layer_to_image')
+            return
+        if self._own_transform():
+            overwrite, self.overwrite_next = self.overwrite_next, False
+            image = self.buffer('image')
+            li = self._layer_image
+            for pol in range(P):
+                check(lib().kimg_grid_to_image_w(
+                    _pol_ptr(image, pol), G, G, _pol_ptr(grid, pol), Gg, Gg,
+                    self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias, float(li.w),
+                    0 if overwrite else 1, layer.ptr,
+                    layer.tensor.numel() * layer.tensor.element_size(), q.handle),
+                    'kimg_grid_to_image_w')
             return
         for pol in range(P):
             check(lib().kimg_grid_to_layer(layer.ptr, G, _pol_ptr(grid, pol), Gg, Gg,
@@ -430,6 +442,17 @@ class ImageToGrid(_GridImage):
                 self._real_plan.execute_in_place(q, layer, inverse=False)
                 check(lib().kimg_half_layer_to_grid(_pol_ptr(grid, pol), Gg, Gg, layer.ptr, G,
                                                     q.handle), 'kimg_half_layer_to_grid')
+            return
+        if self._own_transform():
+            q = self.command_queue
+            image = self.buffer('image')
+            li = self._layer_image
+            for pol in range(P):
+                check(lib().kimg_image_to_grid_w(
+                    _pol_ptr(grid, pol), Gg, Gg, _pol_ptr(image, pol), G, G,
+                    self.buffer('kernel1d').ptr, li.lm_scale, li.lm_bias, float(li.w), layer.ptr,
+                    layer.tensor.numel() * layer.tensor.element_size(), q.handle),
+                    'kimg_image_to_grid_w')
             return
         for pol in range(P):
             self._layer_image.set_polarization(pol)

@@ -703,6 +703,61 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
             assert relerr(back[route], gi.middle(full_grid, small.shape)) < 1e-5, route
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('G,Gg,P,w', [(64, 64, 1, 37.5), (128, 50, 2, -12.25), (16, 6, 1, 3.0),
+                                      (512, 154, 1, 151.0), (2048, 620, 1, 40.0),
+                                      (4096, 1244, 1, -75.5)])
+def test_grid_image_own_transform_any_w(G, Gg, P, w):
+    """w != 0 (a slice of the W stack away from the middle): the two-launch route on the library's
+    own transforms (kimg_grid_to_image_w / kimg_image_to_grid_w) against the FFT library's
+    complex-to-complex plan with the separate pad and correction kernels, and against the oracle."""
+    from katsdpimager_amd import image
+    ctx, q = context_queue()
+    rs = gi.RandomState(G * 3 + Gg)
+    small = rs.complex_uniform(-1, 1, (P, Gg, Gg)).astype(np.complex64)
+    k1d = rs.uniform(1.0, 2.0, G).astype(np.float32)
+    model = rs.uniform(-1, 1, (P, G, G)).astype(np.float32)
+    lm_scale = 0.3 / G
+    lm_bias = -0.5 * G * lm_scale
+    got, back = {}, {}
+    for route, tuning in (('own', {}), ('library', {'own_transform': False})):
+        template = image.GridImageTemplate(ctx, np.float32, tuning)
+        plan = template.make_fft_plan((G, G))
+        g2i = template.instantiate_grid_to_image(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+        g2i.ensure_all_bound()
+        i2g = template.instantiate_image_to_grid(q, (P, Gg, Gg), lm_scale, lm_bias, plan)
+        i2g.bind(layer=g2i.buffer('layer'), kernel1d=g2i.buffer('kernel1d'))
+        i2g.ensure_all_bound()
+        g2i.buffer('kernel1d').set(q, k1d)
+        g2i.buffer('grid').set(q, small)
+        g2i.buffer('image').set(q, np.full((P, G, G), 3.0, np.float32))
+        g2i.set_w(w)
+        assert g2i._own_transform() == (route == 'own')
+        g2i.overwrite_next = g2i.can_overwrite()        # the library route accumulates onto ...
+        if not g2i.can_overwrite():
+            g2i.buffer('image').zero(q)                 # ... explicit zeros
+        g2i()
+        g2i()                                           # accumulates
+        got[route] = g2i.buffer('image').get(q)
+        i2g.buffer('image').set(q, model)
+        i2g.buffer('grid').zero(q)
+        i2g.set_w(w)
+        i2g()
+        back[route] = i2g.buffer('grid').get(q)
+        del g2i, i2g
+    assert np.abs(got['own'] - got['library']).max() <= 2e-6 * np.abs(got['library']).max()
+    assert np.abs(back['own'] - back['library']).max() <= 2e-6 * np.abs(back['library']).max()
+    if G <= 128:
+        full = np.zeros((P, G, G), np.complex64)
+        gi.middle(full, small.shape)[:] = small
+        expected = np.zeros((P, G, G), np.float32)
+        orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, w)
+        orc.grid_to_image(full, expected, k1d, lm_scale, lm_bias, w)
+        assert relerr(got['own'], expected) < 1e-5
+        full_grid, _ = orc.image_to_grid(model, k1d, lm_scale, lm_bias, w)
+        assert relerr(back['own'], gi.middle(full_grid, small.shape)) < 1e-5
+
+
 def test_image_streams():
     """Scale / AddImage / ApplyPrimaryBeam known answers (test_image.py:91-162)."""
     from katsdpimager_amd import image
@@ -1131,9 +1186,9 @@ def test_restore_step():
 
 @pytest.mark.gpu
 def test_clear_dirty_deferred():
-    """Imaging.clear_dirty defers its fill: a grid_to_image that can write the image (w = 0 on the
-    library's own transforms) does so and neither fills nor reads it; any other access sees the
-    zeros.  Same images either way."""
+    """Imaging.clear_dirty defers its fill: a grid_to_image that can write the image (the
+    library's own transforms, w = 0 or not) does so and neither fills nor reads it; any other
+    access sees the zeros.  Same images either way."""
     from katsdpimager_amd import imaging, parameters, weight
     ctx, q = context_queue()
     c = gi.E2E_CONFIGS['degrid']
@@ -1160,7 +1215,7 @@ def test_clear_dirty_deferred():
         im.clear_dirty()
         im.grid_to_image(w)
         assert not im._dirty_cleared
-        assert im._grid_to_image.can_overwrite() == (w == 0.0)
+        assert im._grid_to_image.can_overwrite()
         deferred = im.get_buffer('dirty')
         im.set_buffer('dirty', zeros)
         im.grid_to_image(w)

@@ -1,7 +1,7 @@
 """grid -> image and image -> grid at w = 0: the three routes (own two-launch transforms, the FFT
 library's complex-to-real plan, complex-to-complex), timed.
 
-    python tools/exp_grid_image.py [layer size] [grid size] [repeat]"""
+    python tools/exp_grid_image.py [layer size] [grid size] [repeat] [w of the slice]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from katsdpimager_amd import accel, image
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 Gg = int(sys.argv[2]) if len(sys.argv) > 2 else 1244
 repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+W_SLICE = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 ctx = accel.create_some_context()
 q = ctx.create_command_queue()
 rs = np.random.RandomState(1)
@@ -39,8 +40,8 @@ for route, tuning in ROUTES.items():
     g2i.buffer('kernel1d').set(q, k1d)
     g2i.buffer('grid').set(q, grid)
     i2g.buffer('image').set(q, model)
-    g2i.set_w(0.0)
-    i2g.set_w(0.0)
+    g2i.set_w(W_SLICE)
+    i2g.set_w(W_SLICE)
     g2i.buffer('image').zero(q)
     g2i()
     i2g()
