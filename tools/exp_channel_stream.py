@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import synth
-from katsdpimager_amd import accel, clean, frontend, imaging, parameters, preprocess, trace, weight
+from katsdpimager_amd import accel, clean, frontend, imaging, parameters, preprocess, weight
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 channels = int(sys.argv[2]) if len(sys.argv) > 2 else 12

@@ -8,12 +8,10 @@ import sys
 import time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from katsdpimager_amd import _lib as _kl
 if os.environ.get('KIMG_VARIANT_LIB'):
     _kl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build_variants',
                                 'libkimg_%s.so' % os.environ['KIMG_VARIANT_LIB'])
-import synth
 from katsdpimager_amd import accel, clean, parameters
 
 ph = int(sys.argv[1]) if len(sys.argv) > 1 else 711
