@@ -1129,9 +1129,17 @@ def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm, reader):
     for workers in (1, 2, 3, 4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = frontend.process_channels(jobs, workers=workers)
+        res = frontend.process_channels(jobs, workers=workers, stagger=False)
         torch.cuda.synchronize()
         out['four_channels_%d_in_flight_ms' % workers] = round((time.perf_counter() - t0) * 1e3, 2)
+        if workers > 1:
+            # the default: the channels take turns at gridding (see the 12-channel stream below)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            frontend.process_channels(jobs, workers=workers)
+            torch.cuda.synchronize()
+            out['four_channels_%d_in_flight_turns_ms' % workers] = round(
+                (time.perf_counter() - t0) * 1e3, 2)
         out['four_channels_%d_in_flight_clean_batches' % workers] = [
             list(b) for b in frontend.process_channel_stream.last_batches]
     out['four_channels_minor_cycles'] = [int(r['minor']) for r in res]

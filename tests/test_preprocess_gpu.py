@@ -362,13 +362,16 @@ def test_concurrent_channels_match_serial():
                             clean_p=cp, weight_type=wp.weight_type, vis_block=c['vis_block'],
                             major=c['major'], degrid=True))
         return out
-    serial, conc = jobs(), jobs()
+    serial, conc, turns = jobs(), jobs(), jobs()
     rs = frontend.process_channels(serial, workers=1)
     rc = frontend.process_channels(conc, workers=2)
-    for a, b, ja, jb in zip(rs, rc, serial, conc):
-        assert a['minor'] == b['minor'] and a['psf_patch'] == b['psf_patch']
-        assert sorted(ja['imager']._model_components) == sorted(jb['imager']._model_components)
-        assert relerr(ja['imager'].get_buffer('model'), jb['imager'].get_buffer('model')) < 1e-5
+    # ... and with the channels taking turns at their throughput-bound stages (CleanBatcher phased)
+    rt = frontend.process_channels(turns, workers=2, stagger=True)
+    for other, jobs_other in ((rc, conc), (rt, turns)):
+        for a, b, ja, jb in zip(rs, other, serial, jobs_other):
+            assert a['minor'] == b['minor'] and a['psf_patch'] == b['psf_patch']
+            assert sorted(ja['imager']._model_components) == sorted(jb['imager']._model_components)
+            assert relerr(ja['imager'].get_buffer('model'), jb['imager'].get_buffer('model')) < 1e-5
     # the two channels differ by the factor put into the visibilities
     m0 = serial[0]['imager'].get_buffer('model')
     m1 = serial[1]['imager'].get_buffer('model')
