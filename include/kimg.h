@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KIMG_VERSION 3
+#define KIMG_VERSION 4
 
 #define KIMG_EINVAL (-10001)      /* bad argument (null pointer, negative size ...) */
 #define KIMG_EUNSUPPORTED (-10002) /* parameter combination not supported by this build */
@@ -83,6 +83,16 @@ extern "C" {
 int kimg_version(void);
 /* Static string describing a return code of this library. */
 const char *kimg_error_string(int code);
+/* How many of the device's CUs the window kernels (kimg_grid / kimg_degrid, MFMA variants) fill with
+ * their resident workgroups: 256 (all; the default, also set by 0) down to 1.  Process-wide, takes
+ * effect with the next launch.  A process that keeps several channels in flight on one GPU
+ * (frontend.process_channel_stream) sets 192: the window kernels' workgroups stay for a whole launch
+ * (0.7 ms on a stored W-slice) and leave no room for another channel's CLEAN workgroups (1024
+ * threads, 64 KB of LDS), whose latency-bound chain then stands still; with 64 CUs left free a
+ * 12-channel stream with four in flight takes 6.1 instead of 7.2 ms per channel, one channel alone
+ * 16.1 instead of 15.6.  No counterpart in the reference (its kernels are not resident). */
+int kimg_set_window_cus(int cus);
+int kimg_get_window_cus(void);
 
 /* ---- convolution kernel table: grid.py:235-334 antialias_w_kernel, as called for every W plane
  * by ConvolutionKernel.__init__ (grid.py:358-389), evaluated on the device in float64.

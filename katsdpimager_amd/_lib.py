@@ -18,7 +18,7 @@ I = c_int
 L = c_int64
 F = c_float
 
-VERSION = 3     # KIMG_VERSION of include/kimg.h
+VERSION = 4     # KIMG_VERSION of include/kimg.h
 
 PROTOTYPES = {
     'kimg_version': (c_int, []),
@@ -47,6 +47,8 @@ PROTOTYPES = {
     'kimg_real_layer_to_image': (c_int, [P, L, P, L, I, P, F, F, P]),
     'kimg_image_to_real_layer': (c_int, [P, L, P, L, I, P, F, F, P]),
     'kimg_half_layer_to_grid': (c_int, [P, L, I, P, I, P]),
+    'kimg_set_window_cus': (c_int, [I]),
+    'kimg_get_window_cus': (c_int, []),
     'kimg_grid_image_real_supported': (c_int, [I, I]),
     'kimg_grid_image_real_workspace_bytes': (c_size_t, [I, I]),
     'kimg_grid_to_image_real': (c_int, [P, L, I, P, L, I, P, F, F, I, P, c_size_t, P]),

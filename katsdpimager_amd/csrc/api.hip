@@ -1,7 +1,24 @@
 // Version / error strings of the libkimg C ABI.
 #include "kimg_common.h"
 
+#include <atomic>
+
 extern "C" int kimg_version(void) { return KIMG_VERSION; }
+
+namespace {
+std::atomic<int> window_cus{256};
+}
+
+int kimg_window_cus_now() { return window_cus.load(std::memory_order_relaxed); }
+
+extern "C" int kimg_set_window_cus(int cus)
+{
+    KIMG_CHECK_ARG(cus >= 0 && cus <= 256);
+    window_cus.store(cus == 0 ? 256 : cus, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int kimg_get_window_cus(void) { return kimg_window_cus_now(); }
 
 extern "C" const char *kimg_error_string(int code)
 {

@@ -667,7 +667,7 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
         attr_set = true;
     }
-    const int blocks_max = 256;
+    const int blocks_max = kimg_window_cus_now();
     int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
     vis_per_block = (vis_per_block + 63) / 64 * 64;
     if (vis_per_block < 64 * NW)

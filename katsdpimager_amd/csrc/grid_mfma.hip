@@ -1174,7 +1174,7 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
     // as many blocks resident per CU as the LDS (kernel table + staging) allows;
     // every block streams a contiguous span (a multiple of 64).
     const int per_cu = (!TG && lds <= LDS_LIMIT / 2) ? 2 : 1;
-    const int blocks_max = 256 * per_cu;
+    const int blocks_max = kimg_window_cus_now() * per_cu;
     int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
     vis_per_block = (vis_per_block + 63) / 64 * 64;
     if (vis_per_block < 64 * NW)

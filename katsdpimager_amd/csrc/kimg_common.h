@@ -17,6 +17,10 @@ static inline int kimg_launch_status()
 
 static inline int kimg_divup(int64_t a, int64_t b) { return (int) ((a + b - 1) / b); }
 
+// CUs the window kernels (gridder, degridder) may fill with their resident workgroups
+// (kimg_set_window_cus; api.hip)
+int kimg_window_cus_now();
+
 constexpr int WAVE = 64;    // gfx950 wavefront
 
 // Wave-wide sum by DPP-backed shuffles; result valid in every lane.

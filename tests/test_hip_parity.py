@@ -59,6 +59,43 @@ def test_gridder_vs_golden(golden, name, variant):
     assert relerr(actual, expected) < GRID_TOL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('cus', [1, 7, 64, 192])
+def test_window_kernels_on_part_of_the_device(cus):
+    """kimg_set_window_cus: gridder and degridder on a part of the CUs (what a process with several
+    channels in flight sets, so that the other channels' CLEAN launches find room) give the results
+    of the whole device; the setting is process-wide and restored here."""
+    from katsdpimager_amd import grid
+    from katsdpimager_amd._lib import lib
+    c = gi.make_config(512, 0.0001, 0.01, 2, 28, 16, grid_cover=300, n_vis=60000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'mfma', max_vis=65536)
+    whole = _run_gridder(fn, q, t)
+    assert lib().kimg_get_window_cus() == 256
+    try:
+        assert lib().kimg_set_window_cus(cus) == 0 and lib().kimg_get_window_cus() == cus
+        part = _run_gridder(fn, q, t)
+        assert relerr(part, whole) < 2e-6
+        ip, gp, ap = make_params(c)
+        d = grid.DegridderTemplate(fn.template.context, ip.fixed, gp.fixed,
+                                   {'variant': 'mfma'}).instantiate(q, ap, ip, gp, 65536)
+        d.bind(grid=fn.buffer('grid'), uv=fn.buffer('uv'), w_plane=fn.buffer('w_plane'))
+        d.ensure_all_bound()
+        d.num_vis = len(t['uv'])
+        res = {}
+        for setting in (cus, 0):
+            assert lib().kimg_set_window_cus(setting) == 0
+            d.buffer('weights').set_region(q, np.ones(t['vis'].shape, np.float32),
+                                           np.s_[:len(t['uv'])], np.s_[:])
+            d.buffer('vis').set_region(q, t['vis'], np.s_[:len(t['uv'])], np.s_[:])
+            d()
+            res[setting] = d.buffer('vis').get(q)[:len(t['uv'])]
+        assert lib().kimg_get_window_cus() == 256          # 0 = all
+        np.testing.assert_allclose(res[cus], res[0], rtol=1e-5, atol=1e-5 * np.abs(res[0]).max())
+    finally:
+        lib().kimg_set_window_cus(0)
+
+
 @pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 @pytest.mark.parametrize('P', [1, 2, 3, 4])
 def test_gridder_bruteforce(variant, P):

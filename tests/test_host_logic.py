@@ -692,6 +692,21 @@ def test_process_channel_stream_bounds_live_jobs(monkeypatch):
     assert got == {c: 2 * c for c in range(7)}
 
 
+def test_window_cus_setting():
+    """kimg_set_window_cus / kimg_get_window_cus (host state only): 0 means all 256, values outside
+    0 ... 256 are refused and leave the setting alone."""
+    from katsdpimager_amd._lib import lib
+    handle = lib()
+    assert handle.kimg_get_window_cus() == 256
+    try:
+        assert handle.kimg_set_window_cus(192) == 0 and handle.kimg_get_window_cus() == 192
+        assert handle.kimg_set_window_cus(300) != 0 and handle.kimg_get_window_cus() == 192
+        assert handle.kimg_set_window_cus(-1) != 0 and handle.kimg_get_window_cus() == 192
+        assert handle.kimg_set_window_cus(0) == 0 and handle.kimg_get_window_cus() == 256
+    finally:
+        handle.kimg_set_window_cus(0)
+
+
 def test_clean_batcher_rendezvous(monkeypatch):
     """clean.CleanBatcher (host logic only; the device loop is faked): channels that arrive
     together share one enqueue, a patch too large for the one-launch form runs alone, a thread

@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import synth
+from katsdpimager_amd import _lib as _kl
+if os.environ.get("KIMG_VARIANT_LIB"):
+    _kl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_variants",
+                                "libkimg_%s.so" % os.environ["KIMG_VARIANT_LIB"])
 from katsdpimager_amd import accel, clean, frontend, imaging, parameters, preprocess, weight
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
