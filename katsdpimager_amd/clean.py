@@ -578,7 +578,7 @@ class CleanBatcher:
     before it either (each runs on the stream of its first channel).
     """
 
-    def __init__(self, parties, timeout=0.02, phased=False, overlap=True):
+    def __init__(self, parties, timeout=0.02, phased=False, overlap=True, phase_permits=1):
         import threading
         self._cond = threading.Condition()
         self._parties = int(parties)
@@ -586,7 +586,7 @@ class CleanBatcher:
         self._waiting = []
         self.phased = bool(phased)
         self._overlap = bool(overlap)
-        self._phase_lock = threading.Lock()
+        self._phase_lock = threading.Semaphore(max(1, int(phase_permits)))    # channels inside a device phase
         self._expected = set()      # threads between the end of a device phase and their cycles
         self._cleaning = 0          # channels whose cycles are running
         #: (number of channels, cycles asked for) of every launch sequence so far, for tests / reports

@@ -61,7 +61,7 @@ torch.cuda.synchronize()
 print('one channel at a time: %.2f ms per channel' % ((time.perf_counter() - t0) * 1e3 / 4))
 _make = clean.CleanBatcher
 for workers in workers_list:
-    for name, kw in (('in step', None), ('turns', dict(overlap=True)), ('turns, one batch at a time', dict(overlap=False))):
+    for name, kw in (('in step', None), ('turns', dict(overlap=True)), ('turns, two at a time', dict(phase_permits=2))):
         if kw is not None:
             clean.CleanBatcher = lambda parties, phased=False, kw=kw: _make(parties, phased=True, **kw)
         else:
