@@ -423,8 +423,8 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     P, G = args.polarizations, args.pixels
 
     # grid -> image: at w = 0 (every slice of C2 / C5) the Hermitian part of the grid goes through a
-    # complex-to-real transform of half the size -- for a layer size that is a power of two in two
-    # launches of the library's own (kimg_grid_to_image_real: only the columns the grid reaches,
+    # complex-to-real transform of half the size -- for an even layer size without a prime factor
+    # above 7 in two launches of the library's own (kimg_grid_to_image_real: only the columns the grid reaches,
     # fold / padding / image correction fused), else kimg_grid_to_half_layer + rocFFT C2R in place +
     # kimg_real_layer_to_image; at w != 0 pad/shift + rocFFT C2C + layer_to_image
     Gg = grid_buf.shape[1]

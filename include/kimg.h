@@ -303,8 +303,9 @@ int kimg_image_to_real_layer(float *layer, int64_t layer_row_stride, const float
 int kimg_half_layer_to_grid(void *grid, int64_t grid_row_stride, int grid_size,
                             const void *half_layer, int layer_size, void *stream);
 /* The whole of GridToImage.__call__ / ImageToGrid.__call__ (image.py:609-673, :676-740) for one
- * polarization at w = 0 in two launches, with transforms of the library's own (layer sizes that
- * are powers of two, 16 .. 8192): only the Gg/2 + 1 columns of the half layer the grid reaches
+ * polarization at w = 0 in two launches, with transforms of the library's own (even layer sizes
+ * 16 .. 8192 with no prime factor above 7 -- every size parameters.py:17-25 of the reference picks
+ * in that range; mixed radix 4 / 2 / 3 / 5 / 7 in LDS): only the Gg/2 + 1 columns of the half layer the grid reaches
  * are transformed, the fold / padding and the image correction are the prologue and epilogue of
  * the transform kernels, and what passes between the two launches is (Gg/2 + 1) x G cells in
  * `workspace` (16-byte aligned, kimg_grid_image_real_workspace_bytes; the layer buffer will do).

@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void apply_primary_beam_kernel(
 // those columns only, reading the grid directly (fold and padding on the fly), and one launch of
 // row transforms, two real rows per complex transform, with the image correction as its
 // epilogue; what passes between them is (Gg/2 + 1) x G cells (20 MB at 4096 / 1244).
-// Transforms: in-LDS radix-4 decimation in time (one radix-2 stage when log2 G is odd) on
-// bit-reversed input, one workgroup per transform, twiddles from a table.
+// Transforms: in LDS, decimation in time in stages of radix 4, 2, 3, 5, 7 on digit-reversed
+// input (any size 2^a 3^b 5^c 7^d up to 8192 -- the sizes the reference picks, parameters.py:17-25),
+// one workgroup per transform, twiddles from a table.
 constexpr int FFT_THREADS = 512;
 constexpr int FFT_UNROLL = 2;       // butterflies a thread has in flight (4096 cells: all it has)
 
@@ -268,103 +269,170 @@ __device__ inline float2 cmul(float2 a, float2 b)
 __device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-__device__ inline int bit_reverse(int i, int log2G) { return (int) (__brev((unsigned) i) >> (32 - log2G)); }
-
 // LDS index of cell i: one cell of padding per 32, so that the strided accesses of the first
-// stages (and the bit-reversed scatter before them) spread over the banks.
+// stages (and the digit-reversed scatter before them) spread over the banks.
 __device__ __host__ inline int fft_pad(int i) { return i + (i >> 5); }
 
-// Twiddles, one contiguous run per stage (a table indexed j * G / 4q would be read with strides
-// that put all 64 lanes on one bank): for the radix-4 stage of quarter length q = 1, 4, 16 ...
-// q cells e^{2 pi i j / 4q} from offset (q - 1) / 3 (the stage's other twiddle is their square),
-// and G / 2 cells e^{2 pi i j / G} for the radix-2 stage that ends an odd log2 G.
-__host__ __device__ inline int fft_twiddle_count(int G)
+// A transform of G = 2^a 3^b 5^c 7^d cells: decimation in time, in place, stages of radix 4 (two
+// radix-2 steps in one pass over LDS), 2, 3, 5 and 7 in that order; the input goes in at the cells
+// the generalised digit reversal names (`perm`, made once per size on the host), the result comes
+// out in natural order.  Twiddles, one contiguous run per stage (a single table indexed
+// j G / rq would be read with strides that put all 64 lanes on one bank): for the stage of radix r
+// over blocks of q cells, q cells e^{2 pi i j / rq} (the stage's other twiddles are their powers).
+struct fft_plan {
+    const float2 *twiddle;
+    const unsigned short *perm;     // LDS cell (before padding) of input index n
+    int twiddles;                   // cells of `twiddle`
+    int stages;
+    int log2size;                   // log2 G when G is a power of two (perm is then the bit reversal)
+    unsigned char radix[16];
+};
+
+// ODD: the size has factors 3, 5 or 7.  Powers of two get kernels without those stages (fewer
+// registers: three workgroups per CU instead of two) that compute the bit reversal themselves.
+template<bool ODD>
+__device__ inline int fft_cell(const fft_plan &plan, int n)
+{
+    return ODD ? (int) plan.perm[n] : (int) (__brev((unsigned) n) >> (32 - plan.log2size));
+}
+
+template<bool INVERSE>
+__device__ inline float2 fft_conj_if_forward(float2 w) { return INVERSE ? w : make_float2(w.x, -w.y); }
+
+// Radix 3, 5, 7: out[c] = sum_k in[k] e^{+-2 pi i k c / R} with the R-th roots of unity as constants
+template<int R> struct fft_roots;
+template<> struct fft_roots<3> {
+    static constexpr float c[3] = {1.0f, -0.5f, -0.5f};
+    static constexpr float s[3] = {0.0f, 0.86602540378443865f, -0.86602540378443865f};
+};
+template<> struct fft_roots<5> {
+    static constexpr float c[5] = {1.0f, 0.30901699437494742f, -0.80901699437494742f,
+                                   -0.80901699437494742f, 0.30901699437494742f};
+    static constexpr float s[5] = {0.0f, 0.95105651629515357f, 0.58778525229247313f,
+                                   -0.58778525229247313f, -0.95105651629515357f};
+};
+template<> struct fft_roots<7> {
+    static constexpr float c[7] = {1.0f, 0.62348980185873353f, -0.22252093395631440f,
+                                   -0.90096886790241913f, -0.90096886790241913f,
+                                   -0.22252093395631440f, 0.62348980185873353f};
+    static constexpr float s[7] = {0.0f, 0.78183148246802981f, 0.97492791218182361f,
+                                   0.43388373911755812f, -0.43388373911755812f,
+                                   -0.97492791218182361f, -0.78183148246802981f};
+};
+
+template<bool INVERSE, int R>
+__device__ inline void fft_stage_odd(float2 *x, const float2 *tw, int G, int q)
+{
+    for (int t = threadIdx.x; t < G / R; t += FFT_THREADS) {
+        const int block = t / q, j = t - block * q;
+        const int base = block * (R * q) + j;
+        const float2 w = fft_conj_if_forward<INVERSE>(tw[j]);
+        float2 in[R];
+        int at[R];
+        float2 wk = make_float2(1.0f, 0.0f);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            at[k] = fft_pad(base + k * q);
+            in[k] = k ? cmul(wk, x[at[k]]) : x[at[k]];
+            wk = k ? cmul(wk, w) : w;
+        }
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+            float2 acc = in[0];
+#pragma unroll
+            for (int k = 1; k < R; k++) {
+                const int m = (k * c) % R;
+                const float2 root = make_float2(fft_roots<R>::c[m],
+                                                INVERSE ? fft_roots<R>::s[m] : -fft_roots<R>::s[m]);
+                acc = cadd(acc, cmul(root, in[k]));
+            }
+            x[at[c]] = acc;
+        }
+    }
+}
+
+// x: G cells in `perm` order on entry, the transform (sign + for INVERSE, unnormalised) in natural
+// order on return.  Called by the whole workgroup; starts and ends with a barrier.
+template<bool INVERSE, bool ODD>
+__device__ inline void lds_fft(float2 *x, const float2 *tw, int G, const fft_plan &plan)
 {
     int q = 1;
-    while (4 * q <= G)
-        q *= 4;
-    return (q - 1) / 3 + (q < G ? G / 2 : 0);
-}
-
-__global__ __launch_bounds__(256) void twiddle_kernel(float2 *__restrict__ tw, int G)
-{
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= fft_twiddle_count(G))
-        return;
-    int q = 1, offset = 0;
-    while (4 * q <= G && n >= offset + q) {
-        offset += q;
-        q *= 4;
+    // (a power of two: the stages follow from G -- radix 4 while it fits, then one radix 2 --
+    // and nothing is read from the plan between the barriers)
+    const int stages = ODD ? plan.stages : (plan.log2size + 1) / 2;
+    // (the radices are fetched once, up front: a scalar load per stage would sit between its barriers)
+    unsigned radix_words[4] = {0, 0, 0, 0};
+    if (ODD) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            radix_words[i] = (unsigned) plan.radix[4 * i] | ((unsigned) plan.radix[4 * i + 1] << 8)
+                             | ((unsigned) plan.radix[4 * i + 2] << 16) | ((unsigned) plan.radix[4 * i + 3] << 24);
     }
-    double angle;
-    if (4 * q <= G) {
-        angle = (double) (n - offset) / (double) (4 * q);
-    } else {
-        angle = (double) (n - offset) / (double) G;
-    }
-    double s, c;
-    sincospi(2.0 * angle, &s, &c);
-    tw[n] = make_float2((float) c, (float) s);
-}
-
-// x: G cells in bit-reversed order on entry, the transform (sign + for INVERSE, unnormalised) in
-// natural order on return.  Called by the whole workgroup; starts and ends with a barrier.
-template<bool INVERSE>
-__device__ inline void lds_fft(float2 *x, const float2 *tw, int G, int log2G)
-{
-    int q = 1, shift = 0;
-    for (; 4 * q <= G; q *= 4, shift += 2) {
+    for (int stage = 0; stage < stages; stage++) {
+        const unsigned word = stage < 4 ? radix_words[0] : stage < 8 ? radix_words[1]
+                              : stage < 12 ? radix_words[2] : radix_words[3];
+        const int r = ODD ? (int) ((word >> (8 * (stage & 3))) & 255u) : (4 * q <= G ? 4 : 2);
         __syncthreads();
-        for (int t0 = threadIdx.x; t0 < G / 4; t0 += FFT_UNROLL * FFT_THREADS) {
-            float2 a[FFT_UNROLL][4], w2[FFT_UNROLL];
-            int at[FFT_UNROLL][4];
+        if (r == 4) {
+            // (q is a power of two here: the radix-4 and radix-2 stages come first)
+            const int shift = ODD ? 31 - __clz(q) : 2 * stage;
+            for (int t0 = threadIdx.x; t0 < G / 4; t0 += FFT_UNROLL * FFT_THREADS) {
+                float2 a[FFT_UNROLL][4], w2[FFT_UNROLL];
+                int at[FFT_UNROLL][4];
 #pragma unroll
-            for (int u = 0; u < FFT_UNROLL; u++) {
-                const int t = t0 + u * FFT_THREADS;
-                if (t < G / 4) {
-                    const int j = t & (q - 1);
-                    const int base = ((t >> shift) << (shift + 2)) + j;
-                    w2[u] = tw[j];
+                for (int u = 0; u < FFT_UNROLL; u++) {
+                    const int t = t0 + u * FFT_THREADS;
+                    if (t < G / 4) {
+                        const int j = t & (q - 1);
+                        const int base = ((t >> shift) << (shift + 2)) + j;
+                        w2[u] = tw[j];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        at[u][k] = fft_pad(base + k * q);
-                        a[u][k] = x[at[u][k]];
+                        for (int k = 0; k < 4; k++) {
+                            at[u][k] = fft_pad(base + k * q);
+                            a[u][k] = x[at[u][k]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FFT_UNROLL; u++) {
+                    if (t0 + u * FFT_THREADS < G / 4) {
+                        if (!INVERSE)
+                            w2[u].y = -w2[u].y;
+                        const float2 w1 = cmul(w2[u], w2[u]);
+                        const float2 a0 = a[u][0], a1 = cmul(w1, a[u][1]);
+                        const float2 a2 = a[u][2], a3 = cmul(w1, a[u][3]);
+                        const float2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
+                        const float2 b2 = cmul(w2[u], cadd(a2, a3));
+                        const float2 t3 = cmul(w2[u], csub(a2, a3));
+                        // the twiddle of the second pair is w2 times e^{+-i pi / 2}
+                        const float2 b3 = INVERSE ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
+                        x[at[u][0]] = cadd(b0, b2);
+                        x[at[u][2]] = csub(b0, b2);
+                        x[at[u][1]] = cadd(b1, b3);
+                        x[at[u][3]] = csub(b1, b3);
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < FFT_UNROLL; u++) {
-                if (t0 + u * FFT_THREADS < G / 4) {
-                    if (!INVERSE)
-                        w2[u].y = -w2[u].y;
-                    const float2 w1 = cmul(w2[u], w2[u]);
-                    const float2 a0 = a[u][0], a1 = cmul(w1, a[u][1]);
-                    const float2 a2 = a[u][2], a3 = cmul(w1, a[u][3]);
-                    const float2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
-                    const float2 b2 = cmul(w2[u], cadd(a2, a3));
-                    const float2 t3 = cmul(w2[u], csub(a2, a3));
-                    // the twiddle of the second pair is w2 times e^{+-i pi / 2}
-                    const float2 b3 = INVERSE ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
-                    x[at[u][0]] = cadd(b0, b2);
-                    x[at[u][2]] = csub(b0, b2);
-                    x[at[u][1]] = cadd(b1, b3);
-                    x[at[u][3]] = csub(b1, b3);
-                }
+        } else if (r == 2) {
+            const int shift = 31 - __clz(q);
+            for (int t = threadIdx.x; t < G / 2; t += FFT_THREADS) {
+                const int j = t & (q - 1);
+                const int base = ((t >> shift) << (shift + 1)) + j;
+                const float2 w = fft_conj_if_forward<INVERSE>(tw[j]);
+                const int i0 = fft_pad(base), i1 = fft_pad(base + q);
+                const float2 a0 = x[i0], a1 = cmul(w, x[i1]);
+                x[i0] = cadd(a0, a1);
+                x[i1] = csub(a0, a1);
             }
+        } else if (ODD && r == 3) {
+            fft_stage_odd<INVERSE, 3>(x, tw, G, q);
+        } else if (ODD && r == 5) {
+            fft_stage_odd<INVERSE, 5>(x, tw, G, q);
+        } else if (ODD) {
+            fft_stage_odd<INVERSE, 7>(x, tw, G, q);
         }
         tw += q;
-    }
-    if (q < G) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < G / 2; t += FFT_THREADS) {
-            float2 w = tw[t];
-            if (!INVERSE)
-                w.y = -w.y;
-            const int i0 = fft_pad(t), i1 = fft_pad(t + q);
-            const float2 a0 = x[i0], a1 = cmul(w, x[i1]);
-            x[i0] = cadd(a0, a1);
-            x[i1] = csub(a0, a1);
-        }
+        q *= r;
     }
     __syncthreads();
 }
@@ -372,12 +440,10 @@ __device__ inline void lds_fft(float2 *x, const float2 *tw, int G, int log2G)
 // LDS of the transform kernels: the (padded) cells, then the twiddles
 __host__ __device__ inline int fft_lds_cells(int G) { return fft_pad(G) + 1; }
 
-__device__ inline void fft_lds_setup(float2 *x, float2 *tw, const float2 *__restrict__ twiddle, int G,
-                                     bool clear)
+__device__ inline void fft_lds_setup(float2 *x, float2 *tw, const fft_plan &plan, int G, bool clear)
 {
-    const int count = fft_twiddle_count(G);
-    for (int i = threadIdx.x; i < count; i += FFT_THREADS)
-        tw[i] = twiddle[i];
+    for (int i = threadIdx.x; i < plan.twiddles; i += FFT_THREADS)
+        tw[i] = plan.twiddle[i];
     if (clear)
         for (int i = threadIdx.x; i < fft_lds_cells(G); i += FFT_THREADS)
             x[i] = make_float2(0.0f, 0.0f);
@@ -396,22 +462,23 @@ __device__ inline int xcd_contiguous(int block, int blocks)
 }
 
 // Column lx of the half layer (never stored): T[lx][sy] = sum_ly half_layer[ly][lx] e^{2 pi i ly sy / G}
+template<bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
     float2 *__restrict__ T, const float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle)
+    fft_plan plan)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, true);
+    fft_lds_setup(x, tw, plan, G, true);
     const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     // the rows the grid (or its mirror image) reaches: centred -half .. half
     const int rows = 2 * half == G ? G : Gg + 1;
     for (int r = threadIdx.x; r < rows; r += FFT_THREADS) {
         const int cy = r - half;
         const int ly = cy < 0 ? cy + G : cy;
-        x[fft_pad(bit_reverse(ly, log2G))] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
+        x[fft_pad(fft_cell<ODD>(plan, ly))] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
     }
-    lds_fft<true>(x, tw, G, log2G);
+    lds_fft<true, ODD>(x, tw, G, plan);
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
         T[(int64_t) lx * G + sy] = x[fft_pad(sy)];
 }
@@ -419,27 +486,27 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
 // Rows sy1 = 2 * blockIdx.x and sy1 + 1 of the real transform: both Hermitian sequences in one
 // complex transform (z = row1 + i row2 comes out with row1 in its real part, row2 in its
 // imaginary part), then real_layer_to_image_kernel's arithmetic.
-template<bool ACCUMULATE>
+template<bool ACCUMULATE, bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
     float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, true);
+    fft_lds_setup(x, tw, plan, G, true);
     const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int n = threadIdx.x; n <= half; n += FFT_THREADS) {
         // (t.x, t.y) = T[n][sy1], (t.z, t.w) = T[n][sy1 + 1]
         const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + sy1);
         if (n == 0 || 2 * n == G) {
-            x[fft_pad(bit_reverse(n, log2G))] = make_float2(t.x, t.z);       // (real up to rounding)
+            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x, t.z);       // (real up to rounding)
         } else {
-            x[fft_pad(bit_reverse(n, log2G))] = make_float2(t.x - t.w, t.y + t.z);
-            x[fft_pad(bit_reverse(G - n, log2G))] = make_float2(t.x + t.w, t.z - t.y);
+            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x - t.w, t.y + t.z);
+            x[fft_pad(fft_cell<ODD>(plan, G - n))] = make_float2(t.x + t.w, t.z - t.y);
         }
     }
-    lds_fft<true>(x, tw, G, log2G);
+    lds_fft<true, ODD>(x, tw, G, plan);
     const int hG = G / 2;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -464,14 +531,15 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
 // image -> grid, rows: two real layer rows (image_to_real_layer_kernel's arithmetic) as one
 // complex sequence, forward transform, the two half spectra taken apart;
 // T[lx][sy] for lx = 0 .. Gg / 2.
+template<bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
     float2 *__restrict__ T, const float *__restrict__ image, int64_t image_row_stride, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, false);
+    fft_lds_setup(x, tw, plan, G, false);
     const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
     const int y1 = fft_shift(sy1, hG), y2 = fft_shift(sy1 + 1, hG);
     const float ma = lm_coord(y1, lm_scale, lm_bias), mb = lm_coord(y2, lm_scale, lm_bias);
@@ -485,9 +553,9 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
         const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
         const float va = image[(int64_t) y1 * image_row_stride + xx] / ((ka * kx) * na);
         const float vb = image[(int64_t) y2 * image_row_stride + xx] / ((kb * kx) * nb);
-        x[fft_pad(bit_reverse(sx, log2G))] = make_float2(va, vb);
+        x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(va, vb);
     }
-    lds_fft<false>(x, tw, G, log2G);
+    lds_fft<false, ODD>(x, tw, G, plan);
     for (int lx = threadIdx.x; lx <= half; lx += FFT_THREADS) {
         const float2 z = x[fft_pad(lx)], zm = x[fft_pad(lx ? G - lx : 0)];
         // row a: (z + conj zm) / 2, row b: (z - conj zm) / 2i
@@ -499,17 +567,18 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
 
 // image -> grid, columns: F[ly][lx] = sum_sy T[lx][sy] e^{-2 pi i ly sy / G}; grid column
 // half + lx from it, column half - lx from its mirror image (half_layer_to_grid_kernel).
+template<bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void i2g_columns_kernel(
     float2 *__restrict__ grid, int64_t grid_row_stride, const float2 *__restrict__ T, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle)
+    fft_plan plan)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, false);
+    fft_lds_setup(x, tw, plan, G, false);
     const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        x[fft_pad(bit_reverse(sy, log2G))] = T[(int64_t) lx * G + sy];
-    lds_fft<false>(x, tw, G, log2G);
+        x[fft_pad(fft_cell<ODD>(plan, sy))] = T[(int64_t) lx * G + sy];
+    lds_fft<false, ODD>(x, tw, G, plan);
     for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS) {
         const int cy = gy - half;
         const int ly = cy < 0 ? cy + G : cy;
@@ -536,31 +605,33 @@ __device__ inline int grid_to_layer_index(int c, int half, int G)
     return centred < 0 ? centred + G : centred;
 }
 
+template<bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void g2iw_columns_kernel(
     float2 *__restrict__ T, const float2 *__restrict__ grid, int64_t grid_row_stride, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle)
+    fft_plan plan)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, true);
+    fft_lds_setup(x, tw, plan, G, true);
     const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int r = threadIdx.x; r < Gg; r += FFT_THREADS)
-        x[fft_pad(bit_reverse(grid_to_layer_index(r, half, G), log2G))] = grid[(int64_t) r * grid_row_stride + c];
-    lds_fft<true>(x, tw, G, log2G);
+        x[fft_pad(fft_cell<ODD>(plan, grid_to_layer_index(r, half, G)))] = grid[(int64_t) r * grid_row_stride + c];
+    lds_fft<true, ODD>(x, tw, G, plan);
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
         T[(int64_t) c * G + sy] = x[fft_pad(sy)];
 }
 
 // layer_to_image_kernel's arithmetic on rows sy1 = 2 * blockIdx.x and sy1 + 1
-template<bool ACCUMULATE>
-__global__ __launch_bounds__(FFT_THREADS) void g2iw_rows_kernel(
+// (at most 128 registers: two workgroups per CU)
+template<bool ACCUMULATE, bool ODD>
+__global__ __launch_bounds__(FFT_THREADS, 4) void g2iw_rows_kernel(
     float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias, float w)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, true);
+    fft_lds_setup(x, tw, plan, G, true);
     const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
     float2 second[FFT_ROW_CELLS];
 #pragma unroll
@@ -568,7 +639,7 @@ __global__ __launch_bounds__(FFT_THREADS) void g2iw_rows_kernel(
         const int c = threadIdx.x + k * FFT_THREADS;
         if (c < Gg) {
             const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) c * G + sy1);
-            x[fft_pad(bit_reverse(grid_to_layer_index(c, half, G), log2G))] = make_float2(t.x, t.y);
+            x[fft_pad(fft_cell<ODD>(plan, grid_to_layer_index(c, half, G)))] = make_float2(t.x, t.y);
             second[k] = make_float2(t.z, t.w);
         }
     }
@@ -583,10 +654,10 @@ __global__ __launch_bounds__(FFT_THREADS) void g2iw_rows_kernel(
             for (int k = 0; k < FFT_ROW_CELLS; k++) {
                 const int c = threadIdx.x + k * FFT_THREADS;
                 if (c < Gg)
-                    x[fft_pad(bit_reverse(grid_to_layer_index(c, half, G), log2G))] = second[k];
+                    x[fft_pad(fft_cell<ODD>(plan, grid_to_layer_index(c, half, G)))] = second[k];
             }
         }
-        lds_fft<true>(x, tw, G, log2G);
+        lds_fft<true, ODD>(x, tw, G, plan);
         const int y = fft_shift(sy1 + r, hG);
         const float m = lm_coord(y, lm_scale, lm_bias);
         const float m2 = m * m;
@@ -609,14 +680,15 @@ __global__ __launch_bounds__(FFT_THREADS) void g2iw_rows_kernel(
 }
 
 // image_to_layer_kernel's arithmetic on two rows, forward transforms, the Gg columns kept
-__global__ __launch_bounds__(FFT_THREADS) void i2gw_rows_kernel(
+template<bool ODD>
+__global__ __launch_bounds__(FFT_THREADS, 4) void i2gw_rows_kernel(
     float2 *__restrict__ T, const float *__restrict__ image, int64_t image_row_stride, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle, const float *__restrict__ kernel1d,
+    fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias, float w)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, false);
+    fft_lds_setup(x, tw, plan, G, false);
     const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2, hG = G / 2;
     float2 first[FFT_ROW_CELLS];
 #pragma unroll
@@ -636,9 +708,9 @@ __global__ __launch_bounds__(FFT_THREADS) void i2gw_rows_kernel(
             expj2pi(-w * (n - 1.0f), c, s);
             const float taper = ky * kernel1d[xx];
             const float v = image[(int64_t) y * image_row_stride + xx] / (taper * n);
-            x[fft_pad(bit_reverse(sx, log2G))] = make_float2(v * c, v * s);
+            x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(v * c, v * s);
         }
-        lds_fft<false>(x, tw, G, log2G);
+        lds_fft<false, ODD>(x, tw, G, plan);
 #pragma unroll
         for (int k = 0; k < FFT_ROW_CELLS; k++) {
             const int c = threadIdx.x + k * FFT_THREADS;
@@ -654,17 +726,18 @@ __global__ __launch_bounds__(FFT_THREADS) void i2gw_rows_kernel(
     }
 }
 
+template<bool ODD>
 __global__ __launch_bounds__(FFT_THREADS) void i2gw_columns_kernel(
     float2 *__restrict__ grid, int64_t grid_row_stride, const float2 *__restrict__ T, int Gg, int G,
-    int log2G, const float2 *__restrict__ twiddle)
+    fft_plan plan)
 {
     extern __shared__ float2 fft_lds[];
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
-    fft_lds_setup(x, tw, twiddle, G, false);
+    fft_lds_setup(x, tw, plan, G, false);
     const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        x[fft_pad(bit_reverse(sy, log2G))] = T[(int64_t) c * G + sy];
-    lds_fft<false>(x, tw, G, log2G);
+        x[fft_pad(fft_cell<ODD>(plan, sy))] = T[(int64_t) c * G + sy];
+    lds_fft<false, ODD>(x, tw, G, plan);
     for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS)
         grid[(int64_t) gy * grid_row_stride + c] = x[fft_pad(grid_to_layer_index(gy, half, G))];
 }
@@ -925,47 +998,110 @@ extern "C" int kimg_image_nansum(const float *image, int64_t row_stride, int64_t
 }
 
 // ---- grid <-> image at w = 0, own transforms ------------------------------------------------
+#include <cmath>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
 namespace {
 
-struct twiddle_entry { int device, size; float2 *table; };
-std::mutex twiddle_mutex;
-std::vector<twiddle_entry> twiddle_tables;
+struct plan_entry { int device, size; fft_plan plan; };
+std::mutex plan_mutex;
+std::vector<plan_entry> plans;
 
-// The table for transforms of G cells on the current device: made once (and the stream waited
-// for, so that every other stream may read it), never freed.
-int twiddle_table(int G, hipStream_t s, const float2 **out)
+// Radices of the stages for G cells (4s, then at most one 2, then 3s, 5s, 7s), or false when G has
+// another prime factor
+bool fft_stages(int G, fft_plan *plan)
+{
+    int twos = 0, rest = G, n = 0;
+    while (rest % 2 == 0) {
+        rest /= 2;
+        twos++;
+    }
+    for (int i = 0; i < twos / 2; i++)
+        plan->radix[n++] = 4;
+    if (twos % 2)
+        plan->radix[n++] = 2;
+    for (int r : {3, 5, 7})
+        while (rest % r == 0) {
+            if (n >= 16)
+                return false;
+            rest /= r;
+            plan->radix[n++] = (unsigned char) r;
+        }
+    plan->stages = n;
+    return rest == 1 && n > 0;
+}
+
+// The plan for transforms of G cells on the current device: twiddles and digit reversal made once
+// on the host (in double) and copied over -- the stream is waited for, so that every other stream
+// may use them --, never freed.
+int fft_plan_for(int G, hipStream_t s, fft_plan *out)
 {
     int device = 0;
     KIMG_HIP(hipGetDevice(&device));
-    std::lock_guard<std::mutex> lock(twiddle_mutex);
-    for (const twiddle_entry &e : twiddle_tables)
+    std::lock_guard<std::mutex> lock(plan_mutex);
+    for (const plan_entry &e : plans)
         if (e.device == device && e.size == G) {
-            *out = e.table;
+            *out = e.plan;
             return 0;
         }
-    float2 *table = nullptr;
-    const int count = fft_twiddle_count(G);
-    KIMG_HIP(hipMalloc((void **) &table, sizeof(float2) * (size_t) count));
-    twiddle_kernel<<<kimg_divup(count, 256), 256, 0, s>>>(table, G);
-    hipError_t e = hipStreamSynchronize(s);
+    fft_plan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    if (!fft_stages(G, &plan))
+        return KIMG_EUNSUPPORTED;
+    std::vector<float2> tw;
+    std::vector<int> radix2;        // the radix-4 stages as the two radix-2 steps they are
+    int q = 1;
+    for (int i = 0; i < plan.stages; i++) {
+        const int r = plan.radix[i];
+        for (int j = 0; j < q; j++) {
+            const double angle = 2.0 * M_PI * (double) j / (double) (r * q);
+            tw.push_back(make_float2((float) cos(angle), (float) sin(angle)));
+        }
+        q *= r;
+        if (r == 4) {
+            radix2.push_back(2);
+            radix2.push_back(2);
+        } else {
+            radix2.push_back(r);
+        }
+    }
+    std::vector<unsigned short> perm(G);
+    for (int n = 0; n < G; n++) {
+        int rem = n, block = G, pos = 0;
+        for (int i = (int) radix2.size() - 1; i >= 0; i--) {
+            block /= radix2[i];
+            pos += (rem % radix2[i]) * block;
+            rem /= radix2[i];
+        }
+        perm[n] = (unsigned short) pos;
+    }
+    float2 *d_tw = nullptr;
+    unsigned short *d_perm = nullptr;
+    KIMG_HIP(hipMalloc((void **) &d_tw, sizeof(float2) * tw.size()));
+    hipError_t e = hipMalloc((void **) &d_perm, sizeof(unsigned short) * perm.size());
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_perm, perm.data(), sizeof(unsigned short) * perm.size(),
+                           hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);        // (also: the host vectors go out of scope)
     if (e != hipSuccess) {
-        (void) hipFree(table);
+        (void) hipFree(d_tw);
+        (void) hipFree(d_perm);
         return -(int) e;
     }
-    twiddle_tables.push_back(twiddle_entry{device, G, table});
-    *out = table;
+    plan.twiddle = d_tw;
+    plan.perm = d_perm;
+    plan.twiddles = (int) tw.size();
+    if ((G & (G - 1)) == 0)
+        while ((1 << plan.log2size) < G)
+            plan.log2size++;
+    plans.push_back(plan_entry{device, G, plan});
+    *out = plan;
     return 0;
-}
-
-int fft_log2(int G)
-{
-    int k = 0;
-    while ((1 << k) < G)
-        k++;
-    return k;
 }
 
 template<typename Kernel>
@@ -977,11 +1113,18 @@ int fft_lds_attribute(Kernel kernel, size_t lds)
     return 0;
 }
 
+size_t fft_lds_bytes(int G, const fft_plan &plan)
+{
+    return sizeof(float2) * (size_t) (fft_lds_cells(G) + plan.twiddles);
+}
+
 } // namespace
 
 extern "C" int kimg_grid_image_real_supported(int layer_size, int grid_size)
 {
-    return layer_size >= 16 && layer_size <= 8192 && (layer_size & (layer_size - 1)) == 0
+    fft_plan plan;
+    // (even sizes: rows go in pairs; 160 KB of LDS hold the cells and the twiddles up to 8192)
+    return layer_size >= 16 && layer_size <= 8192 && layer_size % 2 == 0 && fft_stages(layer_size, &plan)
         && grid_size >= 2 && grid_size % 2 == 0 && grid_size <= layer_size;
 }
 
@@ -1004,25 +1147,33 @@ extern "C" int kimg_grid_to_image_real(float *image, int64_t image_row_stride, i
     KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_real_workspace_bytes(layer_size, grid_size));
     KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
     hipStream_t s = (hipStream_t) stream;
-    const int G = layer_size, log2G = fft_log2(G);
-    const float2 *tw = nullptr;
-    int rc = twiddle_table(G, s, &tw);
+    const int G = layer_size;
+    fft_plan plan;
+    int rc = fft_plan_for(G, s, &plan);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
-    if ((rc = fft_lds_attribute(&g2i_columns_kernel, lds))
-        || (rc = fft_lds_attribute(&g2i_rows_kernel<true>, lds))
-        || (rc = fft_lds_attribute(&g2i_rows_kernel<false>, lds)))
-        return rc;
+    const size_t lds = fft_lds_bytes(G, plan);
     float2 *T = static_cast<float2 *>(workspace);
-    g2i_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
-        T, static_cast<const float2 *>(grid), grid_row_stride, grid_size, G, log2G, tw);
-    if (accumulate)
-        g2i_rows_kernel<true><<<G / 2, FFT_THREADS, lds, s>>>(
-            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+    const float2 *g = static_cast<const float2 *>(grid);
+    const int columns = grid_size / 2 + 1;
+#define G2I(ODD) do { \
+        if ((rc = fft_lds_attribute(&g2i_columns_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&g2i_rows_kernel<true, ODD>, lds)) \
+            || (rc = fft_lds_attribute(&g2i_rows_kernel<false, ODD>, lds))) \
+            return rc; \
+        g2i_columns_kernel<ODD><<<columns, FFT_THREADS, lds, s>>>(T, g, grid_row_stride, grid_size, G, plan); \
+        if (accumulate) \
+            g2i_rows_kernel<true, ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+                image, image_row_stride, T, grid_size, G, plan, kernel1d, lm_scale, lm_bias); \
+        else \
+            g2i_rows_kernel<false, ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+                image, image_row_stride, T, grid_size, G, plan, kernel1d, lm_scale, lm_bias); \
+    } while (0)
+    if (plan.log2size)
+        G2I(false);
     else
-        g2i_rows_kernel<false><<<G / 2, FFT_THREADS, lds, s>>>(
-            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
+        G2I(true);
+#undef G2I
     return kimg_launch_status();
 }
 
@@ -1037,19 +1188,28 @@ extern "C" int kimg_image_to_grid_real(void *grid, int64_t grid_row_stride, int 
     KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_real_workspace_bytes(layer_size, grid_size));
     KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
     hipStream_t s = (hipStream_t) stream;
-    const int G = layer_size, log2G = fft_log2(G);
-    const float2 *tw = nullptr;
-    int rc = twiddle_table(G, s, &tw);
+    const int G = layer_size;
+    fft_plan plan;
+    int rc = fft_plan_for(G, s, &plan);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
-    if ((rc = fft_lds_attribute(&i2g_rows_kernel, lds)) || (rc = fft_lds_attribute(&i2g_columns_kernel, lds)))
-        return rc;
+    const size_t lds = fft_lds_bytes(G, plan);
     float2 *T = static_cast<float2 *>(workspace);
-    i2g_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
-        T, image, image_row_stride, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias);
-    i2g_columns_kernel<<<grid_size / 2 + 1, FFT_THREADS, lds, s>>>(
-        static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, log2G, tw);
+    const int columns = grid_size / 2 + 1;
+#define I2G(ODD) do { \
+        if ((rc = fft_lds_attribute(&i2g_rows_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&i2g_columns_kernel<ODD>, lds))) \
+            return rc; \
+        i2g_rows_kernel<ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+            T, image, image_row_stride, grid_size, G, plan, kernel1d, lm_scale, lm_bias); \
+        i2g_columns_kernel<ODD><<<columns, FFT_THREADS, lds, s>>>( \
+            static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, plan); \
+    } while (0)
+    if (plan.log2size)
+        I2G(false);
+    else
+        I2G(true);
+#undef I2G
     return kimg_launch_status();
 }
 
@@ -1073,25 +1233,32 @@ extern "C" int kimg_grid_to_image_w(float *image, int64_t image_row_stride, int 
     KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_w_workspace_bytes(layer_size, grid_size));
     KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
     hipStream_t s = (hipStream_t) stream;
-    const int G = layer_size, log2G = fft_log2(G);
-    const float2 *tw = nullptr;
-    int rc = twiddle_table(G, s, &tw);
+    const int G = layer_size;
+    fft_plan plan;
+    int rc = fft_plan_for(G, s, &plan);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
-    if ((rc = fft_lds_attribute(&g2iw_columns_kernel, lds))
-        || (rc = fft_lds_attribute(&g2iw_rows_kernel<true>, lds))
-        || (rc = fft_lds_attribute(&g2iw_rows_kernel<false>, lds)))
-        return rc;
+    const size_t lds = fft_lds_bytes(G, plan);
     float2 *T = static_cast<float2 *>(workspace);
-    g2iw_columns_kernel<<<grid_size, FFT_THREADS, lds, s>>>(
-        T, static_cast<const float2 *>(grid), grid_row_stride, grid_size, G, log2G, tw);
-    if (accumulate)
-        g2iw_rows_kernel<true><<<G / 2, FFT_THREADS, lds, s>>>(
-            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
+    const float2 *g = static_cast<const float2 *>(grid);
+#define G2IW(ODD) do { \
+        if ((rc = fft_lds_attribute(&g2iw_columns_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&g2iw_rows_kernel<true, ODD>, lds)) \
+            || (rc = fft_lds_attribute(&g2iw_rows_kernel<false, ODD>, lds))) \
+            return rc; \
+        g2iw_columns_kernel<ODD><<<grid_size, FFT_THREADS, lds, s>>>(T, g, grid_row_stride, grid_size, G, plan); \
+        if (accumulate) \
+            g2iw_rows_kernel<true, ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+                image, image_row_stride, T, grid_size, G, plan, kernel1d, lm_scale, lm_bias, w); \
+        else \
+            g2iw_rows_kernel<false, ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+                image, image_row_stride, T, grid_size, G, plan, kernel1d, lm_scale, lm_bias, w); \
+    } while (0)
+    if (plan.log2size)
+        G2IW(false);
     else
-        g2iw_rows_kernel<false><<<G / 2, FFT_THREADS, lds, s>>>(
-            image, image_row_stride, T, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
+        G2IW(true);
+#undef G2IW
     return kimg_launch_status();
 }
 
@@ -1106,18 +1273,26 @@ extern "C" int kimg_image_to_grid_w(void *grid, int64_t grid_row_stride, int gri
     KIMG_CHECK_ARG(workspace_bytes >= kimg_grid_image_w_workspace_bytes(layer_size, grid_size));
     KIMG_CHECK_ARG(((uintptr_t) workspace & 15) == 0);
     hipStream_t s = (hipStream_t) stream;
-    const int G = layer_size, log2G = fft_log2(G);
-    const float2 *tw = nullptr;
-    int rc = twiddle_table(G, s, &tw);
+    const int G = layer_size;
+    fft_plan plan;
+    int rc = fft_plan_for(G, s, &plan);
     if (rc)
         return rc;
-    const size_t lds = sizeof(float2) * (size_t) (fft_lds_cells(G) + fft_twiddle_count(G));
-    if ((rc = fft_lds_attribute(&i2gw_rows_kernel, lds)) || (rc = fft_lds_attribute(&i2gw_columns_kernel, lds)))
-        return rc;
+    const size_t lds = fft_lds_bytes(G, plan);
     float2 *T = static_cast<float2 *>(workspace);
-    i2gw_rows_kernel<<<G / 2, FFT_THREADS, lds, s>>>(
-        T, image, image_row_stride, grid_size, G, log2G, tw, kernel1d, lm_scale, lm_bias, w);
-    i2gw_columns_kernel<<<grid_size, FFT_THREADS, lds, s>>>(
-        static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, log2G, tw);
+#define I2GW(ODD) do { \
+        if ((rc = fft_lds_attribute(&i2gw_rows_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&i2gw_columns_kernel<ODD>, lds))) \
+            return rc; \
+        i2gw_rows_kernel<ODD><<<G / 2, FFT_THREADS, lds, s>>>( \
+            T, image, image_row_stride, grid_size, G, plan, kernel1d, lm_scale, lm_bias, w); \
+        i2gw_columns_kernel<ODD><<<grid_size, FFT_THREADS, lds, s>>>( \
+            static_cast<float2 *>(grid), grid_row_stride, T, grid_size, G, plan); \
+    } while (0)
+    if (plan.log2size)
+        I2GW(false);
+    else
+        I2GW(true);
+#undef I2GW
     return kimg_launch_status();
 }

@@ -288,7 +288,8 @@ class GridImageTemplate:
     ``tuning={'real_transform': False}`` switches off the complex-to-real route that grid -> image
     takes for w = 0 (see :class:`GridToImage`); ``{'own_transform': False}`` keeps that route on
     the library's 2-D plans where it would otherwise run the two-launch transforms of
-    ``kimg_grid_to_image_real`` / ``kimg_image_to_grid_real`` (layer sizes that are powers of two)."""
+    ``kimg_grid_to_image_real`` / ``kimg_image_to_grid_real`` and their any-w counterparts (even
+    layer sizes up to 8192 without a prime factor above 7)."""
 
     def __init__(self, context, real_dtype, tuning=None):
         types.require_float32(real_dtype, 'GridImageTemplate')

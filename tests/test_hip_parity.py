@@ -668,11 +668,14 @@ _W0_ROUTES = {'own': {}, 'library': {'own_transform': False}, 'c2c': {'real_tran
 @pytest.mark.gpu
 @pytest.mark.parametrize('G,Gg,P', [(96, 40, 2), (64, 64, 1), (128, 126, 3), (4096, 2486, 1),
                                     (16, 2, 1), (16, 16, 2), (32, 6, 1), (512, 154, 2),
-                                    (2048, 620, 1), (2048, 2048, 1), (8192, 2486, 1)])
+                                    (2048, 620, 1), (2048, 2048, 1), (8192, 2486, 1),
+                                    (120, 36, 1), (70, 70, 2), (66, 20, 1), (1000, 300, 1),
+                                    (4800, 1440, 1), (6720, 2016, 1), (5040, 5040, 1)])
 def test_grid_to_image_real_transform_route(G, Gg, P):
     """w = 0: GridToImage takes the Hermitian part of the (zero-padded) grid through a
     complex-to-real transform of half the size -- with the library's own two-launch transforms
-    where the layer size is a power of two ('own'), else on the FFT library's plan ('library').
+    where the layer size has no prime factor above 7 ('own': the sizes the reference picks,
+    parameters.py:17-25), else on the FFT library's plan ('library').
     Both against the oracle (= the reference's host path on the padded grid) and against the
     complex-to-complex route of the same operator, with accumulation; grids as large as the image
     (the -G/2 row and column have no mirror) and smaller, even and odd log2 of the size."""
@@ -685,7 +688,11 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
     lm_scale = 0.3 / G
     lm_bias = -0.5 * G * lm_scale
     own = bool(lib().kimg_grid_image_real_supported(G, Gg))
-    assert own == (G & (G - 1) == 0)
+    rest = G
+    for prime in (2, 3, 5, 7):
+        while rest % prime == 0:
+            rest //= prime
+    assert own == (rest == 1 and G >= 16)           # (66 = 2 * 3 * 11 stays with the FFT library)
     got = {}
     for route, tuning in _W0_ROUTES.items():
         template = image.GridImageTemplate(ctx, np.float32, tuning)
@@ -743,7 +750,8 @@ def test_grid_to_image_real_transform_route(G, Gg, P):
 @pytest.mark.gpu
 @pytest.mark.parametrize('G,Gg,P,w', [(64, 64, 1, 37.5), (128, 50, 2, -12.25), (16, 6, 1, 3.0),
                                       (512, 154, 1, 151.0), (2048, 620, 1, 40.0),
-                                      (4096, 1244, 1, -75.5)])
+                                      (4096, 1244, 1, -75.5), (96, 40, 2, 21.0), (126, 126, 1, -9.5),
+                                      (4800, 1440, 1, 33.0), (5040, 1512, 1, -18.0)])
 def test_grid_image_own_transform_any_w(G, Gg, P, w):
     """w != 0 (a slice of the W stack away from the middle): the two-launch route on the library's
     own transforms (kimg_grid_to_image_w / kimg_image_to_grid_w) against the FFT library's
