@@ -337,6 +337,15 @@ int kimg_image_to_grid_w(void *grid, int64_t grid_row_stride, int grid_size,
                          const float *kernel1d, float lm_scale, float lm_bias, float w,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* ConvolveBeam.__call__ (beam.py:351-398) for a square image of a size the functions above take
+ * (kimg_grid_image_real_supported(size, size)), in three launches on the library's own transforms:
+ * rows (two real rows per complex transform) -> per column of the half spectrum: forward transform,
+ * times amplitude * exp((a v + b u) v + c u^2) (kimg_fourier_beam's factor; 1 / (H W) folded into
+ * the amplitude as there), inverse transform -> rows back.  In place on `image`; workspace =
+ * (size / 2 + 1) x size cells, 16-byte aligned (the operator's `fourier` buffer). */
+int kimg_convolve_beam(float *image, int64_t row_stride, int size, float amplitude, float a,
+                       float b, float c, void *workspace, size_t workspace_bytes, void *stream);
+
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
  * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */
 int kimg_fft_plan_create(void **plan, int size_y, int size_x);

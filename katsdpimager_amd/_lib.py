@@ -53,6 +53,7 @@ PROTOTYPES = {
     'kimg_grid_image_real_workspace_bytes': (c_size_t, [I, I]),
     'kimg_grid_to_image_real': (c_int, [P, L, I, P, L, I, P, F, F, I, P, c_size_t, P]),
     'kimg_image_to_grid_real': (c_int, [P, L, I, P, L, I, P, F, F, P, c_size_t, P]),
+    'kimg_convolve_beam': (c_int, [P, L, I, F, F, F, F, P, c_size_t, P]),
     'kimg_grid_image_w_workspace_bytes': (c_size_t, [I, I]),
     'kimg_grid_to_image_w': (c_int, [P, L, I, P, L, I, P, F, F, F, I, P, c_size_t, P]),
     'kimg_image_to_grid_w': (c_int, [P, L, I, P, L, I, P, F, F, F, P, c_size_t, P]),

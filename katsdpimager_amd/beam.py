@@ -186,8 +186,22 @@ class ConvolveBeamTemplate:
         self.context = context
         self.dtype = np.dtype(dtype)
         self.shape = tuple(shape)
-        self.fft = _RfftPlan(self.shape)
+        tuning = dict(tuning or {})
+        #: square images of a size the library's own transforms take (even, at most 8192, no prime
+        #: factor above 7) are convolved by ``kimg_convolve_beam`` (three launches) unless
+        #: ``tuning={'own_transform': False}``
+        self.own_transform = bool(tuning.pop('own_transform', True)) and self.shape[0] == self.shape[1] \
+            and bool(lib().kimg_grid_image_real_supported(self.shape[0], self.shape[0]))
+        self._fft = None
         self.fourier_beam = FourierBeamTemplate(context, dtype, tuning)
+
+    @property
+    def fft(self):
+        """The FFT library's real <-> half-complex plans (made when first needed: plan creation
+        costs milliseconds)."""
+        if self._fft is None:
+            self._fft = _RfftPlan(self.shape)
+        return self._fft
 
     def instantiate(self, *args, **kwargs):
         return ConvolveBeam(self, *args, **kwargs)
@@ -217,6 +231,13 @@ class ConvolveBeam(accel.Operation):
         if self.beam is None:
             raise ValueError('Must set beam')
         image, fourier = self.buffer('image'), self.buffer('fourier')
+        if self.template.own_transform:
+            amplitude, a, b, c = self._fourier_beam.coefficients()
+            check(lib().kimg_convolve_beam(
+                image.ptr, image.shape[1], image.shape[0], amplitude, a, b, c, fourier.ptr,
+                fourier.tensor.numel() * fourier.tensor.element_size(), self.command_queue.handle),
+                'kimg_convolve_beam')
+            return
         self.template.fft.execute(self.command_queue, image, fourier, inverse=False)
         self._fourier_beam()
         self.template.fft.execute(self.command_queue, image, fourier, inverse=True)

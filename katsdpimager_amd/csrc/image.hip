@@ -742,6 +742,92 @@ __global__ __launch_bounds__(FFT_THREADS) void i2gw_columns_kernel(
         grid[(int64_t) gy * grid_row_stride + c] = x[fft_pad(grid_to_layer_index(gy, half, G))];
 }
 
+// ---- restoring-beam convolution (beam.py:351-398) on the same transforms -----------------------
+// image -> rows (two real rows per complex transform, no shift) -> T[u][y] for u = 0 .. G/2 ->
+// per column: forward transform, times the beam's Fourier transform, inverse transform, all in LDS
+// -> rows back.  Three launches; the half spectrum is written once and read once more than it must.
+template<bool ODD>
+__global__ __launch_bounds__(FFT_THREADS) void cb_rows_forward_kernel(
+    float2 *__restrict__ T, const float *__restrict__ image, int64_t row_stride, int G, fft_plan plan)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, plan, G, false);
+    const int y1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x);
+    for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS)
+        x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(image[(int64_t) y1 * row_stride + sx],
+                                                          image[(int64_t) (y1 + 1) * row_stride + sx]);
+    lds_fft<false, ODD>(x, tw, G, plan);
+    for (int lx = threadIdx.x; lx <= G / 2; lx += FFT_THREADS) {
+        const float2 z = x[fft_pad(lx)], zm = x[fft_pad(lx ? G - lx : 0)];
+        *reinterpret_cast<float4 *>(T + (int64_t) lx * G + y1) =
+            make_float4(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y), 0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
+    }
+}
+
+template<bool ODD>
+__global__ __launch_bounds__(FFT_THREADS) void cb_columns_kernel(
+    float2 *__restrict__ T, int G, fft_plan plan, float amplitude, float a, float b, float c)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, plan, G, false);
+    const int lx = xcd_contiguous(blockIdx.x, gridDim.x);
+    float2 *column = T + (int64_t) lx * G;
+    for (int y = threadIdx.x; y < G; y += FFT_THREADS)
+        x[fft_pad(fft_cell<ODD>(plan, y))] = column[y];
+    lds_fft<false, ODD>(x, tw, G, plan);
+    // fourier_beam_kernel's factor, and the result into the cells the inverse transform starts from
+    const float u = (float) lx;
+    float2 held[FFT_ROW_CELLS];
+#pragma unroll
+    for (int k = 0; k < FFT_ROW_CELLS; k++) {
+        const int ly = threadIdx.x + k * FFT_THREADS;
+        if (ly < G) {
+            const float v = (float) (ly * 2 >= G ? ly - G : ly);
+            const float power = (a * v + b * u) * v + c * u * u;
+            const float ft = amplitude * expf(power);
+            const float2 value = x[fft_pad(ly)];
+            held[k] = make_float2(value.x * ft, value.y * ft);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FFT_ROW_CELLS; k++) {
+        const int ly = threadIdx.x + k * FFT_THREADS;
+        if (ly < G)
+            x[fft_pad(fft_cell<ODD>(plan, ly))] = held[k];
+    }
+    lds_fft<true, ODD>(x, tw, G, plan);
+    for (int y = threadIdx.x; y < G; y += FFT_THREADS)
+        column[y] = x[fft_pad(y)];
+}
+
+template<bool ODD>
+__global__ __launch_bounds__(FFT_THREADS) void cb_rows_inverse_kernel(
+    float *__restrict__ image, int64_t row_stride, const float2 *__restrict__ T, int G, fft_plan plan)
+{
+    extern __shared__ float2 fft_lds[];
+    float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
+    fft_lds_setup(x, tw, plan, G, false);
+    const int y1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x);
+    for (int n = threadIdx.x; n <= G / 2; n += FFT_THREADS) {
+        const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + y1);
+        if (n == 0 || 2 * n == G) {
+            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x, t.z);     // (imaginary parts ignored,
+        } else {                                                          // as a complex-to-real plan does)
+            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x - t.w, t.y + t.z);
+            x[fft_pad(fft_cell<ODD>(plan, G - n))] = make_float2(t.x + t.w, t.z - t.y);
+        }
+    }
+    lds_fft<true, ODD>(x, tw, G, plan);
+    for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+        const float2 v = x[fft_pad(sx)];
+        image[(int64_t) y1 * row_stride + sx] = v.x;
+        image[(int64_t) (y1 + 1) * row_stride + sx] = v.y;
+    }
+}
+
 } // namespace
 
 extern "C" int kimg_grid_to_layer(void *layer, int layer_size, const void *grid,
@@ -1294,5 +1380,38 @@ extern "C" int kimg_image_to_grid_w(void *grid, int64_t grid_row_stride, int gri
     else
         I2GW(true);
 #undef I2GW
+    return kimg_launch_status();
+}
+
+// ---- restoring-beam convolution on the library's own transforms -------------------------------
+extern "C" int kimg_convolve_beam(float *image, int64_t row_stride, int size, float amplitude,
+                                  float a, float b, float c, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    KIMG_CHECK_ARG(image && workspace && kimg_grid_image_real_supported(size, size));
+    KIMG_CHECK_ARG(row_stride >= size && ((uintptr_t) workspace & 15) == 0);
+    KIMG_CHECK_ARG(workspace_bytes >= sizeof(float2) * (size_t) (size / 2 + 1) * (size_t) size);
+    hipStream_t s = (hipStream_t) stream;
+    const int G = size;
+    fft_plan plan;
+    int rc = fft_plan_for(G, s, &plan);
+    if (rc)
+        return rc;
+    const size_t lds = fft_lds_bytes(G, plan);
+    float2 *T = static_cast<float2 *>(workspace);
+#define CONVOLVE(ODD) do { \
+        if ((rc = fft_lds_attribute(&cb_rows_forward_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&cb_columns_kernel<ODD>, lds)) \
+            || (rc = fft_lds_attribute(&cb_rows_inverse_kernel<ODD>, lds))) \
+            return rc; \
+        cb_rows_forward_kernel<ODD><<<G / 2, FFT_THREADS, lds, s>>>(T, image, row_stride, G, plan); \
+        cb_columns_kernel<ODD><<<G / 2 + 1, FFT_THREADS, lds, s>>>(T, G, plan, amplitude, a, b, c); \
+        cb_rows_inverse_kernel<ODD><<<G / 2, FFT_THREADS, lds, s>>>(image, row_stride, T, G, plan); \
+    } while (0)
+    if (plan.log2size)
+        CONVOLVE(false);
+    else
+        CONVOLVE(true);
+#undef CONVOLVE
     return kimg_launch_status();
 }

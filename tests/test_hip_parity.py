@@ -1196,6 +1196,40 @@ def test_convolve_beam_vs_golden(golden, case):
         np.testing.assert_allclose(actual, ref[pol], rtol=1e-5, atol=1e-5 * peak)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('G', [16, 64, 120, 126, 1000, 2048, 4096, 4800])
+def test_convolve_beam_own_transform(G):
+    """kimg_convolve_beam (square images of a size the library's own transforms take: rows, then
+    per column forward transform x beam x inverse transform, then rows back) against the route on
+    the FFT library's real <-> half-complex plans, and against the restatement at small sizes."""
+    from katsdpimager_amd import beam
+    ctx, q = context_queue()
+    rs = np.random.RandomState(G)
+    model = np.zeros((G, G), np.float32)
+    for _ in range(50):
+        model[rs.randint(G), rs.randint(G)] += rs.uniform(-1, 2)
+    model += (0.01 * rs.standard_normal((G, G))).astype(np.float32)
+    b = dict(amplitude=1.3, x_stddev=2.2, y_stddev=3.7, theta=0.6)
+    out = {}
+    for route, tuning in (('own', None), ('library', {'own_transform': False})):
+        template = beam.ConvolveBeamTemplate(ctx, (G, G), np.float32, tuning=tuning)
+        assert template.own_transform == (route == 'own')
+        fn = template.instantiate(q)
+        fn.beam = beam.Beam(**b)
+        fn.ensure_all_bound()
+        fn.buffer('image').set(q, model)
+        fn()
+        out[route] = fn.buffer('image').get(q)
+        del fn
+    peak = np.abs(out['library']).max()
+    np.testing.assert_allclose(out['own'], out['library'], rtol=0, atol=3e-6 * peak)
+    if G <= 128:
+        ref = orc.convolve_beam(model[np.newaxis], **b)[0]
+        np.testing.assert_allclose(out['own'], ref, rtol=1e-5, atol=1e-5 * peak)
+    # a rectangular image stays with the FFT library
+    assert not beam.ConvolveBeamTemplate(ctx, (96, 160), np.float32).own_transform
+
+
 def test_restore_step():
     """frontend.py:623-641 on the facade buffers: model (x) beam + residuals."""
     from katsdpimager_amd import beam, imaging, parameters, weight
