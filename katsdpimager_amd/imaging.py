@@ -679,5 +679,7 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def free_buffer(self, name):
+        if name == 'dirty':
+            self._dirty_cleared = False     # (a deferred fill has nothing left to fill)
         if name in self.slots:
             self.slots[name].bind(None)
