@@ -83,11 +83,22 @@ __global__ __launch_bounds__(256) void mean_weight_kernel(
     int width, int height)
 {
     double acc[2] = {0, 0};
-    for (int y = blockIdx.y; y < height; y += gridDim.y)
+    // (four rows per round, their loads issued together: with few, long-lived workgroups -- see
+    // image_grid -- a thread's loop would otherwise be one memory round trip per row)
+    constexpr int ROWS = 4;
+    for (int y0 = blockIdx.y; y0 < height; y0 += gridDim.y * ROWS)
         for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x) {
-            float w = grid[(int64_t) y * row_stride + x];
-            acc[0] += w;
-            acc[1] += (double) w * w;
+            float w[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + r * gridDim.y;
+                w[r] = y < height ? grid[(int64_t) y * row_stride + x] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                acc[0] += w[r];
+                acc[1] += (double) w[r] * w[r];
+            }
         }
     block_accumulate<2>(acc, sums);
 }
@@ -97,22 +108,32 @@ __global__ __launch_bounds__(256) void density_weights_kernel(
     int width, int height, int num_pols, float a, float b)
 {
     double acc[3] = {0, 0, 0};
-    for (int y = blockIdx.y; y < height; y += gridDim.y)
-        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x) {
-            int64_t addr = (int64_t) y * row_stride + x;
+    constexpr int ROWS = 4;
+    for (int y0 = blockIdx.y; y0 < height; y0 += gridDim.y * ROWS)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x)
             for (int p = 0; p < num_pols; p++) {
-                float w = grid[addr + p * pol_stride];
-                // weight.py:596-597: 1 / (w*S2 + 1), zero where no visibilities fell
-                float d = (w != 0.0f) ? 1.0f / (a * w + b) : 0.0f;
-                if (p == 0) {
-                    double dw = (double) d * w;
-                    acc[0] += w;
-                    acc[1] += dw;
-                    acc[2] += d * dw;
+                float w[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int y = y0 + r * gridDim.y;
+                    w[r] = y < height ? grid[(int64_t) y * row_stride + x + p * pol_stride] : 0.0f;
                 }
-                grid[addr + p * pol_stride] = d;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int y = y0 + r * gridDim.y;
+                    if (y >= height)
+                        continue;
+                    // weight.py:596-597: 1 / (w*S2 + 1), zero where no visibilities fell
+                    const float d = (w[r] != 0.0f) ? 1.0f / (a * w[r] + b) : 0.0f;
+                    if (p == 0) {
+                        const double dw = (double) d * w[r];
+                        acc[0] += w[r];
+                        acc[1] += dw;
+                        acc[2] += d * dw;
+                    }
+                    grid[(int64_t) y * row_stride + x + p * pol_stride] = d;
+                }
             }
-        }
     block_accumulate<3>(acc, sums);
 }
 
@@ -153,9 +174,11 @@ extern "C" int kimg_grid_weights(float *grid, int64_t row_stride, int64_t pol_st
 
 static dim3 image_grid(int width, int height)
 {
-    // enough workgroups to fill 256 CUs several times over, grid-stride the rest
+    // Four workgroups per CU, grid-stride the rest: every workgroup ends with two or three double
+    // atomics on the SAME addresses, which the memory system serves one after the other (~30 ns each:
+    // with 4096 workgroups that chain was longer than the pass over the grid)
     int bx = kimg_divup(width, 256);
-    int by = height < 4096 / bx ? height : 4096 / bx;
+    int by = height < 1024 / bx ? height : 1024 / bx;
     return dim3(bx, by > 0 ? by : 1);
 }
 
