@@ -1009,21 +1009,38 @@ __global__ __launch_bounds__(256) void image_peak_kernel(
 {
     float peak = 0.0f;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int ROWS = 4;     // rows in flight per thread
     if (x < width)
-        for (int y = blockIdx.y; y < height; y += gridDim.y) {
-            const float pb = pbeam ? pbeam[(int64_t) y * beam_row_stride + x] : 1.0f;
+        for (int y0 = blockIdx.y; y0 < height; y0 += gridDim.y * ROWS)
             for (int p = 0; p < P; p++) {
-                const float v = fabsf(image[p * pol_stride + (int64_t) y * row_stride + x]);
-                if (v > peak && v * pb > limit)
-                    peak = v;
+                float v[ROWS], pb[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int y = y0 + r * gridDim.y;
+                    const bool ok = y < height;
+                    v[r] = ok ? fabsf(image[p * pol_stride + (int64_t) y * row_stride + x]) : 0.0f;
+                    pb[r] = (ok && pbeam) ? pbeam[(int64_t) y * beam_row_stride + x] : 1.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; r++)
+                    if (v[r] > peak && v[r] * pb[r] > limit)
+                        peak = v[r];
             }
-        }
     peak = fmaxf(peak, __shfl_xor(peak, 32, WAVE));
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1)
         peak = fmaxf(peak, __shfl_xor(peak, off, WAVE));
-    if ((threadIdx.x & 63) == 0 && peak > 0.0f)
-        atomicMax(out, __float_as_uint(peak));
+    // one atomic per workgroup (atomics on one address are served one after the other)
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = peak;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int) (blockDim.x >> 6); w++)
+            peak = fmaxf(peak, part[w]);
+        if (peak > 0.0f)
+            atomicMax(out, __float_as_uint(peak));
+    }
 }
 
 // get_totals (frontend.py:197-209): per-polarization sum ignoring NaNs, in float64.
@@ -1034,11 +1051,19 @@ __global__ __launch_bounds__(256) void image_nansum_kernel(
     const int p = blockIdx.z;
     double acc = 0.0;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int ROWS = 4;
     if (x < width)
-        for (int y = blockIdx.y; y < height; y += gridDim.y) {
-            const float v = image[p * pol_stride + (int64_t) y * row_stride + x];
-            if (v == v)
-                acc += (double) v;
+        for (int y0 = blockIdx.y; y0 < height; y0 += gridDim.y * ROWS) {
+            float v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + r * gridDim.y;
+                v[r] = y < height ? image[p * pol_stride + (int64_t) y * row_stride + x] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++)
+                if (v[r] == v[r])
+                    acc += (double) v[r];
         }
     acc = wave_sum(acc);
     __shared__ double part[4];
@@ -1061,7 +1086,7 @@ extern "C" int kimg_image_peak(const float *image, int64_t row_stride, int64_t p
     KIMG_CHECK_ARG(image && peak && width > 0 && height > 0 && num_polarizations >= 1);
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(peak, 0, sizeof(float), s));
-    int by = height < 256 ? height : 256;
+    int by = height < 64 ? height : 64;
     dim3 grid(kimg_divup(width, 256), by);
     image_peak_kernel<<<grid, 256, 0, s>>>(image, row_stride, pol_stride, pbeam, beam_row_stride,
                                            width, height, num_polarizations, 7.5f * noise,
@@ -1077,7 +1102,7 @@ extern "C" int kimg_image_nansum(const float *image, int64_t row_stride, int64_t
                    && num_polarizations <= 65535);
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * num_polarizations, s));
-    int by = height < 128 ? height : 128;
+    int by = height < 32 ? height : 32;
     dim3 grid(kimg_divup(width, 256), by, num_polarizations);
     image_nansum_kernel<<<grid, 256, 0, s>>>(image, row_stride, pol_stride, width, height, sums);
     return kimg_launch_status();
