@@ -349,7 +349,7 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def clear_weights(self):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self._weights.clear()
 
     @_serial
@@ -362,12 +362,12 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def finalize_weights(self):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         return self._weights.finalize()
 
     @_serial
     def clear_grid(self):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self.buffer('grid').zero(self.command_queue)
 
     @_serial
@@ -380,7 +380,7 @@ class Imaging(accel.OperationSequence):
 
     @_serial
     def clear_model(self):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self.buffer('model').zero(self.command_queue)
         self._components.clear()
         del self._pending_components[:]
@@ -432,7 +432,7 @@ class Imaging(accel.OperationSequence):
         ``predict`` subtracts the model in place and the store must keep the originals."""
         if field not in ('vis', 'weights'):
             raise ValueError('field must be vis or weights')
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         if self._use_side():
             side = self._side
             n = chunk.num_vis
@@ -483,7 +483,7 @@ class Imaging(accel.OperationSequence):
     # ---- operations -------------------------------------------------------------------
     def grid(self):
         """Grid the current chunk; with ``streams=2`` the next chunk goes to the other stream."""
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         if self._use_side():
             self._side.gridder()
         else:
@@ -492,14 +492,14 @@ class Imaging(accel.OperationSequence):
             self._cur ^= 1
 
     def predict(self, w):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         op = self._side.predict if self._use_side() else self._predict
         if not self.template.fixed_grid_parameters.degrid:
             op.set_w(w)
         op()
 
     def continuum_predict(self, w):
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         op = self._side.continuum if self._use_side() else self._continuum_predict
         op.set_w(w)
         op()
@@ -507,7 +507,7 @@ class Imaging(accel.OperationSequence):
     @_serial
     def set_sky_arrays(self, lmn, flux):
         """Continuum model as arrays (l, m, n-1) / flux[P]; see predict.Predict."""
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self._continuum_predict.set_sky_arrays(lmn, flux)
         if self._side is not None:
             self._side.continuum.set_sky_arrays(lmn, flux)
@@ -516,7 +516,7 @@ class Imaging(accel.OperationSequence):
     def set_sky_model(self, sky_model, phase_centre):
         """imaging.py:331-332: continuum model from an object with the reference's SkyModel
         interface (``lmn(phase_centre)``, ``flux_density(wavelength)``, ``len``)."""
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self._continuum_predict.set_sky_model(sky_model, phase_centre)
         if self._side is not None:
             self._side.continuum.set_sky_model(sky_model, phase_centre)
@@ -537,7 +537,7 @@ class Imaging(accel.OperationSequence):
     def model_to_grid(self, w):
         if not self._image_to_grid:
             raise RuntimeError('Can only use model_to_grid with degridding')
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self._image_to_grid.set_w(w)
         self._image_to_grid()
 
@@ -545,7 +545,7 @@ class Imaging(accel.OperationSequence):
     def model_to_predict(self):
         if self.template.fixed_grid_parameters.degrid:
             raise RuntimeError('Can only use model_to_predict with direct prediction')
-        self._ready()
+        self._ready(keep_cleared=True)     # (does not touch the dirty image)
         self._predict.set_sky_image(self._model_components)
         if self._side is not None:
             self._side.predict.set_sky_image(self._model_components)
