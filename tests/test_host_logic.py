@@ -48,6 +48,31 @@ def test_argument_errors_without_gpu():
     assert lib.kimg_degrid(one, 8, 64, 8, 1, one, one, one, one, 4, one, 1, 8, 4, None, 0,
                            0, 2, None) == -10001
     assert lib.kimg_grid_weights(None, 1, 1, 2, 2, 1, None, None, 0, None) == -10001
+    # the two-launch grid <-> image routes: which sizes they take, and their argument checks
+    assert lib.kimg_grid_image_real_supported(4096, 1244) == 1
+    assert lib.kimg_grid_image_real_supported(4800, 1440) == 1      # 2^6 3 5^2
+    assert lib.kimg_grid_image_real_supported(6720, 6720) == 1      # 2^6 3 5 7
+    assert lib.kimg_grid_image_real_supported(4224, 1000) == 0      # 11
+    assert lib.kimg_grid_image_real_supported(16384, 1000) == 0     # LDS
+    assert lib.kimg_grid_image_real_supported(4095, 1000) == 0 and \
+        lib.kimg_grid_image_real_supported(4096, 1001) == 0         # odd sizes
+    assert lib.kimg_grid_image_real_supported(4096, 4098) == 0      # grid larger than the layer
+    assert lib.kimg_grid_image_real_workspace_bytes(4096, 1244) == 623 * 4096 * 8
+    assert lib.kimg_grid_image_w_workspace_bytes(4096, 1244) == 1244 * 4096 * 8
+    assert lib.kimg_grid_image_real_workspace_bytes(4224, 1000) == 0
+    sixteen = ctypes.c_void_p(16)
+    assert lib.kimg_grid_to_image_real(None, 64, 64, one, 16, 16, one, 0.0, 0.0, 1, sixteen,
+                                       1 << 20, None) == -10001
+    assert lib.kimg_grid_to_image_real(one, 64, 64, one, 16, 16, one, 0.0, 0.0, 1, sixteen,
+                                       100, None) == -10001          # workspace too small
+    assert lib.kimg_grid_to_image_real(one, 64, 64, one, 16, 16, one, 0.0, 0.0, 1, one,
+                                       1 << 20, None) == -10001          # workspace not aligned
+    assert lib.kimg_grid_to_image_real(one, 66, 66, one, 16, 16, one, 0.0, 0.0, 1, sixteen,
+                                       1 << 20, None) == -10001          # 66 = 2 3 11
+    assert lib.kimg_image_to_grid_w(one, 16, 16, one, 64, 64, None, 0.0, 0.0, 3.0, sixteen,
+                                    1 << 20, None) == -10001
+    assert lib.kimg_convolve_beam(one, 64, 64, 1.0, 0.0, 0.0, 0.0, sixteen, 100, None) == -10001
+    assert lib.kimg_convolve_beam(one, 60, 64, 1.0, 0.0, 0.0, 0.0, sixteen, 1 << 20, None) == -10001
     with pytest.raises(_lib.KimgError):
         _lib.check(-10001, 'kimg_fill')
 
