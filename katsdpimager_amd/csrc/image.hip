@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void apply_primary_beam_kernel(
 // input (any size 2^a 3^b 5^c 7^d up to 8192 -- the sizes the reference picks, parameters.py:17-25),
 // one workgroup per transform, twiddles from a table.
 constexpr int FFT_THREADS = 512;
+constexpr int FFT_BATCH = 4;        // global loads a thread has in flight in the kernels' prologues
 constexpr int FFT_UNROLL = 2;       // butterflies a thread has in flight (4096 cells: all it has)
 
 __device__ inline float2 cmul(float2 a, float2 b)
@@ -473,10 +474,23 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
     const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
     // the rows the grid (or its mirror image) reaches: centred -half .. half
     const int rows = 2 * half == G ? G : Gg + 1;
-    for (int r = threadIdx.x; r < rows; r += FFT_THREADS) {
-        const int cy = r - half;
-        const int ly = cy < 0 ? cy + G : cy;
-        x[fft_pad(fft_cell<ODD>(plan, ly))] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
+    // (FFT_BATCH cells per thread and round: their loads are issued before the first of them is used)
+    for (int r0 = threadIdx.x; r0 < rows; r0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+        int cell[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++) {
+            const int r = r0 + k * FFT_THREADS;
+            const int cy = r - half;
+            const int ly = cy < 0 ? cy + G : cy;
+            cell[k] = r < rows ? ly : -1;
+            if (r < rows)
+                value[k] = half_layer_value(grid, grid_row_stride, Gg, G, lx, ly);
+        }
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (cell[k] >= 0)
+                x[fft_pad(fft_cell<ODD>(plan, cell[k]))] = value[k];
     }
     lds_fft<true, ODD>(x, tw, G, plan);
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
@@ -496,34 +510,63 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, plan, G, true);
     const int sy1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
-    for (int n = threadIdx.x; n <= half; n += FFT_THREADS) {
+    for (int n0 = threadIdx.x; n0 <= half; n0 += FFT_BATCH * FFT_THREADS) {
         // (t.x, t.y) = T[n][sy1], (t.z, t.w) = T[n][sy1 + 1]
-        const float4 t = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + sy1);
-        if (n == 0 || 2 * n == G) {
-            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x, t.z);       // (real up to rounding)
-        } else {
-            x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x - t.w, t.y + t.z);
-            x[fft_pad(fft_cell<ODD>(plan, G - n))] = make_float2(t.x + t.w, t.z - t.y);
+        float4 t4[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++) {
+            const int n = n0 + k * FFT_THREADS;
+            if (n <= half)
+                t4[k] = *reinterpret_cast<const float4 *>(T + (int64_t) n * G + sy1);
+        }
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++) {
+            const int n = n0 + k * FFT_THREADS;
+            if (n > half)
+                continue;
+            const float4 t = t4[k];
+            if (n == 0 || 2 * n == G) {
+                x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x, t.z);       // (real up to rounding)
+            } else {
+                x[fft_pad(fft_cell<ODD>(plan, n))] = make_float2(t.x - t.w, t.y + t.z);
+                x[fft_pad(fft_cell<ODD>(plan, G - n))] = make_float2(t.x + t.w, t.z - t.y);
+            }
         }
     }
     lds_fft<true, ODD>(x, tw, G, plan);
     const int hG = G / 2;
+    const int ya = fft_shift(sy1, hG), yb = fft_shift(sy1 + 1, hG);
+    const float ma = lm_coord(ya, lm_scale, lm_bias), mb = lm_coord(yb, lm_scale, lm_bias);
+    const float ma2 = ma * ma, mb2 = mb * mb;
+    const float ka = kernel1d[ya], kb = kernel1d[yb];
+    float *rowa = image + (int64_t) ya * image_row_stride, *rowb = image + (int64_t) yb * image_row_stride;
+    for (int sx0 = threadIdx.x; sx0 < G; sx0 += 2 * FFT_THREADS) {
+        float olda[2] = {0.0f, 0.0f}, oldb[2] = {0.0f, 0.0f}, kx[2];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int y = fft_shift(sy1 + r, hG);
-        const float m = lm_coord(y, lm_scale, lm_bias);
-        const float m2 = m * m;
-        const float ky = kernel1d[y];
-        float *row = image + (int64_t) y * image_row_stride;
-        for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
+        for (int k = 0; k < 2; k++) {
+            const int sx = sx0 + k * FFT_THREADS;
+            if (sx < G) {
+                const int xx = fft_shift(sx, hG);
+                kx[k] = kernel1d[xx];
+                if (ACCUMULATE) {
+                    olda[k] = rowa[xx];
+                    oldb[k] = rowb[xx];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int sx = sx0 + k * FFT_THREADS;
+            if (sx >= G)
+                continue;
             const int xx = fft_shift(sx, hG);
-            const float rotated = r ? x[fft_pad(sx)].y : x[fft_pad(sx)].x;
+            const float2 both = x[fft_pad(sx)];
             const float l = lm_coord(xx, lm_scale, lm_bias);
             const float l2 = l * l;
-            const float n = sqrtf(1.0f - (m2 + l2));
-            const float taper = ky * kernel1d[xx];
-            const float v = (rotated * n) / taper;
-            row[xx] = ACCUMULATE ? row[xx] + v : v;
+            const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
+            const float va = (both.x * na) / (ka * kx[k]), vb = (both.y * nb) / (kb * kx[k]);
+            rowa[xx] = ACCUMULATE ? olda[k] + va : va;
+            rowb[xx] = ACCUMULATE ? oldb[k] + vb : vb;
         }
     }
 }
@@ -545,15 +588,31 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
     const float ma = lm_coord(y1, lm_scale, lm_bias), mb = lm_coord(y2, lm_scale, lm_bias);
     const float ma2 = ma * ma, mb2 = mb * mb;
     const float ka = kernel1d[y1], kb = kernel1d[y2];
-    for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
-        const int xx = fft_shift(sx, hG);
-        const float l = lm_coord(xx, lm_scale, lm_bias);
-        const float l2 = l * l;
-        const float kx = kernel1d[xx];
-        const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
-        const float va = image[(int64_t) y1 * image_row_stride + xx] / ((ka * kx) * na);
-        const float vb = image[(int64_t) y2 * image_row_stride + xx] / ((kb * kx) * nb);
-        x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(va, vb);
+    for (int sx0 = threadIdx.x; sx0 < G; sx0 += FFT_BATCH * FFT_THREADS) {
+        float pa[FFT_BATCH], pb[FFT_BATCH], kx[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++) {
+            const int sx = sx0 + k * FFT_THREADS;
+            if (sx < G) {
+                const int xx = fft_shift(sx, hG);
+                kx[k] = kernel1d[xx];
+                pa[k] = image[(int64_t) y1 * image_row_stride + xx];
+                pb[k] = image[(int64_t) y2 * image_row_stride + xx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++) {
+            const int sx = sx0 + k * FFT_THREADS;
+            if (sx >= G)
+                continue;
+            const int xx = fft_shift(sx, hG);
+            const float l = lm_coord(xx, lm_scale, lm_bias);
+            const float l2 = l * l;
+            const float na = sqrtf(1.0f - (ma2 + l2)), nb = sqrtf(1.0f - (mb2 + l2));
+            const float va = pa[k] / ((ka * kx[k]) * na);
+            const float vb = pb[k] / ((kb * kx[k]) * nb);
+            x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(va, vb);
+        }
     }
     lds_fft<false, ODD>(x, tw, G, plan);
     for (int lx = threadIdx.x; lx <= half; lx += FFT_THREADS) {
@@ -576,8 +635,17 @@ __global__ __launch_bounds__(FFT_THREADS) void i2g_columns_kernel(
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, plan, G, false);
     const int lx = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
-    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        x[fft_pad(fft_cell<ODD>(plan, sy))] = T[(int64_t) lx * G + sy];
+    for (int sy0 = threadIdx.x; sy0 < G; sy0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sy0 + k * FFT_THREADS < G)
+                value[k] = T[(int64_t) lx * G + sy0 + k * FFT_THREADS];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sy0 + k * FFT_THREADS < G)
+                x[fft_pad(fft_cell<ODD>(plan, sy0 + k * FFT_THREADS))] = value[k];
+    }
     lds_fft<false, ODD>(x, tw, G, plan);
     for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS) {
         const int cy = gy - half;
@@ -614,8 +682,17 @@ __global__ __launch_bounds__(FFT_THREADS) void g2iw_columns_kernel(
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, plan, G, true);
     const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
-    for (int r = threadIdx.x; r < Gg; r += FFT_THREADS)
-        x[fft_pad(fft_cell<ODD>(plan, grid_to_layer_index(r, half, G)))] = grid[(int64_t) r * grid_row_stride + c];
+    for (int r0 = threadIdx.x; r0 < Gg; r0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (r0 + k * FFT_THREADS < Gg)
+                value[k] = grid[(int64_t) (r0 + k * FFT_THREADS) * grid_row_stride + c];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (r0 + k * FFT_THREADS < Gg)
+                x[fft_pad(fft_cell<ODD>(plan, grid_to_layer_index(r0 + k * FFT_THREADS, half, G)))] = value[k];
+    }
     lds_fft<true, ODD>(x, tw, G, plan);
     for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
         T[(int64_t) c * G + sy] = x[fft_pad(sy)];
@@ -699,16 +776,32 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void i2gw_rows_kernel(
         const float ky = kernel1d[y];
         if (r == 1)
             __syncthreads();        // (the first row's results have been taken out of x)
-        for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS) {
-            const int xx = fft_shift(sx, hG);
-            const float l = lm_coord(xx, lm_scale, lm_bias);
-            const float l2 = l * l;
-            const float n = sqrtf(1.0f - (m2 + l2));
-            float c, s;
-            expj2pi(-w * (n - 1.0f), c, s);
-            const float taper = ky * kernel1d[xx];
-            const float v = image[(int64_t) y * image_row_stride + xx] / (taper * n);
-            x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(v * c, v * s);
+        for (int sx0 = threadIdx.x; sx0 < G; sx0 += FFT_BATCH * FFT_THREADS) {
+            float pixel[FFT_BATCH], kx[FFT_BATCH];
+#pragma unroll
+            for (int k = 0; k < FFT_BATCH; k++) {
+                const int sx = sx0 + k * FFT_THREADS;
+                if (sx < G) {
+                    const int xx = fft_shift(sx, hG);
+                    pixel[k] = image[(int64_t) y * image_row_stride + xx];
+                    kx[k] = kernel1d[xx];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FFT_BATCH; k++) {
+                const int sx = sx0 + k * FFT_THREADS;
+                if (sx >= G)
+                    continue;
+                const int xx = fft_shift(sx, hG);
+                const float l = lm_coord(xx, lm_scale, lm_bias);
+                const float l2 = l * l;
+                const float n = sqrtf(1.0f - (m2 + l2));
+                float c, s;
+                expj2pi(-w * (n - 1.0f), c, s);
+                const float taper = ky * kx[k];
+                const float v = pixel[k] / (taper * n);
+                x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(v * c, v * s);
+            }
         }
         lds_fft<false, ODD>(x, tw, G, plan);
 #pragma unroll
@@ -735,8 +828,17 @@ __global__ __launch_bounds__(FFT_THREADS) void i2gw_columns_kernel(
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, plan, G, false);
     const int c = xcd_contiguous(blockIdx.x, gridDim.x), half = Gg / 2;
-    for (int sy = threadIdx.x; sy < G; sy += FFT_THREADS)
-        x[fft_pad(fft_cell<ODD>(plan, sy))] = T[(int64_t) c * G + sy];
+    for (int sy0 = threadIdx.x; sy0 < G; sy0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sy0 + k * FFT_THREADS < G)
+                value[k] = T[(int64_t) c * G + sy0 + k * FFT_THREADS];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sy0 + k * FFT_THREADS < G)
+                x[fft_pad(fft_cell<ODD>(plan, sy0 + k * FFT_THREADS))] = value[k];
+    }
     lds_fft<false, ODD>(x, tw, G, plan);
     for (int gy = threadIdx.x; gy < Gg; gy += FFT_THREADS)
         grid[(int64_t) gy * grid_row_stride + c] = x[fft_pad(grid_to_layer_index(gy, half, G))];
@@ -754,9 +856,18 @@ __global__ __launch_bounds__(FFT_THREADS) void cb_rows_forward_kernel(
     float2 *x = fft_lds, *tw = fft_lds + fft_lds_cells(G);
     fft_lds_setup(x, tw, plan, G, false);
     const int y1 = 2 * xcd_contiguous(blockIdx.x, gridDim.x);
-    for (int sx = threadIdx.x; sx < G; sx += FFT_THREADS)
-        x[fft_pad(fft_cell<ODD>(plan, sx))] = make_float2(image[(int64_t) y1 * row_stride + sx],
-                                                          image[(int64_t) (y1 + 1) * row_stride + sx]);
+    for (int sx0 = threadIdx.x; sx0 < G; sx0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sx0 + k * FFT_THREADS < G)
+                value[k] = make_float2(image[(int64_t) y1 * row_stride + sx0 + k * FFT_THREADS],
+                                       image[(int64_t) (y1 + 1) * row_stride + sx0 + k * FFT_THREADS]);
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (sx0 + k * FFT_THREADS < G)
+                x[fft_pad(fft_cell<ODD>(plan, sx0 + k * FFT_THREADS))] = value[k];
+    }
     lds_fft<false, ODD>(x, tw, G, plan);
     for (int lx = threadIdx.x; lx <= G / 2; lx += FFT_THREADS) {
         const float2 z = x[fft_pad(lx)], zm = x[fft_pad(lx ? G - lx : 0)];
@@ -774,8 +885,17 @@ __global__ __launch_bounds__(FFT_THREADS) void cb_columns_kernel(
     fft_lds_setup(x, tw, plan, G, false);
     const int lx = xcd_contiguous(blockIdx.x, gridDim.x);
     float2 *column = T + (int64_t) lx * G;
-    for (int y = threadIdx.x; y < G; y += FFT_THREADS)
-        x[fft_pad(fft_cell<ODD>(plan, y))] = column[y];
+    for (int y0 = threadIdx.x; y0 < G; y0 += FFT_BATCH * FFT_THREADS) {
+        float2 value[FFT_BATCH];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (y0 + k * FFT_THREADS < G)
+                value[k] = column[y0 + k * FFT_THREADS];
+#pragma unroll
+        for (int k = 0; k < FFT_BATCH; k++)
+            if (y0 + k * FFT_THREADS < G)
+                x[fft_pad(fft_cell<ODD>(plan, y0 + k * FFT_THREADS))] = value[k];
+    }
     lds_fft<false, ODD>(x, tw, G, plan);
     // fourier_beam_kernel's factor, and the result into the cells the inverse transform starts from
     const float u = (float) lx;
