@@ -398,6 +398,7 @@ class Clean(accel.OperationSequence):
             command_queue.context, (lib().kimg_clean_state_bytes(image_shape[0], tile_shape[1], tile_shape[0]) // 4,),
             np.int32, queue=command_queue)
         self._log = None
+        self._log_rows = 0
 
     def _run(self):
         raise NotImplementedError('use __call__(psf_patch, threshold) or run_cycles')
@@ -462,18 +463,29 @@ class Clean(accel.OperationSequence):
         if self._log is None or self._log.shape[0] < max_cycles:
             self._log = accel.DeviceArray(self.command_queue.context, (max_cycles, 3 + P),
                                           np.float32, queue=self.command_queue)
+        self._log_rows = max_cycles         # rows the coming call can write (the read-back's size)
 
     def _collect_cycle_arrays(self):
         """Read back what the device-resident loop logged (synchronises with the queue):
         (peak metrics float32 [n], positions int32 [n][2] as (y, x), model pixels float32 [n][P])."""
         # (only the head of the state buffer: it also holds the persistent form's per-workgroup
         # replicas, tens of megabytes)
-        state = np.empty((4,), np.int32)
-        self._state.get_region(self.command_queue, state, np.s_[:4], np.s_[:])
+        # ... and state and log in ONE read-back (each is a host round trip)
+        import torch
+        q = self.command_queue
+        self._state.used_on(q)
+        self._log.used_on(q)
+        with torch.cuda.stream(q.stream):
+            head = self._state.tensor.reshape(-1)[:4]
+            if head.dtype != torch.float32:
+                head = head.view(torch.float32)
+            rows = min(self._log_rows, self._log.shape[0])
+            both = torch.cat([head, self._log.tensor[:rows].reshape(-1)]).cpu().numpy()
+        state = both[:4].view(np.int32)
         if int(state[1]) == 2:
             check(-10004, 'kimg_clean_cycles')       # KIMG_ETIMEOUT: the persistent loop gave up
         count = int(state[0])
-        log = self._log.get(self.command_queue)[:count]
+        log = both[4:].reshape(rows, self._log.shape[1])[:count]
         return log[:, 0].copy(), log[:, 1:3].copy().view(np.int32), log[:, 3:].copy()
 
     def _collect_cycles(self):
