@@ -128,20 +128,24 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
             dirty = imager.buffer('dirty')
             centre = dirty.shape[1] // 2
             psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
+            # (this read is where the PSF's gridding and transform are waited for: the turn at the
+            # device ends here; what follows is small launches and host round trips, which
+            # may run next to another channel's gridding)
             dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
-            if np.any(psf_peak == 0):
-                return None
-            scale = np.reciprocal(psf_peak)
-            imager.scale_dirty(scale)
-            imager.dirty_to_psf()
-            psf_patch = imager.psf_patch()
-        out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
-                   psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
-                   peaks=[], noise=None)
-        if fit_beam:
-            from . import beam
-            psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
-            out['restoring_beam'] = beam.fit_beam(psf_core)
+    with trace.range('psf_patch'):
+        if np.any(psf_peak == 0):
+            return None
+        scale = np.reciprocal(psf_peak)
+        imager.scale_dirty(scale)
+        imager.dirty_to_psf()
+        psf_patch = imager.psf_patch()
+    out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
+               psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
+               peaks=[], noise=None)
+    if fit_beam:
+        from . import beam
+        psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
+        out['restoring_beam'] = beam.fit_beam(psf_core)
     for i in range(major):
         with device_phase():
             with trace.range('make_dirty[%d]' % i):
@@ -150,11 +154,11 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
             imager.scale_dirty(scale)
             out['major'] += 1
             with trace.range('noise_est'):
-                noise = imager.noise_est()
+                noise = imager.noise_est()      # (waits for the gridding: the turn ends here)
             out['noise'] = noise
-            with trace.range('first_cycle'):
-                imager.clean_reset()
-                peak_value = imager.clean_cycle(psf_patch)
+        with trace.range('first_cycle'):
+            imager.clean_reset()
+            peak_value = imager.clean_cycle(psf_patch)
         out['peaks'].append(peak_value)
         peak_power = clean.metric_to_power(clean_p.mode, peak_value)
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,

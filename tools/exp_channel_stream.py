@@ -60,6 +60,8 @@ frontend.process_channel_stream(make_job, range(4), workers=1)
 torch.cuda.synchronize()
 print('one channel at a time: %.2f ms per channel' % ((time.perf_counter() - t0) * 1e3 / 4))
 _make = clean.CleanBatcher
+if os.environ.get('KIMG_WINDOW_CUS'):      # (experiment: CUs the window kernels fill while channels share the device)
+    frontend.WINDOW_CUS_SHARED = int(os.environ['KIMG_WINDOW_CUS'])
 for workers in workers_list:
     for name, kw in (('in step', None), ('turns', dict(overlap=True)), ('turns, two at a time', dict(phase_permits=2))):
         if kw is not None:
