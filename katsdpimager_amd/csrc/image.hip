@@ -500,8 +500,9 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_columns_kernel(
 // Rows sy1 = 2 * blockIdx.x and sy1 + 1 of the real transform: both Hermitian sequences in one
 // complex transform (z = row1 + i row2 comes out with row1 in its real part, row2 in its
 // imaginary part), then real_layer_to_image_kernel's arithmetic.
+// (at most 85 registers: three workgroups per CU, as many as the LDS allows)
 template<bool ACCUMULATE, bool ODD>
-__global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
+__global__ __launch_bounds__(FFT_THREADS, 6) void g2i_rows_kernel(
     float *__restrict__ image, int64_t image_row_stride, const float2 *__restrict__ T, int Gg, int G,
     fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias)
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(FFT_THREADS) void g2i_rows_kernel(
 // complex sequence, forward transform, the two half spectra taken apart;
 // T[lx][sy] for lx = 0 .. Gg / 2.
 template<bool ODD>
-__global__ __launch_bounds__(FFT_THREADS) void i2g_rows_kernel(
+__global__ __launch_bounds__(FFT_THREADS, 6) void i2g_rows_kernel(
     float2 *__restrict__ T, const float *__restrict__ image, int64_t image_row_stride, int Gg, int G,
     fft_plan plan, const float *__restrict__ kernel1d,
     float lm_scale, float lm_bias)
