@@ -77,6 +77,20 @@ extern "C" {
                                          * 6.3 us per cycle: one CU's memory pipe): AUTO does not
                                          * take it. */
 
+#define KIMG_CLEAN_FORM_MULTI 5     /* SEVERAL components per launch: a launch verifies the components
+                                     * the last one evaluated speculatively, commits the verified
+                                     * prefix and evaluates the next up to 8 (csrc/clean_multi.hip);
+                                     * results bit-identical to the other forms.  At most 256 lattice
+                                     * blocks per patch (8 components per launch up to 32 blocks, 4
+                                     * up to 64, 2 up to 128) and 2047 tiles per axis; falls back to
+                                     * AUTO's other choices otherwise.  `form | n << 8` caps the
+                                     * components per launch at n (1..8).  AUTO takes this form when
+                                     * at least 2 components fit and at least 4 cycles are asked for.
+                                     * HOST-PACED: the number of launches depends on the data, so the
+                                     * call watches a progress word the device writes and returns
+                                     * once the loop has ended -- it blocks the calling thread for
+                                     * about as long as the loop runs, and cannot be captured. */
+
 #define KIMG_CLEAN_I 0      /* clean.py:29 */
 #define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libkimg.so')
 
 SOURCES = ['api.hip', 'grid.hip', 'grid_mfma.hip', 'grid_binned.hip', 'degrid_mfma.hip', 'image.hip', 'fft.hip', 'weight.hip',
-           'clean.hip', 'preprocess.hip', 'ktable.hip', 'store.hip']
+           'clean.hip', 'clean_multi.hip', 'preprocess.hip', 'ktable.hip', 'store.hip']
 
 # -ffp-contract=off: a*b+c is fused only where the source says fmaf(); the image/CLEAN
 # kernels must round exactly like the reference's numpy host path.

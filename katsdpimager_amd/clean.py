@@ -337,19 +337,22 @@ class _SubtractPsf(accel.Operation):
         check(rc, 'kimg_subtract_psf')
 
 
-CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2, 'persistent': 3, 'one_workgroup': 4}     # KIMG_CLEAN_FORM_*
+CLEAN_FORMS = {'auto': 0, 'two_launch': 1, 'one_launch': 2, 'persistent': 3, 'one_workgroup': 4,
+               'multi': 5}     # KIMG_CLEAN_FORM_*
 
 
 class CleanTemplate:
     """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'|
-    'persistent'|'one_workgroup'}``, the form of the device-resident loop of :meth:`Clean.run_cycles` (results are
-    identical; ``auto`` takes the fastest one the PSF patch allows)."""
+    'persistent'|'one_workgroup'|'multi'}``, the form of the device-resident loop of :meth:`Clean.run_cycles`
+    (results are identical; ``auto`` takes the fastest one the PSF patch allows), and with ``multi``
+    ``'components'``: the most components a launch may plan (1 to 8, default 8)."""
     def __init__(self, context, clean_parameters, dtype, num_polarizations, tuning=None):
         types.require_float32(dtype, 'CleanTemplate')
         tuning = tuning or {}
-        if set(tuning) - {'form'} or tuning.get('form', 'auto') not in CLEAN_FORMS:
+        if set(tuning) - {'form', 'components'} or tuning.get('form', 'auto') not in CLEAN_FORMS \
+                or not 0 <= int(tuning.get('components', 0)) <= 8:
             raise ValueError('bad CleanTemplate tuning {}'.format(tuning))
-        self.form = CLEAN_FORMS[tuning.get('form', 'auto')]
+        self.form = CLEAN_FORMS[tuning.get('form', 'auto')] | int(tuning.get('components', 0)) << 8
         self.context = context
         self.clean_parameters = clean_parameters
         self.dtype = np.dtype(dtype)
@@ -487,6 +490,19 @@ class Clean(accel.OperationSequence):
         count = int(state[0])
         log = both[4:].reshape(rows, self._log.shape[1])[:count]
         return log[:, 0].copy(), log[:, 1:3].copy().view(np.int32), log[:, 3:].copy()
+
+    def last_launches(self):
+        """Launches the last :meth:`run_cycles` took if it ran in the multi-component form
+        (KIMG_CLEAN_FORM_MULTI: 1 to 8 components per launch), else None.  Synchronises."""
+        import torch
+        q = self.command_queue
+        self._state.used_on(q)
+        with torch.cuda.stream(q.stream):
+            head = self._state.tensor.reshape(-1)[:176].cpu().numpy().view(np.int32)
+        if head[4] != 0x4d554c54:       # mc_scratch.pad[0], set by mc_init_kernel
+            return None
+        # mc_state.launches of the two state buffers (byte offsets 64 + 28 and 64 + 560 + 28)
+        return int(max(head[16 + 7], head[16 + 140 + 7]))
 
     def _collect_cycles(self):
         """The same as a list of (peak_value, (y, x), model_pixel), the reference's per-cycle

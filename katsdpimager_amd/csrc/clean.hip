@@ -2078,8 +2078,10 @@ extern "C" size_t kimg_clean_state_bytes(int num_polarizations, int tiles_x, int
     static_assert(sizeof(fused_scratch) >= sizeof(clean_state), "the two forms share the scratch");
     if (tiles_x <= 0 || tiles_y <= 0)
         return 0;
-    return persist_offset(tiles_x, tiles_y) + sizeof(persist_header)
-           + (size_t) (PERSIST_MAX_WGS - 1) * tiles_x * tiles_y * sizeof(replica_t);
+    const size_t n = persist_offset(tiles_x, tiles_y) + sizeof(persist_header)
+                     + (size_t) (PERSIST_MAX_WGS - 1) * tiles_x * tiles_y * sizeof(replica_t);
+    const size_t m = kimg_clean_multi_state_bytes(tiles_x, tiles_y);
+    return n > m ? n : m;
 }
 
 namespace {
@@ -2275,10 +2277,30 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
+    const int components = (form >> 8) & 0xff;      // KIMG_CLEAN_FORM_MULTI: components per launch
+    form &= 0xff;
     KIMG_CHECK_ARG(form == KIMG_CLEAN_FORM_AUTO || form == KIMG_CLEAN_FORM_TWO_LAUNCH
                    || form == KIMG_CLEAN_FORM_ONE_LAUNCH || form == KIMG_CLEAN_FORM_PERSISTENT
-                   || form == KIMG_CLEAN_FORM_ONE_WORKGROUP);
+                   || form == KIMG_CLEAN_FORM_ONE_WORKGROUP || form == KIMG_CLEAN_FORM_MULTI);
     hipStream_t s = (hipStream_t) stream;
+    // several components per launch where the patch leaves room for at least two lattices among
+    // the 256 records of a launch (a call of a few cycles is not worth the host-paced loop)
+    {
+        const int m = kimg_clean_multi_components(patch_width, patch_height, tiles_x, tiles_y);
+        if (max_cycles > 0 && (form == KIMG_CLEAN_FORM_MULTI ? m >= 1
+                                                             : form == KIMG_CLEAN_FORM_AUTO && m >= 2
+                                                                   && max_cycles >= 4)) {
+            const int rc = kimg_clean_multi_run(
+                dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf,
+                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
+                border, mode, loop_gain, threshold, tile_max, tile_pos, tiles_x, tiles_y,
+                max_cycles, components, state, log, s);
+            if (rc != KIMG_EUNSUPPORTED)
+                return rc;
+        }
+        if (form == KIMG_CLEAN_FORM_MULTI)
+            form = KIMG_CLEAN_FORM_AUTO;
+    }
     // one launch per cycle when the patch touches few lattice blocks (every workgroup then
     // repeats the global peak search)
     const int bx = kimg_divup(patch_width, TILE) + 1, by = kimg_divup(patch_height, TILE) + 1;

@@ -21,6 +21,17 @@ static inline int kimg_divup(int64_t a, int64_t b) { return (int) ((a + b - 1) /
 // (kimg_set_window_cus; api.hip)
 int kimg_window_cus_now();
 
+// The multi-component form of the CLEAN loop (clean_multi.hip), reached through kimg_clean_cycles
+int kimg_clean_multi_components(int patch_width, int patch_height, int tiles_x, int tiles_y);
+size_t kimg_clean_multi_state_bytes(int tiles_x, int tiles_y);
+int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
+                         int width, int height, int num_polarizations, const float *psf,
+                         int64_t psf_row_stride, int64_t psf_pol_stride, int psf_width,
+                         int psf_height, int patch_width, int patch_height, int border, int mode,
+                         float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
+                         int tiles_x, int tiles_y, int max_cycles, int components, void *state,
+                         float *log, hipStream_t s);
+
 constexpr int WAVE = 64;    // gfx950 wavefront
 
 // Wave-wide sum by DPP-backed shuffles; result valid in every lane.

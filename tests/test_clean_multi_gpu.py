@@ -1,0 +1,132 @@
+"""GPU parity of the multi-component CLEAN launch (csrc/clean_multi.hip, KIMG_CLEAN_FORM_MULTI)
+through the C ABI: components (metric, position, flux), residual image, model image and the tile
+arrays left behind are BIT-EXACT against the restated CleanHost (oracle/kimg_oracle.Clean,
+clean.py:1060-1075), for every cap on the components per launch."""
+import numpy as np
+import pytest
+
+from helpers import context_queue
+from oracle import kimg_oracle as orc
+from test_clean_multi_model import fuzz_problem, reference_run, sources_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _clean(G, P, mode, border, loop_gain, dirty, psf, tuning):
+    from katsdpimager_amd import clean, parameters
+    ctx, q = context_queue()
+    fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
+    cp = parameters.CleanParameters(1000, loop_gain, 0.85, 5.0, mode, 0.01, 0.5, border)
+    fn = clean.CleanTemplate(ctx, cp, np.float32, P, tuning).instantiate(q, ip)
+    fn.ensure_all_bound()
+    fn.buffer('dirty').set(q, dirty)
+    fn.buffer('psf').set(q, psf)
+    fn.buffer('model').zero(q)
+    fn.reset()
+    return fn, q
+
+
+def _check(fn, q, got, want):
+    log, img, model, tile_max, tile_pos = want
+    assert len(got) == len(log)
+    for a, b in zip(got, log):
+        assert a[0] == b[0] and tuple(a[1]) == tuple(b[1]), (a, b)
+        np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(fn.buffer('dirty').get(q), img)
+    np.testing.assert_array_equal(fn.buffer('model').get(q), model)
+    np.testing.assert_array_equal(fn.buffer('tile_max').get(q), tile_max)
+    np.testing.assert_array_equal(fn.buffer('tile_pos').get(q), tile_pos)
+
+
+@pytest.mark.parametrize('components', [0, 1, 2, 5])
+@pytest.mark.parametrize('seed', range(8))
+def test_multi_fuzz(seed, components):
+    """The problems of test_clean_fuzz (odd shapes, 1-4 polarizations, both metrics, borders,
+    patches from one pixel to larger than the image, thresholds that stop the loop)."""
+    rs, P, mode, G, border, loop_gain, psf, dirty, patch, cycles = fuzz_problem(seed)
+    fn, q = _clean(G, P, mode, border, loop_gain, dirty, psf, {'form': 'multi', 'components': components})
+    first = float(np.max(fn.buffer('tile_max').get(q)))
+    threshold = float(rs.choice([0.0, 0.3 * first, 2.0 * first]))
+    want = reference_run(G, border, loop_gain, mode, dirty, psf, patch, threshold, cycles)
+    got = fn.run_cycles(patch, threshold, cycles)
+    _check(fn, q, got, want)
+
+
+@pytest.mark.parametrize('G,P,mode,border,patch,n_sources,cycles,components', [
+    (512, 1, 0, 0.02, (33, 47), 60, 300, 0),
+    (512, 1, 0, 0.02, (33, 47), 60, 300, 3),
+    (768, 1, 0, 0.02, (111, 133), 40, 250, 0),       # 5 x 6 lattice blocks: the bench's patch
+    (640, 2, 1, 0.05, (65, 65), 50, 200, 0),         # 4 x 4 lattice blocks, sum of squares
+    (512, 4, 1, 0.0, (31, 95), 60, 150, 0),
+    (512, 4, 0, 0.1, (95, 31), 60, 150, 4),
+    (1024, 1, 0, 0.02, (161, 191), 50, 200, 0),      # 7 x 7 = 49 blocks: four components per launch
+    (1024, 1, 0, 0.02, (225, 321), 50, 120, 0),      # 9 x 12 = 108 blocks: two per launch
+    (1024, 1, 0, 0.013, (65, 97), 120, 400, 0),      # border 13
+])
+def test_multi_many_sources(G, P, mode, border, patch, n_sources, cycles, components):
+    """Many sources of similar brightness: launches plan several components, some of them in
+    vain (neighbouring sources, repeated peaks); the result is the reference's all the same."""
+    rs, psf, dirty = sources_problem(G + P, G=G, P=P, n_sources=n_sources)
+    fn, q = _clean(G, P, mode, border, 0.1, dirty, psf, {'form': 'multi', 'components': components})
+    full = (P,) + patch
+    want = reference_run(G, border, 0.1, mode, dirty, psf, full, 0.0, cycles)
+    got = fn.run_cycles(full, 0.0, cycles)
+    _check(fn, q, got, want)
+    launches = fn.last_launches()
+    assert launches is not None and launches >= 1
+    if components != 1 and patch[0] * patch[1] < 100 * 140:
+        assert launches < 0.7 * cycles, launches     # several components per launch did happen
+
+
+def test_multi_continues_and_stops():
+    """Consecutive calls continue where the last one stopped; thresholds and cycle limits stop the
+    loop at exactly the reference's component, whatever had been planned beyond it."""
+    G, P = 512, 1
+    rs, psf, dirty = sources_problem(3, G=G, P=P, n_sources=50)
+    fn, q = _clean(G, P, 0, 0.02, 0.1, dirty, psf, {'form': 'multi'})
+    patch = (1, 47, 33)
+    img, model = dirty.copy(), np.zeros_like(dirty)
+    ref = orc.Clean(G, 0.02, 0.1, 0, img, psf, model)
+    ref.reset()
+    first = float(np.max(ref._tile_max))
+    for cycles, threshold in ((1, 0.0), (2, 0.0), (3, 0.0), (7, 0.0), (64, 0.0), (500, 0.8 * first),
+                              (500, 0.8 * first), (33, 0.5 * first), (500, 0.6 * first)):
+        want = []
+        for _ in range(cycles):
+            v, pos, pix = ref(patch, threshold)
+            if v is None:
+                break
+            want.append((v, ref.last_pos, np.array(pix)))
+        got = fn.run_cycles(patch, threshold, cycles)
+        _check(fn, q, got, (want, img, model, ref._tile_max, ref._tile_pos))
+
+
+def test_multi_edge_images():
+    """An all-zero image (the (x0, y0) start position of clean.py:950 wins every cycle), a constant
+    one (every tile ties: the lowest tile index wins; more equal maxima than the keeper lists), and
+    exact ties between distant pixels."""
+    G = 160
+    psf = np.zeros((1, G, G), np.float32)
+    psf[0, G // 2 - 2:G // 2 + 3, G // 2 - 2:G // 2 + 3] = 0.5
+    psf[0, G // 2, G // 2] = 1.0
+    tie = np.zeros((1, G, G), np.float32)
+    tie[0, 20, 130] = tie[0, 100, 30] = tie[0, 100, 31] = tie[0, 140, 140] = 3.0
+    tie[0, 60, 60] = -3.0
+    for dirty in (np.zeros((1, G, G), np.float32), np.full((1, G, G), 0.75, np.float32), tie):
+        for border in (0.0, 0.05):
+            fn, q = _clean(G, 1, 0, border, 0.3, dirty, psf, {'form': 'multi'})
+            want = reference_run(G, border, 0.3, 0, dirty, psf, (1, 5, 5), 0.0, 40)
+            got = fn.run_cycles((1, 5, 5), 0.0, 40)
+            _check(fn, q, got, want)
+
+
+def test_multi_is_what_auto_takes():
+    """`auto` takes the multi-component form when the patch leaves room for two lattices."""
+    G = 512
+    rs, psf, dirty = sources_problem(11, G=G, P=1, n_sources=60)
+    fn, q = _clean(G, 1, 0, 0.02, 0.1, dirty, psf, None)
+    want = reference_run(G, 0.02, 0.1, 0, dirty, psf, (1, 33, 47), 0.0, 200)
+    got = fn.run_cycles((1, 33, 47), 0.0, 200)
+    _check(fn, q, got, want)
+    assert fn.last_launches() is not None and fn.last_launches() < 140

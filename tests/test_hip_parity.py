@@ -1744,7 +1744,7 @@ def test_clean_one_launch_cycle_matches_two_launch(G, P, mode, border, patch):
         return (log, fn.buffer('dirty').get(q), fn.buffer('model').get(q),
                 fn.buffer('tile_max').get(q), fn.buffer('tile_pos').get(q))
     b = run('two_launch')
-    for form in ('one_launch', 'persistent', 'one_workgroup', 'auto'):
+    for form in ('one_launch', 'persistent', 'one_workgroup', 'auto', 'multi'):
         a = run(form)
         assert len(a[0]) == len(b[0]) and 188 <= len(a[0]) < 1188
         for u, w in zip(a[0], b[0]):

@@ -1,0 +1,64 @@
+"""Minor cycles per second of the multi-component CLEAN launch (KIMG_CLEAN_FORM_MULTI) against the
+one-launch-per-cycle form, by the cap on the components per launch, on the bench's CLEAN image
+(4096^2, 200 point sources (x) PSF + noise), with the launches taken and the components per launch.
+
+    python tools/exp_clean_multi.py [patch height] [patch width] [cycles]"""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from katsdpimager_amd import accel, clean, parameters
+
+ph = int(sys.argv[1]) if len(sys.argv) > 1 else 111
+pw = int(sys.argv[2]) if len(sys.argv) > 2 else 133
+cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+G, P = 4096, 1
+ctx = accel.create_some_context()
+q = ctx.create_command_queue()
+rs = np.random.RandomState(4)
+g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
+psf = np.outer(g1, g1)[None].astype(np.float32)
+psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
+psf[:, G // 2, G // 2] = 1.0
+sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
+for _ in range(200):
+    y, x = rs.randint(100, G - 100, 2)
+    sky[:, y - 30:y + 31, x - 30:x + 31] += rs.uniform(0.5, 2.0) * psf[:, G // 2 - 30:G // 2 + 31,
+                                                                     G // 2 - 30:G // 2 + 31]
+
+
+class _IP:      # what CleanTemplate.instantiate reads of the image parameters
+    pixels = G
+
+    class fixed:
+        polarizations = [0]
+        real_dtype = np.float32
+
+
+cp = parameters.CleanParameters(cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
+patch = (P, ph, pw)
+first = None
+for form, comps in [('one_launch', 0)] + [('multi', c) for c in (1, 2, 4, 6, 8)]:
+    cl = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form, 'components': comps}).instantiate(q, _IP)
+    cl.ensure_all_bound()
+    cl.buffer('psf').set(q, psf)
+    rates = []
+    for rep in range(4):
+        cl.buffer('dirty').set(q, sky)
+        cl.buffer('model').zero(q)
+        cl.reset()
+        q.finish()
+        t0 = time.perf_counter()
+        got = cl.run_cycles(patch, 0.0, cycles)
+        q.finish()
+        rates.append(len(got) / (time.perf_counter() - t0))
+    launches = cl.last_launches()
+    sig = [(round(float(v), 6), tuple(p)) for v, p, m in got]
+    first = first or sig
+    print('%-10s cap %d: %9.0f cycles/s = %.2f us per cycle; launches %s (%.2f components each, %.2f us per launch)  %s' % (
+        form, comps, max(rates), 1e6 / max(rates), launches,
+        len(got) / launches if launches else 1.0,
+        1e6 * len(got) / max(rates) / (launches or len(got)),
+        'same components' if sig == first else 'DIFFERENT'))
+    del cl
