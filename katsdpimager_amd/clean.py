@@ -498,11 +498,11 @@ class Clean(accel.OperationSequence):
         q = self.command_queue
         self._state.used_on(q)
         with torch.cuda.stream(q.stream):
-            head = self._state.tensor.reshape(-1)[:176].cpu().numpy().view(np.int32)
+            head = self._state.tensor.reshape(-1)[:1140].cpu().numpy().view(np.int32)
         if head[4] != 0x4d554c54:       # mc_scratch.pad[0], set by mc_init_kernel
             return None
-        # mc_state.launches of the two state buffers (byte offsets 64 + 28 and 64 + 560 + 28)
-        return int(max(head[16 + 7], head[16 + 140 + 7]))
+        # mc_state.launches of the two state buffers (byte offsets 64 + 28 and 64 + 4416 + 28)
+        return int(max(head[16 + 7], head[16 + 1104 + 7]))
 
     def _collect_cycles(self):
         """The same as a list of (peak_value, (y, x), model_pixel), the reference's per-cycle
@@ -527,6 +527,32 @@ def batch_supported(clean, psf_patch):
     bx = accel.divup(psf_patch[2], TILE) + 1
     by = accel.divup(psf_patch[1], TILE) + 1
     return bx <= 32 and by <= 32 and bx * (by + 1) <= 256
+
+
+def multi_components(clean, psf_patch):
+    """Components per launch of the multi-component form of the device-resident loop
+    (KIMG_CLEAN_FORM_MULTI, csrc/clean_multi.hip: kimg_clean_multi_components) for this patch:
+    256 record slots per launch, a power of two (at least 16) of them per lattice; 0 = not available."""
+    bx = accel.divup(psf_patch[2], TILE) + 1
+    by = accel.divup(psf_patch[1], TILE) + 1
+    tiles = clean.buffer('tile_max').shape
+    if bx * by > 256 or max(tiles) > 2047 or tiles[0] * tiles[1] < 4:
+        return 0
+    seg = 16
+    while seg < bx * by:
+        seg *= 2
+    return min(8, 256 // seg)
+
+
+def prefers_solo(clean, psf_patch, max_cycles):
+    """Is this channel's loop better run on its own than in a batch?  Yes where a launch can plan
+    several components (what ``auto`` then does: kimg_clean_cycles): several components per
+    launch beat one per channel and launch, and the launches of that form wait for nobody, so the
+    channels' loops share the device freely."""
+    template = getattr(clean, 'template', None)
+    if template is None or (template.form & 0xff) != CLEAN_FORMS['auto'] or max_cycles < 4:
+        return False
+    return multi_components(clean, psf_patch) >= 2
 
 
 def enqueue_cycles_batch(cleans, psf_patches, thresholds, max_cycles, command_queue=None):
@@ -665,7 +691,9 @@ class CleanBatcher:
         self._cleaning += len(entries)
         groups = {}
         for e in entries:
-            if batch_supported(e['clean'], e['patch']):
+            if prefers_solo(e['clean'], e['patch'], e['max_cycles']):
+                e['solo'] = True
+            elif batch_supported(e['clean'], e['patch']):
                 groups.setdefault(e['clean']._batch_key(), []).append(e)
             else:
                 e['solo'] = True

@@ -52,7 +52,10 @@ typedef unsigned long long mkey_t;
 constexpr int TILE = 32;                // clean.py:996
 constexpr int MC_MAX = 8;               // components per launch
 constexpr int MC_THREADS = 256;         // threads of a workgroup = records of a launch
-constexpr int MC_REST = 8;              // entries of the keeper's list that the next launch reads
+constexpr int MC_REST = 24;             // entries of the list (lanes 8 .. 31 of a wave load one each)
+constexpr int MC_POOL_REST = 8;         // of which the first that survive enter the candidate pool
+constexpr int MC_TOP = 128;             // entries of the list the lister maintains
+constexpr int MC_LOW = 24;              // fewer than this left: the lister scans the tile maxima again
 constexpr int MC_CAP = 256;             // tiles the keeper sorts: one per thread
 constexpr mkey_t MC_REAL = 1024;        // smaller keys stand for "nothing" (distinct fillers)
 constexpr int MC_MAX_TILES = 2047;      // tiles per axis (11 bits each in a key)
@@ -158,17 +161,19 @@ struct __attribute__((aligned(16))) mc_state {      // written by the keeper of 
     int count, done, limit;
     float threshold;
     int planned;            // components planned by the launch that wrote this
-    int rest_n;             // entries of `rest`
-    int tau;                // value bits above which the keeper lists a tile (-1: every tile)
+    int top_n;              // entries of `top`
+    int tau;                // value bits above which the last scan listed a tile (-1: every tile)
     int launches;
-    mkey_t rest_floor;      // every tile outside the planned lattices that is not in `rest` has a key <= this
+    mkey_t rest_floor;      // for a reader of the first MC_REST entries: every other tile has a key <= this
     int gen;                // the call's tag in the progress word
     int pad;
+    mkey_t top_floor;       // every tile that is not in `top` has a key <= this
+    mkey_t pad2;
     mc_record plan[MC_MAX]; // the planned components: key + pixel values at the peak
-    mc_record rest[MC_REST];
+    mc_record top[MC_TOP];  // the best tiles of the image, sorted: key + pixel values at the tile's peak
 };
 
-static_assert(sizeof(mc_state) == 560, "Clean.last_launches reads `launches` at fixed offsets");
+static_assert(sizeof(mc_state) == 4416, "Clean.last_launches reads `launches` at fixed offsets");
 
 struct mc_scratch {
     int head[4];            // count, done, limit, threshold bits: what the host reads, as the other forms'
@@ -213,60 +218,108 @@ __device__ inline int lower_tau(int tau)
 #define MC_FLUSH() do { } while (0)
 #endif
 
-// ---- the keeper's list -----------------------------------------------------------------------
-// The best tiles outside the rectangles `excl` (this launch's lattices), sorted, into next->rest,
-// with a floor: every tile outside them that is not listed has a key <= floor.  Values: the base tile
-// arrays -- exact for every tile outside the rectangles `flux` (the lattices being folded by this
-// launch's folder), whose tiles come from the delta records the threads hold instead.
+// ---- the lister's list ----------------------------------------------------------------------
+// The best tiles of the image as the commits so far leave it, sorted, into next->top, with a
+// floor: every tile that is not listed has a key <= floor.  (The list does not know this launch's
+// plan: the next launch drops the entries inside this launch's lattices itself.)
+//
+// From launch to launch the list is MAINTAINED, not rebuilt: the tiles whose values changed are
+// exactly those of the lattices the folder is writing, so the entries inside those go, the delta
+// records above the floor come in, everything else stands, and the floor holds.  One workgroup
+// reading all the tile maxima in every launch was the longest chain of the launch (60 KB through one
+// CU's memory pipe: 3 us).  Only when fewer than MC_LOW entries are left (the image has been
+// cleaned down to the floor) are the tile maxima scanned again, with a lower floor:
 //   pass A  every thread filters its share of the tile maxima by value alone (bits > tau) and
-//           appends the indices that pass to a list in LDS; threads that hold a committed delta
-//           above tau append it too.  tau follows the image down from launch to launch so that
-//           some tens of tiles pass;
-//   pass B  one listed tile per thread: tile coordinates, the rectangle tests, its key;
-//   rank    one listed tile per thread: the number of larger keys; the best MC_REST go out with their
-//           best pixel and the values there (base arrays or delta table).
-// If more than MC_CAP tiles pass, or none survives pass B, tau is moved (bisection, bounded) and the
-// passes are repeated: rare.  One workgroup; all threads call.
+//           appends the indices that pass to a list in LDS (values: the base arrays -- exact
+//           outside the lattices being folded, whose tiles come from the delta records instead);
+//   pass B  one listed tile per thread: tile coordinates, the rectangle tests, its key.
+//   If more than MC_CAP tiles pass, or none survives pass B, tau is moved (bisection, bounded)
+//   and the passes are repeated.
+// Then, either way, one listed tile per thread: its rank = the number of larger keys; the best
+// MC_TOP go out with their best pixel and the values there.  One workgroup; all threads call.
 struct rest_lds {
-    mkey_t key[MC_CAP];
-    int idx[MC_CAP];            // tile index in the base arrays, or -1 - (slot of the delta record)
+    __attribute__((aligned(16))) mkey_t key[MC_CAP];
+    int idx[MC_CAP];            // tile index in the base arrays, -1 - (slot of the delta record), or
+                                // INT_MIN: an entry of the old list, pixel values in `pix`
+    float pix[MC_CAP][4];
     int na, hi, nvalid;
     mkey_t best;
 };
 
 __device__ __attribute__((always_inline)) inline void mc_build_rest(
     const float *tile_max, const int32_t *tile_pos, const float *tile_pix, const mc_record *deltas,
-    const mc_geom &g, int tau, int nmin, const int (*flux)[2], int nflux, const int (*excl)[2],
-    int nexcl, mkey_t dkey, mc_state *next, rest_lds &s, long long *dbg_v, long long dbg_t0)
+    const mc_geom &g, int tau, int nmin, int myrx, int myry, int nflux, mkey_t dkey, float4 dpix,
+    bool have_old, int4 old0, int4 old1, int old_n, mkey_t old_floor, mc_state *next, rest_lds &s,
+    long long *dbg_v, long long dbg_t0)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
+    // myrx, myry: lane r < nflux of every wave holds the tile origin of rectangle r (the lattices
+    // the folder is writing: their tiles come from the delta records, `dkey`)
+    const int tid = threadIdx.x;
     const int nt = g.tiles_x * g.tiles_y;
     constexpr int CH = 8;
-    // lane r of every wave keeps rectangle r: the folder's first, then this launch's
-    int myrx = INT_MIN / 2, myry = INT_MIN / 2;
-    if (lane < nflux) {
-        myrx = flux[lane][0];
-        myry = flux[lane][1];
-    } else if (lane < nflux + nexcl) {
-        myrx = excl[lane - nflux][0];
-        myry = excl[lane - nflux][1];
-    }
     const unsigned flux_mask = (1u << nflux) - 1u;
-    const unsigned excl_mask = ((1u << (nflux + nexcl)) - 1u) & ~flux_mask;
     auto rect_hits = [&](int tx, int ty) {
         unsigned hits = 0;
 #pragma unroll
-        for (int r = 0; r < 2 * MC_MAX; r++) {
+        for (int r = 0; r < MC_MAX; r++) {
             const int rx = __builtin_amdgcn_readlane(myrx, r), ry = __builtin_amdgcn_readlane(myry, r);
             hits |= ((unsigned) (tx - rx) < (unsigned) g.lat_x && (unsigned) (ty - ry) < (unsigned) g.lat_y)
                         ? 1u << r : 0u;
         }
-        return hits;
+        return hits & flux_mask;
     };
     int lo = -2, up = -2;           // tau known to list too many / known to list nothing (-2: none)
     bool single = false;
     int na = 0;
-    for (int attempt = 0; attempt < 100; attempt++) {
+    bool scan = !have_old;
+    if (!scan) {
+        // ---- the old list without the lattices being folded, plus their delta records ----------
+        __syncthreads();
+        if (tid == 0) {
+            s.na = 0;
+            s.nvalid = 0;
+        }
+        // (this thread's entry of the old list was fetched with the launch's first loads)
+        mc_record o;
+        o.key = tid < old_n ? ((mkey_t) (unsigned) old0.y << 32) | (unsigned) old0.x : 0;
+        o.pix[0] = __int_as_float(old0.z);
+        o.pix[1] = __int_as_float(old0.w);
+        o.pix[2] = __int_as_float(old1.x);
+        o.pix[3] = __int_as_float(old1.y);
+        const mc_cand oc = mc_decode(o.key, g.border);
+        const bool keep = o.key >= MC_REAL && !rect_hits(oc.tx, oc.ty);
+        const bool fresh = dkey >= MC_REAL && dkey > old_floor;
+        __syncthreads();
+        // (two reservations of ONE slot each: a sum of per-lane counts would be gathered lane by lane)
+        if (keep) {
+            const int slot = atomicAdd(&s.na, 1);
+            if (slot < MC_CAP) {
+                s.key[slot] = o.key;
+                s.idx[slot] = INT_MIN;
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    s.pix[slot][p] = o.pix[p];
+            }
+        }
+        if (fresh) {
+            const int slot = atomicAdd(&s.na, 1);
+            if (slot < MC_CAP) {
+                s.key[slot] = dkey;
+                s.idx[slot] = INT_MIN;
+                *reinterpret_cast<float4 *>(s.pix[slot]) = dpix;
+            }
+        }
+        __syncthreads();
+        na = s.na;
+        MC_STAMP(12);
+        // (too many to rank, which 64 + 254 allow in principle, or too few left: scan)
+        scan = na > MC_CAP || (na < MC_LOW && old_floor != 0);
+        if (scan) {
+            tau = lower_tau(tau);
+            nmin = MC_TOP;
+        }
+    }
+    for (int attempt = 0; scan && attempt < 100; attempt++) {
         __syncthreads();
         if (tid == 0) {
             s.na = 0;
@@ -282,35 +335,41 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
                 float4 v[CH];
 #pragma unroll
                 for (int c = 0; c < CH; c++) {
+                    // (all loads of a round in flight together: no branches here; a group that
+                    // reaches past the end is read from the last four tiles instead)
                     const int i4 = base + 4 * (tid + MC_THREADS * c);
-                    if (i4 + 3 < nt) {
-                        v[c] = *reinterpret_cast<const float4 *>(tile_max + i4);
-                    } else {
-                        v[c].x = i4 < nt ? tile_max[i4] : -1.0f;
-                        v[c].y = i4 + 1 < nt ? tile_max[i4 + 1] : -1.0f;
-                        v[c].z = i4 + 2 < nt ? tile_max[i4 + 2] : -1.0f;
-                        v[c].w = -1.0f;
-                    }
+                    v[c] = *reinterpret_cast<const float4 *>(tile_max + min(i4, nt - 4));
                 }
+                // which of this round's 32 tiles pass: one bit each, then ONE reservation of list
+                // slots per thread (an LDS atomic per tile would be a round trip per tile)
+                unsigned pass = 0;
 #pragma unroll
                 for (int c = 0; c < CH; c++) {
-                    // (non-negative floats order like their bit patterns; -1 = no tile)
-                    const int top = max(max(__float_as_int(v[c].x), __float_as_int(v[c].y)),
-                                        max(__float_as_int(v[c].z), __float_as_int(v[c].w)));
-                    if (top > tau) {
-                        const float e[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
-                        for (int k = 0; k < 4; k++) {
-                            const int bits = __float_as_int(e[k]);
-                            if (bits > tau) {
-                                const int slot = atomicAdd(&s.na, 1);
-                                if (slot < MC_CAP)
-                                    s.idx[slot] = base + 4 * (tid + MC_THREADS * c) + k;
-                            }
-                        }
-                        my_hi = max(my_hi, top);
+                    const int i4 = base + 4 * (tid + MC_THREADS * c), b4 = min(i4, nt - 4);
+                    // (non-negative floats order like their bit patterns; -1 = not this group's tile)
+                    const int e[4] = {b4 >= i4 ? __float_as_int(v[c].x) : -1,
+                                      b4 + 1 >= i4 ? __float_as_int(v[c].y) : -1,
+                                      b4 + 2 >= i4 ? __float_as_int(v[c].z) : -1,
+                                      b4 + 3 >= i4 ? __float_as_int(v[c].w) : -1};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        pass |= e[k] > tau ? 1u << (4 * c + k) : 0u;
+                    my_hi = max(my_hi, max(max(e[0], e[1]), max(e[2], e[3])));
+                }
+                if (pass) {
+                    int slot = atomicAdd(&s.na, __builtin_popcount(pass));
+                    while (pass) {
+                        const int bit = __builtin_ctz(pass);
+                        pass &= pass - 1u;
+                        const int c = bit >> 2, i4 = base + 4 * (tid + MC_THREADS * c);
+                        if (slot < MC_CAP)
+                            s.idx[slot] = min(i4, nt - 4) + (bit & 3);
+                        slot++;
                     }
                 }
             }
+            if (attempt == 0)
+                MC_STAMP(13);
             if (dkey >= MC_REAL && (int) (dkey >> 32) > tau) {
                 const int slot = atomicAdd(&s.na, 1);
                 my_hi = max(my_hi, (int) (dkey >> 32));
@@ -319,22 +378,19 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
                     s.key[slot] = dkey;
                 }
             }
-            if (my_hi >= 0)
+            if (my_hi > tau)
                 atomicMax(&s.hi, my_hi);
         } else {
             for (int t = tid; t < nt; t += MC_THREADS) {
                 const float value = tile_max[t];
                 if (__float_as_int(value) == tau + 1) {
                     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
-                    if (!(rect_hits(tx, ty) & (flux_mask | excl_mask)))
+                    if (!rect_hits(tx, ty))
                         atomicMax(&s.best, mc_key(value, tx, ty, 0, 0));
                 }
             }
-            if (dkey >= MC_REAL && (int) (dkey >> 32) == tau + 1) {
-                const mc_cand c = mc_decode(dkey, g.border);
-                if (!(rect_hits(c.tx, c.ty) & excl_mask))
-                    atomicMax(&s.best, dkey);
-            }
+            if (dkey >= MC_REAL && (int) (dkey >> 32) == tau + 1)
+                atomicMax(&s.best, dkey);
         }
         __syncthreads();
         if (single) {
@@ -377,12 +433,9 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
             if (t >= 0) {
                 const float value = tile_max[t];
                 const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
-                key = (rect_hits(tx, ty) & (flux_mask | excl_mask)) ? 0 : mc_key(value, tx, ty, 0, 0);
+                key = rect_hits(tx, ty) ? 0 : mc_key(value, tx, ty, 0, 0);
             } else {
                 key = s.key[tid];
-                const mc_cand c = mc_decode(key, g.border);
-                if (rect_hits(c.tx, c.ty) & excl_mask)
-                    key = 0;
             }
             s.key[tid] = key;
             if (key)
@@ -404,70 +457,77 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
         break;
     }
     MC_STAMP(9);
+    MC_COUNT(19, scan ? 1 : 0);
     // ---- rank and output ----------------------------------------------------------------------------
     const mkey_t k = tid < na ? s.key[tid] : 0;
     int rank = 0;
-    for (int i = 0; i < na; i++)
-        rank += s.key[i] > k ? 1 : 0;
-    const int nvalid = single ? na : s.nvalid;
+    {
+        // (two keys per LDS read; a key past the end of the list never counts)
+        const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(s.key);
+#pragma unroll 4
+        for (int i = 0; i < na; i += 2) {
+            const ulonglong2 two = pairs[i >> 1];
+            rank += two.x > k ? 1 : 0;
+            rank += i + 1 < na && two.y > k ? 1 : 0;
+        }
+    }
+    const int nvalid = !scan || single ? na : s.nvalid;
     MC_COUNT(14, nvalid);
-    const mkey_t floor_tau = single ? (na ? (s.key[0] >> 10 << 10) - 1 : 0)
-                                    : (tau < 0 ? 0 : ((mkey_t) (unsigned) tau << 32 | 0xffffffffu));
-    if (k >= MC_REAL && rank < MC_REST) {
+    // the floor of what was gathered: the old one if the list was only maintained, else the scan's
+    const mkey_t gathered = !scan ? old_floor
+                            : single ? (na ? (s.key[0] >> 10 << 10) - 1 : ((mkey_t) (unsigned) (tau + 1) << 32 | 0xffffffffu))
+                            : (tau < 0 ? 0 : ((mkey_t) (unsigned) tau << 32 | 0xffffffffu));
+    if (k >= MC_REAL && rank < MC_TOP) {
         mc_record r;
         r.key = k;
         r.pad[0] = r.pad[1] = 0;
         const int t = s.idx[tid];
+        float4 px;
         if (t >= 0) {
             // a tile of the base arrays: its best pixel and the values there
             const mc_cand c = mc_decode(k, g.border);
             const int2 pos = *reinterpret_cast<const int2 *>(tile_pos + 2 * t);
-            const float4 px = *reinterpret_cast<const float4 *>(tile_pix + 4 * t);
+            px = *reinterpret_cast<const float4 *>(tile_pix + 4 * t);
             if (c.value != 0.0f)
                 r.key = mc_key(c.value, c.tx, c.ty, pos.x - (c.ty * TILE + g.border),
                                pos.y - (c.tx * TILE + g.border));
-            r.pix[0] = px.x;
-            r.pix[1] = px.y;
-            r.pix[2] = px.z;
-            r.pix[3] = px.w;
+        } else if (t != INT_MIN) {
+            px = *reinterpret_cast<const float4 *>(deltas[-1 - t].pix);
         } else {
-            const float4 px = *reinterpret_cast<const float4 *>(deltas[-1 - t].pix);
-            r.pix[0] = px.x;
-            r.pix[1] = px.y;
-            r.pix[2] = px.z;
-            r.pix[3] = px.w;
+            px = *reinterpret_cast<const float4 *>(s.pix[tid]);
         }
-        next->rest[rank] = r;
+        r.pix[0] = px.x;
+        r.pix[1] = px.y;
+        r.pix[2] = px.z;
+        r.pix[3] = px.w;
+        next->top[rank] = r;
     }
+    // (an entry that is dropped is above everything that stays out)
+    if (k >= MC_REAL && rank == MC_TOP)
+        next->top_floor = k | 0x3ffu;
     if (k >= MC_REAL && rank == MC_REST)
         next->rest_floor = k | 0x3ffu;
     if (tid == 0) {
-        next->rest_n = nvalid < MC_REST ? nvalid : MC_REST;
+        next->top_n = nvalid < MC_TOP ? nvalid : MC_TOP;
+        if (nvalid <= MC_TOP)
+            next->top_floor = gathered;
         if (nvalid <= MC_REST)
-            next->rest_floor = floor_tau;
+            next->rest_floor = gathered;
+        next->tau = tau;
+        next->pad2 = 0;
     }
-    // where the filter stands for the next launch: some tens of tiles should pass
-    if (tid == 0 && (single || nvalid <= 40))
-        next->tau = !single && nvalid < 14 ? lower_tau(tau) : tau;
-    if (k >= MC_REAL && nvalid > 40 && rank == 28)
-        next->tau = (int) (k >> 32) - 1;
     MC_STAMP(10);
 }
 
 // ---- what every workgroup of a launch works out for itself --------------------------------------
 struct mc_lds {
     mkey_t row[16], row2[16];           // per 16 records: best key; best of the non-best
-    mkey_t plan[MC_MAX];                // the planned components' keys
-    float prev_pix[MC_MAX][4];          // pixel values of the previous plan's components
-    float new_pix[MC_MAX][4];           // ... of this launch's
-    int prev_lat[MC_MAX][2];            // lattice origins (tile coordinates) of the previous plan
-    int new_lat[MC_MAX][2];
-    int new_pos[MC_MAX][2];             // (y, x) of this launch's components
-    int prev_pos[MC_MAX][2];
+    float row_pix[16][4];               // pixel values of a row's best record
+    mc_record pool[MC_THREADS / 64][MC_POOL_REST];      // per wave: the list's surviving entries
     mkey_t keys[MC_THREADS / 64];       // block reduction of the pixel phase
 };
 
-constexpr int ROLE_KEEPER = 0, ROLE_FOLDER = 1, ROLE_NEW = 2, ROLE_COMMIT = 3;
+constexpr int ROLE_KEEPER = 0, ROLE_FOLDER = 1, ROLE_LISTER = 2, ROLE_NEW = 3, ROLE_COMMIT = 4;
 
 
 // One block of pixels: dirty (+ a pending subtraction, written back) (- a planned subtraction, in
@@ -598,14 +658,18 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
 {
     __shared__ mc_lds s;
     __shared__ rest_lds sr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = lane & 15;
-    // grid = (lat_x, lat_y, 1 + 2 mmax): plane 0 holds the two bookkeeping workgroups, planes
+    // Lanes: both halves of a wave do the same (l), and the candidate pool lives in the first row of
+    // sixteen lanes (e): every wave works the plan out for itself, so nothing about it has to pass
+    // through LDS or a barrier.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = lane & 31, e = lane & 15;
+    // grid = (lat_x, lat_y, 1 + 2 mmax): plane 0 holds the three bookkeeping workgroups, planes
     // 1 .. mmax the blocks of the planned lattices, the rest the blocks of the committed ones
     int role, comp = 0;
     if (blockIdx.z == 0) {
-        if (blockIdx.y != 0 || blockIdx.x > 1)
+        const int b = blockIdx.y * g.lat_x + blockIdx.x;
+        if (b > 2)
             return;
-        role = blockIdx.x == 0 ? ROLE_KEEPER : ROLE_FOLDER;
+        role = b == 0 ? ROLE_KEEPER : b == 1 ? ROLE_FOLDER : ROLE_LISTER;
     } else if ((int) blockIdx.z <= g.mmax) {
         role = ROLE_NEW;
         comp = blockIdx.z - 1;
@@ -619,8 +683,8 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
 #ifdef KIMG_MC_STAMPS
     long long *dbg = reinterpret_cast<long long *>(tile_pix + 4 * (size_t) g.tiles_x * g.tiles_y);
     const long long dbg_t0 = clock64();
-    const int dbg_row = role == ROLE_KEEPER ? 0 : (role == ROLE_NEW && comp == 0 && blockIdx.x == 0
-                                                    && blockIdx.y == 0) ? 1 : -1;
+    const int dbg_row = role == ROLE_KEEPER ? 0 : role == ROLE_LISTER ? 2
+                        : (role == ROLE_NEW && comp == 0 && blockIdx.x == 0 && blockIdx.y == 0) ? 1 : -1;
     long long dbg_v[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     MC_COUNT(16, 1);
 #else
@@ -637,12 +701,23 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     const mc_record *dp = &scratch->deltas[parity][tid];
     const int4 d0 = reinterpret_cast<const int4 *>(dp)[0];
     const int4 d1 = reinterpret_cast<const int4 *>(dp)[1];
-    const mc_record *pp = e < MC_MAX ? &cur->plan[e] : &cur->rest[e - MC_MAX];
+    // lane l < 8: component l of the previous plan; lane l >= 8: entry l - 8 of the list
+    const mc_record *pp = l < MC_MAX ? &cur->plan[l] : &cur->top[l - MC_MAX];
     const int4 p0 = reinterpret_cast<const int4 *>(pp)[0];
     const int4 p1 = reinterpret_cast<const int4 *>(pp)[1];
+    int4 old0 = make_int4(0, 0, 0, 0), old1 = old0, st4 = old0;
+    if (role == ROLE_LISTER) {
+        // the lister's own share of the round trip: its entry of the list, the list's floor
+        if (tid < MC_TOP) {
+            old0 = reinterpret_cast<const int4 *>(&cur->top[tid])[0];
+            old1 = reinterpret_cast<const int4 *>(&cur->top[tid])[1];
+        }
+        st4 = *reinterpret_cast<const int4 *>(&cur->top_floor);
+    }
     const int count0 = st.x, done = st.y, limit = st.z;
     const float threshold = __int_as_float(st.w);
-    const int Mp = st2.x, rest_n = st2.y, tau = st2.z;
+    const int Mp = st2.x, top_n = st2.y, tau = st2.z;
+    const int rest_n = min(top_n, MC_REST);
     if (done) {
         if (role == ROLE_KEEPER && tid == 0) {
             *reinterpret_cast<int4 *>(next) = st;
@@ -662,30 +737,35 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     const mkey_t dkey = live ? dkey_raw : 0;
     const float dpix[4] = {__int_as_float(d0.z), __int_as_float(d0.w), __int_as_float(d1.x),
                            __int_as_float(d1.y)};
-    const mkey_t pkey = ((mkey_t) (unsigned) p0.y << 32) | (unsigned) p0.x;    // plan[e] or rest[e - 8]
-    if (wave == 0 && lane < MC_MAX) {
-        s.prev_pix[lane][0] = __int_as_float(p0.z);
-        s.prev_pix[lane][1] = __int_as_float(p0.w);
-        s.prev_pix[lane][2] = __int_as_float(p1.x);
-        s.prev_pix[lane][3] = __int_as_float(p1.y);
-        const mc_cand c = mc_decode(pkey, g.border);
-        s.prev_lat[lane][0] = lat_origin(c.x, g.patch_w, g.border);
-        s.prev_lat[lane][1] = lat_origin(c.y, g.patch_h, g.border);
-        s.prev_pos[lane][0] = c.y;
-        s.prev_pos[lane][1] = c.x;
-    }
+    const mkey_t pkey = ((mkey_t) (unsigned) p0.y << 32) | (unsigned) p0.x;
+    const float ppix[4] = {__int_as_float(p0.z), __int_as_float(p0.w), __int_as_float(p1.x),
+                           __int_as_float(p1.y)};
+    // this lane's record as a candidate: its tile and the lattice of the component it would make
+    const mc_cand pc = mc_decode(pkey, g.border);
+    const int plx = lat_origin(pc.x, g.patch_w, g.border), ply = lat_origin(pc.y, g.patch_h, g.border);
     {
+        // first exchange: the best record of every 16, with its pixel values
         const mkey_t r = row_max(dkey);
-        if ((lane & 15) == 0)
+        if (e == 0)
             s.row[tid >> 4] = r;
+        if (dkey != 0 && dkey == r)
+            *reinterpret_cast<float4 *>(s.row_pix[tid >> 4]) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
     }
     lds_barrier();
     MC_STAMP(1);
 
     // ---- verify: the longest prefix of the previous plan that held ------------------------------
-    mkey_t a = 0;                       // lane e < 8: best record of lattice e
-    for (int r = 0; r < q; r++)
-        a = kmax(a, e < MC_MAX && e * q + r < 16 ? s.row[(e * q + r) & 15] : 0);
+    mkey_t a = 0;                       // lane e < 8: best record of lattice e ...
+    int arow = 0;
+    for (int r = 0; r < q; r++) {
+        const int row = e * q + r;
+        const mkey_t v = e < MC_MAX && row < 16 ? s.row[row & 15] : 0;
+        if (v > a) {
+            a = v;
+            arow = row;
+        }
+    }
+    const float4 apix = *reinterpret_cast<const float4 *>(s.row_pix[arow & 15]);   // ... and its pixel values
     mkey_t mine = 0;                    // best record of this thread's lattice
     for (int r = 0; r < q; r++)
         mine = kmax(mine, s.row[(li * q + r) & 15]);
@@ -696,7 +776,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         pre = kmax(pre, kdpp<0x112>(pre));          // row_shr:2
         pre = kmax(pre, kdpp<0x114>(pre));          // row_shr:4
         const mkey_t before = kdpp<0x111>(pre);     // lattices 0 .. e - 1
-        const bool ok = e < Mp && e < MC_MAX && (e == 0 || before < pkey);
+        const bool ok = lane < MC_MAX && lane < Mp && (lane == 0 || before < pkey);
         const unsigned held = (unsigned) __builtin_amdgcn_ballot_w64(ok) & 0xffu;
         j = __builtin_ctz(~held);       // leading run of ones
     }
@@ -713,49 +793,105 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         }
         return;
     }
+    if (role == ROLE_LISTER) {
+        // the list for the next launch, next to (not behind) everybody's planning
+        mc_build_rest(tile_max, tile_pos, tile_pix, scratch->deltas[parity], g, tau, 1,
+                      lane < j ? plx : INT_MIN / 2, lane < j ? ply : INT_MIN / 2, j,
+                      (live && li < j) ? dkey : 0, make_float4(dpix[0], dpix[1], dpix[2], dpix[3]), true,
+                      old0, old1, top_n,
+                      ((mkey_t) (unsigned) st4.y << 32) | (unsigned) st4.x, next, sr, dbg_v, dbg_t0);
+        MC_STAMP(11);
+        MC_FLUSH();
+        return;
+    }
     if (role == ROLE_COMMIT && comp >= j)
         return;
     {
         const mkey_t second = (live && li < j && dkey != mine) ? dkey : 0;
         const mkey_t r = row_max(second);
-        if ((lane & 15) == 0)
+        if (e == 0)
             s.row2[tid >> 4] = r;
     }
+    // (meanwhile) which entries of the list survive: those outside every lattice of the previous
+    // plan, committed or not -- their values stand; the first MC_POOL_REST of them enter the pool
+    const bool mispredicted = j < Mp;
+    bool surv = l >= MC_MAX && l - MC_MAX < rest_n && pkey >= MC_REAL && !mispredicted;
+#pragma unroll
+    for (int i = 0; i < MC_MAX; i++) {
+        const int rx = __builtin_amdgcn_readlane(plx, i), ry = __builtin_amdgcn_readlane(ply, i);
+        const bool inside = (unsigned) (pc.tx - rx) < (unsigned) g.lat_x
+                            && (unsigned) (pc.ty - ry) < (unsigned) g.lat_y;
+        surv = surv && !(inside && i < Mp);
+    }
+    const unsigned smask = (unsigned) __builtin_amdgcn_ballot_w64(surv);    // (lanes 0 .. 31)
+    const int srank = __builtin_popcount(smask & ((1u << l) - 1u));
+    if (lane < 32 && surv && srank < MC_POOL_REST) {
+        mc_record r;
+        r.key = pkey;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            r.pix[i] = ppix[i];
+        r.pad[0] = r.pad[1] = 0;
+        s.pool[wave][srank] = r;
+    }
+    mkey_t list_floor = rest_floor;     // every tile outside the pool and the last lattices is below
+    {
+        const unsigned ninth = (unsigned) __builtin_amdgcn_ballot_w64(surv && srank == MC_POOL_REST);
+        if (ninth)
+            list_floor = lane_key(pkey, __builtin_ctz(ninth)) | 0x3ffu;
+    }
+    const int nsurv = min(__builtin_popcount(smask), MC_POOL_REST);
     lds_barrier();
+    MC_STAMP(3);
 
     // ---- plan -------------------------------------------------------------------------------------
-    MC_STAMP(3);
-    const bool mispredicted = j < Mp;
     mkey_t bound;
     {
         const mkey_t r = row_max(s.row2[e]);
-        bound = kmax(lane_key(r, 0), rest_floor);
+        bound = kmax(lane_key(r, 0), list_floor);
     }
-    // the pool, one candidate per lane of a row: the committed lattices' best records and the list
-    // (after a misprediction: those records and the first component that was not committed, which
-    // was the best tile outside the committed lattices; exactly one component is then planned)
-    mkey_t cand;
-    if (e < MC_MAX)
+    // the pool, one candidate per lane of the first row: the committed lattices' best records and
+    // the surviving entries of the list (after a misprediction: those records and the first
+    // component that was not committed, which was the best tile outside the committed lattices;
+    // exactly one component is then planned)
+    mkey_t cand = 0;
+    float cpix[4] = {apix.x, apix.y, apix.z, apix.w};
+    if (e < MC_MAX) {
         cand = e < j ? a : 0;
-    else if (mispredicted)
-        cand = e == MC_MAX ? lane_key(pkey, j & 7) : 0;
-    else
-        cand = e - MC_MAX < rest_n ? pkey : 0;
+    } else if (mispredicted) {
+        if (e == MC_MAX) {
+            cand = lane_key(pkey, j & 7);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                cpix[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ppix[i]), j & 7));
+        }
+    } else if (e - MC_MAX < nsurv) {
+        const mc_record *r = &s.pool[wave][e - MC_MAX];
+        cand = r->key;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            cpix[i] = r->pix[i];
+    }
     if (cand < MC_REAL)
         cand = 1 + e;                   // distinct fillers below every real key
     const int rank = row_rank<1>(cand);
-    // sorted: lane p of the row gets the p-th largest
+    // sorted: lane p of the first row gets the p-th largest (the other rows keep their own)
+    const int to = (lane < 16 ? rank : lane) << 2;
     mkey_t sk;
+    float spix[4];
     {
-        const unsigned lo = __builtin_amdgcn_ds_permute(rank << 2, (int) (unsigned) cand);
-        const unsigned hi = __builtin_amdgcn_ds_permute(rank << 2, (int) (unsigned) (cand >> 32));
+        const unsigned lo = __builtin_amdgcn_ds_permute(to, (int) (unsigned) cand);
+        const unsigned hi = __builtin_amdgcn_ds_permute(to, (int) (unsigned) (cand >> 32));
         sk = ((mkey_t) hi << 32) | lo;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            spix[i] = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(cpix[i])));
     }
     const mc_cand c = mc_decode(sk, g.border);
     const int cbx = lat_origin(c.x, g.patch_w, g.border), cby = lat_origin(c.y, g.patch_h, g.border);
     // Everything the walk below needs, as masks over the sorted positions (bit p = candidate p):
     // per-candidate properties by one compare each, and per pivot k the candidates whose tile lies
-    // inside lattice k / whose lattice meets lattice k.  The walk itself is scalar.
+    // inside lattice k / whose lattice meets lattice k.  The walk itself is scalar and branch-free.
     const mkey_t overflow = lane_key(sk, MC_MAX);
     const mkey_t bound2 = kmax(bound, overflow >= MC_REAL ? overflow | 0x3ffu : 0);
     const unsigned m_real = (unsigned) __builtin_amdgcn_ballot_w64(sk >= MC_REAL) & 0xffu;
@@ -766,199 +902,158 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
 #pragma unroll
     for (int k = 0; k < MC_MAX; k++) {
         const int pbx = __builtin_amdgcn_readlane(cbx, k), pby = __builtin_amdgcn_readlane(cby, k);
-        m_ins[k] = (unsigned) __builtin_amdgcn_ballot_w64(
-            (unsigned) (c.tx - pbx) < (unsigned) g.lat_x && (unsigned) (c.ty - pby) < (unsigned) g.lat_y);
+        m_ins[k] = (unsigned) __builtin_amdgcn_ballot_w64((unsigned) (c.tx - pbx) < (unsigned) g.lat_x)
+                   & (unsigned) __builtin_amdgcn_ballot_w64((unsigned) (c.ty - pby) < (unsigned) g.lat_y);
         m_ovl[k] = (unsigned) __builtin_amdgcn_ballot_w64(
-            (unsigned) (cbx - pbx + g.lat_x - 1) < (unsigned) (2 * g.lat_x - 1)
-            && (unsigned) (cby - pby + g.lat_y - 1) < (unsigned) (2 * g.lat_y - 1));
+                       (unsigned) (cbx - pbx + g.lat_x - 1) < (unsigned) (2 * g.lat_x - 1))
+                   & (unsigned) __builtin_amdgcn_ballot_w64(
+                       (unsigned) (cby - pby + g.lat_y - 1) < (unsigned) (2 * g.lat_y - 1));
     }
-    unsigned picked = 0, skip = 0, stop = 0;
+    unsigned picked = 0;
     int M = 0;
-    bool done_now = false, zero_special = false;
+    bool done_now, zero_special;
     {
-        const int mcap = mispredicted ? 1 : g.mmax;
         // (the first candidate is the largest tile of the image if it beats every tile that is not
         // listed; with an entry of the list in the pool it does)
-        const bool first_proven = rest_n > 0 || mispredicted || lane_key(sk, 0) > rest_floor;
+        const bool first_proven = nsurv > 0 || mispredicted || lane_key(sk, 0) > list_floor;
+        const unsigned room = (unsigned) min(mispredicted ? 1 : g.mmax, limit - count);
+        // the walk considers the candidates in order while each is real, proven to be next (above
+        // everything outside the pool) and passes the threshold: a prefix of the positions
+        const unsigned elig = m_real & m_thr & (m_above | (first_proven ? 1u : 0u))
+                              & (limit > count ? 0xffu : 0u);
+        const unsigned pref = (1u << __builtin_ctz(~elig)) - 1u;       // its lowest run of ones
+        // clean.py:1065-1066: the loop ends when the largest tile of all fails threshold or limit
+        done_now = (m_real & 1u) && first_proven && !(elig & 1u);
+        unsigned skip = 0, stop = 0, alive = 1, zs = 0;
 #pragma unroll
         for (int p = 0; p < MC_MAX; p++) {
-            const unsigned bit = 1u << p;
-            if (!(m_real & bit))
-                break;
-            const bool first = M == 0;
-            if (first ? !first_proven : !(m_above & bit))
-                break;
-            if (!(m_thr & bit) || count + M >= limit) {         // clean.py:1065-1066
-                done_now = first;
-                break;
-            }
-            if (skip & bit)
-                continue;               // inside a planned lattice: its value is about to change
-            if (stop & bit)
-                break;
-            if (m_zero & bit) {
-                // its pixel is read from the image, which must be up to date
-                if (first && j == 0) {
-                    picked |= bit;
-                    M = 1;
-                    zero_special = true;
-                }
-                break;
-            }
-            picked |= bit;
-            skip |= m_ins[p];
-            stop |= m_ovl[p];
-            M++;
-            if (M == mcap)
-                break;
+            const unsigned c1 = (pref >> p) & alive;                        // candidate p is considered
+            const unsigned sk1 = (skip >> p) & 1u, st1 = (stop >> p) & 1u, z1 = (m_zero >> p) & 1u;
+            // a candidate inside a planned lattice is passed over (its value is about to change);
+            // one whose lattice meets a planned lattice ends the walk; one without any positive
+            // metric is taken only alone, and only while nothing is pending (its pixel is read
+            // from the image, which must be up to date)
+            const unsigned zero_ok = (p == 0 && j == 0) ? 1u : 0u;
+            const unsigned take = c1 & ~sk1 & ~st1 & (~z1 | zero_ok) & 1u;
+            picked |= take << p;
+            M += (int) take;
+            skip |= m_ins[p] & (0u - take);
+            stop |= m_ovl[p] & (0u - take);
+            zs |= take & z1;
+            const unsigned halt = (c1 & ~sk1 & (st1 | z1)) | (take & ((unsigned) M >= room ? 1u : 0u));
+            alive &= c1 & ~halt & 1u;
         }
+        zero_special = zs != 0;
         if (!(m_real & 1u) && j == 0 && rest_floor == 0)
             done_now = true;            // no tiles at all
     }
     MC_STAMP(4);
     MC_COUNT(17, M);
     MC_COUNT(18, j);
-    const int my_m = __builtin_popcount(picked & ((1u << (lane & 31)) - 1u));
-    if (wave == 0 && lane < MC_MAX && (picked >> lane & 1u)) {
-        s.plan[my_m] = sk;
-        s.new_lat[my_m][0] = cbx;
-        s.new_lat[my_m][1] = cby;
-        s.new_pos[my_m][0] = c.y;
-        s.new_pos[my_m][1] = c.x;
-    }
-    // the pixel values of the planned components: whoever holds a planned record says so
-    {
-        const mkey_t held = (live && li < j) ? dkey : 0;
-        // (after a misprediction lane 8 speaks for plan[j], whose pixel values lane j loaded)
-        const mkey_t held2 = wave == 0 && lane >= MC_MAX && lane < 2 * MC_MAX
-                                     && (mispredicted ? lane == MC_MAX : lane - MC_MAX < rest_n)
-                                 ? (mispredicted ? lane_key(pkey, j & 7) : pkey) : 0;
-        float h2[4] = {__int_as_float(p0.z), __int_as_float(p0.w), __int_as_float(p1.x), __int_as_float(p1.y)};
-        if (mispredicted) {
-#pragma unroll
-            for (int p = 0; p < 4; p++)
-                h2[p] = s.prev_pix[j & 7][p];
-        }
-#pragma unroll
-        for (int p = 0; p < MC_MAX; p++) {
-            const mkey_t kp = lane_key(sk, p);
-            const int m = __builtin_popcount(picked & ((1u << p) - 1u));
-            if ((picked >> p & 1u) && held == kp) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    s.new_pix[m][i] = dpix[i];
-            }
-            if ((picked >> p & 1u) && held2 == kp) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    s.new_pix[m][i] = h2[i];
-            }
-        }
-    }
-    lds_barrier();
-    MC_STAMP(5);
-    if (zero_special) {
-        // a tile without any positive metric won: its record holds the (x0, y0) start position of
-        // clean.py:950, whose pixel is read now (nothing is pending: the image is up to date)
-        if (tid < 4) {
-            const int py = s.new_pos[0][0], px = s.new_pos[0][1];
-            const bool ok = py >= 0 && py < g.height && px >= 0 && px < g.width && tid < g.P;
-            s.new_pix[0][tid] = ok ? dirty[tid * g.pol_stride + (int64_t) py * g.row_stride + px] : 0.0f;
-        }
-        lds_barrier();
-    }
+    // the sorted position of planned component m: the m-th set bit of `picked`
+    auto position = [&](int m) {
+        unsigned x = picked;
+        for (int i = 0; i < m; i++)
+            x &= x - 1u;
+        return __builtin_ctz(x | 0x100u);
+    };
+    auto lane_int = [&](int v, int from) { return __builtin_amdgcn_readlane(v, from); };
+    auto lane_float = [&](float v, int from) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
+    };
 
     if (role == ROLE_NEW) {
         if (comp >= M)
             return;
-        const int tx = s.new_lat[comp][0] + (int) blockIdx.x, ty = s.new_lat[comp][1] + (int) blockIdx.y;
-        int pend = -1;
-        for (int i = 0; i < j; i++)
-            if ((unsigned) (tx - s.prev_lat[i][0]) < (unsigned) g.lat_x
-                && (unsigned) (ty - s.prev_lat[i][1]) < (unsigned) g.lat_y)
-                pend = i;
-        float ps[4], ns[4];
+        const int p = position(comp);
+        const int ny = lane_int(c.y, p), nx = lane_int(c.x, p);
+        const int tx = lane_int(cbx, p) + (int) blockIdx.x, ty = lane_int(cby, p) + (int) blockIdx.y;
+        float ns[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            ps[p] = g.loop_gain * s.prev_pix[pend < 0 ? 0 : pend][p];      // clean.py:1044
-            ns[p] = g.loop_gain * s.new_pix[comp][p];
+        for (int i = 0; i < 4; i++)
+            ns[i] = lane_float(spix[i], p);
+        if (zero_special) {
+            // a tile without any positive metric won: its record holds the (x0, y0) start position
+            // of clean.py:950, whose pixel is read now (nothing is pending: the image is up to date)
+            const bool ok = ny >= 0 && ny < g.height && nx >= 0 && nx < g.width;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                ns[i] = ok && i < g.P ? dirty[i * g.pol_stride + (int64_t) ny * g.row_stride + nx] : 0.0f;
         }
-        mc_block<MODE>(dirty, psf, g, tx, ty, pend >= 0, s.prev_pos[pend < 0 ? 0 : pend][0],
-                       s.prev_pos[pend < 0 ? 0 : pend][1], ps, true, s.new_pos[comp][0],
-                       s.new_pos[comp][1], ns,
-                       &scratch->deltas[parity ^ 1][comp * g.seg + (int) blockIdx.y * g.lat_x + (int) blockIdx.x], s,
-                       dbg_v, dbg_t0);
+        // the pending subtraction of a committed lattice that holds this block, if any
+        const unsigned hit = (unsigned) __builtin_amdgcn_ballot_w64(
+            lane < j && (unsigned) (tx - plx) < (unsigned) g.lat_x && (unsigned) (ty - ply) < (unsigned) g.lat_y);
+        const int pend = hit ? __builtin_ctz(hit) : 0;
+        float ps[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ps[i] = g.loop_gain * lane_float(ppix[i], pend);              // clean.py:1044
+            ns[i] = g.loop_gain * ns[i];
+        }
+        MC_STAMP(5);
+        mc_block<MODE>(dirty, psf, g, tx, ty, hit != 0, lane_int(pc.y, pend), lane_int(pc.x, pend), ps,
+                       true, ny, nx, ns,
+                       &scratch->deltas[parity ^ 1][comp * g.seg + (int) blockIdx.y * g.lat_x + (int) blockIdx.x],
+                       s, dbg_v, dbg_t0);
         MC_FLUSH();
         return;
     }
     if (role == ROLE_COMMIT) {
-        const int tx = s.prev_lat[comp][0] + (int) blockIdx.x, ty = s.prev_lat[comp][1] + (int) blockIdx.y;
-        for (int m = 0; m < M; m++)
-            if ((unsigned) (tx - s.new_lat[m][0]) < (unsigned) g.lat_x
-                && (unsigned) (ty - s.new_lat[m][1]) < (unsigned) g.lat_y)
-                return;                 // a workgroup of the new lattice writes this block
+        const int tx = lane_int(plx, comp) + (int) blockIdx.x, ty = lane_int(ply, comp) + (int) blockIdx.y;
+        const unsigned covered = (unsigned) __builtin_amdgcn_ballot_w64(
+            lane < MC_MAX && (picked >> lane & 1u) && (unsigned) (tx - cbx) < (unsigned) g.lat_x
+            && (unsigned) (ty - cby) < (unsigned) g.lat_y);
+        if (covered)
+            return;                     // a workgroup of the new lattice writes this block
         float ps[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-            ps[p] = g.loop_gain * s.prev_pix[comp][p];
-        mc_block<MODE>(dirty, psf, g, tx, ty, true, s.prev_pos[comp][0], s.prev_pos[comp][1], ps, false,
+        for (int i = 0; i < 4; i++)
+            ps[i] = g.loop_gain * lane_float(ppix[i], comp);
+        mc_block<MODE>(dirty, psf, g, tx, ty, true, lane_int(pc.y, comp), lane_int(pc.x, comp), ps, false,
                        0, 0, ps, nullptr, s, dbg_v, dbg_t0);
         return;
     }
 
-    // ---- keeper: the committed components, the next state, the list for the next launch ---------
+    // ---- keeper: the committed components, the planned ones, the next state -------------------------
     if (tid < j) {
-        const int py = s.prev_pos[tid][0], px = s.prev_pos[tid][1];
+        // (lane tid of wave 0 holds component tid of the previous plan)
         float *entry = log + (int64_t) (count0 + tid) * (3 + g.P);
-        entry[0] = __uint_as_float((unsigned) (pkey >> 32));    // (lane tid of wave 0 holds plan[tid])
-        entry[1] = __int_as_float(py);
-        entry[2] = __int_as_float(px);
+        entry[0] = pc.value;
+        entry[1] = __int_as_float(pc.y);
+        entry[2] = __int_as_float(pc.x);
         for (int p = 0; p < g.P; p++) {
-            const float sc = g.loop_gain * s.prev_pix[tid][p];
-            float *mp = model + p * g.pol_stride + (int64_t) py * g.row_stride + px;
+            const float sc = g.loop_gain * ppix[p];
+            float *mp = model + p * g.pol_stride + (int64_t) pc.y * g.row_stride + pc.x;
             entry[3 + p] = sc;
             *mp += sc;                                          // clean.py:1047
         }
     }
-    if (tid < M) {
+    if (tid < MC_MAX && (picked >> tid & 1u)) {
+        // (lane p of wave 0 holds the candidate at sorted position p)
         mc_record r;
-        r.key = s.plan[tid];
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-            r.pix[p] = s.new_pix[tid][p];
+        r.key = sk;
         r.pad[0] = r.pad[1] = 0;
-        next->plan[tid] = r;
+        const bool ok = c.y >= 0 && c.y < g.height && c.x >= 0 && c.x < g.width;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            r.pix[i] = spix[i];
+            if (zero_special)
+                r.pix[i] = ok && i < g.P ? dirty[i * g.pol_stride + (int64_t) c.y * g.row_stride + c.x] : 0.0f;
+        }
+        next->plan[__builtin_popcount(picked & ((1u << tid) - 1u))] = r;
     }
     if (tid == 0) {
         *reinterpret_cast<int4 *>(next) = make_int4(count, done_now ? 1 : 0, limit, st.w);
         next->planned = M;
         next->launches = st2.w + 1;
         next->gen = gen;
+        // (what the host reads goes out last: the word in host memory is a long way off)
+        *reinterpret_cast<int4 *>(scratch->head) = make_int4(count, done_now ? 1 : 0, limit, st.w);
+        if (progress)
+            __hip_atomic_store(progress, progress_word(st2.w + 1, gen, done_now, count),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // (what the host reads goes out last: the word in host memory is a long way off, and the
-    // barriers of the list below would wait for it)
-    auto finish = [&]() {
-        if (tid == 0) {
-            *reinterpret_cast<int4 *>(scratch->head) = make_int4(count, done_now ? 1 : 0, limit, st.w);
-            if (progress)
-                __hip_atomic_store(progress, progress_word(st2.w + 1, gen, done_now, count),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    };
     MC_STAMP(6);
-    if (done_now) {
-        if (tid == 0) {
-            next->rest_n = 0;
-            next->tau = tau;
-            next->rest_floor = 0;
-        }
-        finish();
-        return;
-    }
-    mc_build_rest(tile_max, tile_pos, tile_pix, scratch->deltas[parity], g, tau, 1, s.prev_lat, j,
-                  s.new_lat, M, (live && li < j) ? dkey : 0, next, sr, dbg_v, dbg_t0);
-    finish();
-    MC_STAMP(11);
     MC_FLUSH();
 }
 
@@ -1014,8 +1109,8 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
 #else
     long long *dbg_v = nullptr;
 #endif
-    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), 32, nullptr, 0, nullptr,
-                  0, 0, st, sr, dbg_v, 0);
+    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), MC_TOP, INT_MIN / 2,
+                  INT_MIN / 2, 0, 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), false, make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), 0, 0, st, sr, dbg_v, 0);
 }
 
 // ---- host --------------------------------------------------------------------------------------
@@ -1195,7 +1290,8 @@ int kimg_clean_multi_components(int patch_width, int patch_height, int tiles_x, 
 {
     const int lat_x = kimg_divup(patch_width, TILE) + 1, lat_y = kimg_divup(patch_height, TILE) + 1;
     const int64_t nb = (int64_t) lat_x * lat_y;
-    if (nb > MC_THREADS || tiles_x > MC_MAX_TILES || tiles_y > MC_MAX_TILES)
+    if (nb > MC_THREADS || tiles_x > MC_MAX_TILES || tiles_y > MC_MAX_TILES
+        || (int64_t) tiles_x * tiles_y < 4)         // (the list's scan reads the tile maxima four at a time)
         return 0;
     int seg = 16;
     while (seg < nb)
@@ -1206,7 +1302,7 @@ int kimg_clean_multi_components(int patch_width, int patch_height, int tiles_x, 
 
 size_t kimg_clean_multi_state_bytes(int tiles_x, int tiles_y)
 {
-    return sizeof(mc_scratch) + (size_t) tiles_x * tiles_y * 4 * sizeof(float) + 1024;     // (+ stamps of a test build)
+    return sizeof(mc_scratch) + (size_t) tiles_x * tiles_y * 4 * sizeof(float) + 1024;     // (+ stamps of a test build: 3 rows of 32 words)
 }
 
 // The loop of kimg_clean_cycles in this form.  Unlike the other forms it is HOST-PACED: how many

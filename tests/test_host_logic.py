@@ -788,6 +788,17 @@ def test_clean_batcher_rendezvous(monkeypatch):
     assert out == {n: [('batched', n)] for n in 'xyz'}
     assert [k for k, _ in launched] == ['batch'] and sorted(launched[0][1]) == list('xyz')
     assert b.batches == [(3, 100)]
+    # channels whose patch lets a launch plan several components run on their own
+    launched.clear()
+    monkeypatch.setattr(clean, 'prefers_solo', lambda c, patch, cycles: c.name in 'xyz')
+    b5 = clean.CleanBatcher(5, timeout=5.0)
+    out = run(b5, [(FakeClean(n), small, 0.0, 100) for n in 'pqxyz'])
+    # (p and q still share their launches)
+    assert sorted(k for k, _ in launched) == ['batch', 'solo', 'solo', 'solo']
+    assert sorted(n for k, n in launched if k == 'solo') == list('xyz')
+    assert [sorted(n) for k, n in launched if k == 'batch'] == [['p', 'q']] and b5.batches == [(2, 100)]
+    assert out == {n: [('solo' if n in 'xyz' else 'batched', n)] for n in 'pqxyz'}
+    monkeypatch.setattr(clean, 'prefers_solo', lambda c, patch, cycles: False)
     # a large patch and a different image shape go alone; the two compatible ones share
     launched.clear()
     items = [(FakeClean('p'), small, 0.0, 10), (FakeClean('q'), (1, 711, 675), 0.0, 10),

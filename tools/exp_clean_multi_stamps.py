@@ -48,20 +48,20 @@ for rep in range(3):
     q.finish()
     dt = time.perf_counter() - t0
 tiles = op.buffer('tile_max').shape
-offset = (17568 + tiles[0] * tiles[1] * 16) // 4
-raw = op._state.get(q)[offset:offset + 128].view(np.int64).reshape(2, 32)
+offset = (64 + 2 * 4416 + 2 * 256 * 32 + tiles[0] * tiles[1] * 16) // 4
+raw = op._state.get(q)[offset:offset + 192].view(np.int64).reshape(3, 32)
 launches = op.last_launches()
 print('%d components in %d launches, %.1f us per launch, %.0f cycles/s' % (
     len(got), launches, dt / launches * 1e6, len(got) / dt))
 names = {0: 'start', 1: 'records + first exchange', 2: 'verified', 3: 'second exchange', 4: 'planned',
-         5: 'pixel values exchanged', 6: 'K: state written / L: pixels loaded', 7: 'L: record stored',
-         8: 'K: first scan done', 9: 'K: list complete', 10: 'K: sorted + stored', 11: 'K: end'}
-for row, label in ((0, 'K'), (1, 'L')):
+         5: 'B: component extracted', 6: 'K: state written / B: pixels loaded', 7: 'B: record stored',
+         12: 'L: old list merged', 13: 'L: tiles filtered (scan)', 8: 'L: first scan done', 9: 'L: list complete', 10: 'L: sorted + stored', 11: 'L: end'}
+for row, label in ((0, 'K (keeper)'), (1, 'B (block (0, 0) of the first planned lattice)'), (2, 'L (lister)')):
     n = raw[row][16]
     if n == 0:
         continue
-    print('%s: %d workgroups; planned %.2f, committed %.2f per launch; scans per launch %.2f, listed %.1f' % (
-        label, n, raw[row][17] / n, raw[row][18] / n, raw[row][15] / n, raw[row][14] / max(n, 1)))
-    for i in sorted(names):
+    print('%s: %d workgroups; planned %.2f, committed %.2f per launch; scans per launch %.2f (in %.2f of the launches), listed %.1f' % (
+        label, n, raw[row][17] / n, raw[row][18] / n, raw[row][15] / n, raw[row][19] / n, raw[row][14] / max(n, 1)))
+    for i in (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 8, 9, 10, 11):
         if raw[row][i]:
             print('   %-40s %8.0f cycles' % (names[i], raw[row][i] / n))
