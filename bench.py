@@ -70,13 +70,20 @@ def parse_args():
     p.add_argument('--extras', action='store_true',
                    help='also: preprocessing + store-driven driver, several channels in flight, '
                         'host-chunk (PCIe-inclusive) gridding')
-    p.add_argument('--traffic-json', default=None,
+    p.add_argument('--traffic-json',
+                   default=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                        'gridder_traffic_fp32.json'),
                    help='HBM bytes per launch from a rocprofv3 --pmc pass of this same command '
-                        '(tools/profile_round.sh); included as roofline.traffic only if its '
-                        'recorded configuration matches this run')
+                        '(tools/profile_round.sh; default: the committed pass of the current '
+                        'kernel); included as roofline.traffic only if its recorded configuration '
+                        'matches this run')
     p.add_argument('--roctx', action='store_true',
                    help='named roctx ranges around the stages of the major-cycle loop '
                         '(rocprofv3 --marker-trace)')
+    p.add_argument('--force-dist', action='store_true',
+                   help='take the distributed code path (RCCL process group, broadcast, '
+                        'gathers, barriers) also with ONE rank: how that path is exercised on a '
+                        'one-GPU box')
     p.add_argument('--rehearse', action='store_true',
                    help='CPU rehearsal of the multi-process plumbing (rendezvous, broadcast, channel '
                         'assignment, barriers, reductions, the JSON line) with no device work; for '
@@ -177,9 +184,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    if distributed:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
+        if 'MASTER_ADDR' not in os.environ:         # (--force-dist without a launcher)
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(parallel.free_port()),
+                              RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
         raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch with torchrun'.format(
@@ -188,7 +199,7 @@ def main():
     ctx = accel.Context(local_rank)
     q = ctx.create_command_queue()
     dev = ctx.device
-    if world > 1:
+    if distributed:
         # one process per GPU, every rank on its own device (one node: LOCAL_RANK = device index)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
         rank_devices = parallel.check_rank_devices(torch.cuda.current_device(), dev)
@@ -197,25 +208,42 @@ def main():
     P, K, W, G = args.polarizations, args.kernel_width, args.w_planes, args.pixels
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier(device_ids=[local_rank])
 
-    # ---- shared tables: computed on rank 0, broadcast over RCCL/xGMI -------
-    t_bcast = 0.0
-    shared = {'baselines': torch.from_numpy(synth.baselines_equatorial()).to(dev) if rank == 0
-              else torch.empty((2016, 3), dtype=torch.float64, device=dev)}
-    if world > 1:
+    # ---- the channel-independent inputs: made on rank 0, broadcast over RCCL / xGMI (SURVEY 8e:
+    # UVW in metres float32 [N][3] -- 0.6 GB for 50 M visibilities -- and the image taper); every
+    # rank then quantises the tracks for its own channel's cell size --------------------------------
+    t_bcast, bcast_bytes = 0.0, 0
+    uvw = None
+    if distributed:
+        # (ConvolutionKernel.taper, grid.py:404-423: it depends on the anti-aliasing width and the
+        # oversampling only, not on the channel)
+        xs = np.arange(G) / G - 0.5
+        taper = (grid.kaiser_bessel_fourier(xs, 7.0, grid.antialias_beta(7.0))
+                 * np.sinc(xs / 8)).astype(np.float32) if rank == 0 else None
+        shared = {
+            'uvw': synth.track_uvw(args.vis, dev) if rank == 0
+            else torch.empty((args.vis, 3), dtype=torch.float32, device=dev),
+            'taper1d': torch.from_numpy(taper).to(dev) if rank == 0
+            else torch.empty((G,), dtype=torch.float32, device=dev)}
+        check = float(shared['uvw'][::9973].double().sum()) if rank == 0 else 0.0
         torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         parallel.broadcast_shared(shared, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-        assert torch.equal(shared['baselines'].cpu(), torch.from_numpy(synth.baselines_equatorial()))
+        bcast_bytes = sum(t.numel() * t.element_size() for t in shared.values())
+        # (every rank holds rank 0's bytes: the gathered spot checksums agree)
+        sums = parallel.gather_stats([float(shared['uvw'][::9973].double().sum())], dev)[:, 0].tolist()
+        assert all(x == sums[0] for x in sums) and (rank != 0 or sums[0] == check), sums
+        uvw = shared['uvw']
 
     # ---- this rank's channel -------------------------------------------------------------
     channel = rank_channel(rank, world)
     obs = synth.make_observation(G, args.vis, W, P, device=dev, cover=0.30,
-                                 channel_scale=channel_scale(channel), seed=2 + rank)
+                                 channel_scale=channel_scale(channel), seed=2 + rank, uvw=uvw)
     ip, gp, ap = synth.make_parameters(obs, P, K)
     n_vis = obs.n_vis
     vb = args.vis_block
@@ -300,7 +328,7 @@ def main():
     # every rank's own numbers, so that the first multi-GPU run localises a slow rank
     per_rank = parallel.gather_stats(
         [float(channel), timer.local_sec_per_step * 1e3, kern_ms, roofline['frac'],
-         float(torch.cuda.current_device())], dev if world > 1 else 'cpu')
+         float(torch.cuda.current_device())], dev if distributed else 'cpu')
     traffic = load_traffic(args, roofline)
     if traffic is not None:
         roofline['traffic'] = traffic
@@ -317,7 +345,9 @@ def main():
         'config': {'workload': workload, 'grid_size': Gg, 'channels': world,
                    'band_channel_of_rank0': channel, 'parallelism': 'channel-sharded',
                    'window_jump_fraction': round(jump_fraction, 5),
-                   'broadcast_ms': round(t_bcast * 1e3, 3)},
+                   'broadcast_ms': round(t_bcast * 1e3, 3), 'broadcast_MB': round(bcast_bytes / 1e6, 1),
+                   'broadcast_GBps': round(bcast_bytes / t_bcast / 1e9, 1) if t_bcast > 0 else None,
+                   'process_group': 'nccl (RCCL), {} rank(s)'.format(world) if distributed else None},
         'roofline': roofline,
         'per_rank': [{'rank': r, 'band_channel': int(row[0]), 'ms_per_step': round(row[1], 3),
                       'kernel_ms': round(row[2], 3), 'roofline_frac': round(row[3], 4),
@@ -394,7 +424,7 @@ def main():
     barrier()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
@@ -519,19 +549,20 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     pp.bind(psf=cl.buffer('psf'))
     patch = pp(cp.psf_cutoff, cp.psf_limit)
 
-    def clean_rate(patch_, per_cycle=False):
-        cl.buffer('dirty').set(q, sky)
-        cl.buffer('model').zero(q)
-        cl.reset()
+    def clean_rate(patch_, per_cycle=False, op=None):
+        op = op or cl
+        op.buffer('dirty').set(q, sky)
+        op.buffer('model').zero(q)
+        op.reset()
         n = min(args.clean_cycles, 200) if per_cycle else args.clean_cycles
         q.finish()
         t0 = time.perf_counter()
         if not per_cycle:
-            done = len(cl.run_cycles(patch_, 0.0, n))
+            done = len(op.run_cycles(patch_, 0.0, n))
         else:
             done = 0
             for _ in range(n):
-                v, p_, m = cl(patch_, 0.0)
+                v, p_, m = op(patch_, 0.0)
                 done += v is not None
         q.finish()
         return done / (time.perf_counter() - t0)
@@ -546,12 +577,24 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
         'small_patch': list(small),
         'small_patch_cycles_per_s': round(clean_rate(small), 1),
         'per_cycle_host_sync_cycles_per_s': round(clean_rate(patch, per_cycle=True), 1),
-        # latency budget of a cycle (dependent chain; DESIGN.md "CLEAN cycle latency"): graph
-        # node-to-node 2.1 us, cold first load 1.0, peak search 0.9, winner record 0.3, block
-        # pixels 0.45, subtract + rescan + stores 1.1
-        'bound': 'latency', 'budget_us_one_launch_cycle': 5.85,
+        # a launch is a latency chain: kernel boundary ~2 us + 6 us of dependent
+        # steps, whatever it commits; the multi-component form commits up to 8 components with it
+        'bound': 'latency',
     }
     out['clean']['small_patch_us_per_cycle'] = round(1e6 / out['clean']['small_patch_cycles_per_s'], 2)
+    launches = cl.last_launches()
+    if launches:
+        out['clean']['small_patch_launches'] = launches
+        out['clean']['small_patch_components_per_launch'] = round(args.clean_cycles / launches, 2)
+        out['clean']['small_patch_us_per_launch'] = round(
+            1e6 * args.clean_cycles / out['clean']['small_patch_cycles_per_s'] / launches, 2)
+    # the same loop with one component per launch (the form of rounds 2-3), for comparison
+    one = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'one_launch'}).instantiate(q, ip)
+    one.bind(**{name: cl.buffer(name) for name in ('dirty', 'model', 'psf', 'tile_max', 'tile_pos')})
+    one.ensure_all_bound()
+    clean_rate(small, op=one)
+    out['clean']['small_patch_one_component_per_launch_cycles_per_s'] = round(clean_rate(small, op=one), 1)
+    del one
     # several channels per launch (kimg_clean_cycles_batch: cycle i of C channels in ONE launch, the
     # kernel boundary is paid once): aggregate minor cycles per second over C channels of a band,
     # each with its own dirty image (the same sky at another amplitude and noise), same PSF patch

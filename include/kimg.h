@@ -107,6 +107,11 @@ const char *kimg_error_string(int code);
  * 16.1 instead of 15.6.  No counterpart in the reference (its kernels are not resident). */
 int kimg_set_window_cus(int cus);
 int kimg_get_window_cus(void);
+/* The same PER CALL, which is what callers should use (the process-wide setting above is kept as
+ * the default for calls that bring none, and is deprecated: two imagers of one process with
+ * different needs would race on it): `variant | KIMG_WINDOW_CUS(n)` in the `variant` argument of
+ * kimg_grid / kimg_degrid, n = 1 .. 256; 0 = the default. */
+#define KIMG_WINDOW_CUS(n) ((n) << 8)
 
 /* ---- convolution kernel table: grid.py:235-334 antialias_w_kernel, as called for every W plane
  * by ConvolutionKernel.__init__ (grid.py:358-389), evaluated on the device in float64.

@@ -711,6 +711,7 @@ class CleanBatcher:
                 e['ready'] = True       # (runs in its own thread, next to the batches)
         self._cond.notify_all()
         self._cond.release()
+        finished = []
         try:
             for part in parts:
                 try:
@@ -724,15 +725,22 @@ class CleanBatcher:
                 except Exception as exc:        # noqa: B902 -- handed to the threads concerned
                     for e in part:
                         e['error'] = exc
+                finished.append(part)
         finally:
+            # (also when the leader is interrupted -- KeyboardInterrupt, SystemExit: the threads
+            # whose entries it took over are no longer waiting in the list and would never be
+            # woken; they get an error instead and the count of running channels stays right)
             self._cond.acquire()
-        for part in parts:
-            if 'batch' in part[0]:
-                self.batches.append(part[0]['batch'])
-            self._cleaning -= len(part)
-            for e in part:
-                e['ready'] = True
-        self._cond.notify_all()
+            for part in parts:
+                if not any(part is f for f in finished):
+                    for e in part:
+                        e['error'] = e['error'] or RuntimeError('the CLEAN batch was interrupted')
+                if 'batch' in part[0]:
+                    self.batches.append(part[0]['batch'])
+                self._cleaning -= len(part)
+                for e in part:
+                    e['ready'] = True
+            self._cond.notify_all()
 
     def run_cycles(self, clean, psf_patch, threshold, max_cycles, arrays=False):
         """``clean.run_cycles(psf_patch, threshold, max_cycles)``, sharing its launches with the

@@ -6,10 +6,23 @@
 extern "C" int kimg_version(void) { return KIMG_VERSION; }
 
 namespace {
-std::atomic<int> window_cus{256};
+std::atomic<int> window_cus{256};       // the process default (kimg_set_window_cus: deprecated)
+thread_local int window_cus_call = 0;   // the value of the kimg_grid / kimg_degrid call in progress
 }
 
-int kimg_window_cus_now() { return window_cus.load(std::memory_order_relaxed); }
+// What the window kernels of the call in progress on this thread may fill: the call's own value
+// (bits 8-16 of its `variant` argument) if it brought one, else the process default.
+int kimg_window_cus_now()
+{
+    return window_cus_call > 0 ? window_cus_call : window_cus.load(std::memory_order_relaxed);
+}
+
+kimg_window_cus_scope::kimg_window_cus_scope(int cus) : before(window_cus_call)
+{
+    window_cus_call = cus > 0 ? cus : before;
+}
+
+kimg_window_cus_scope::~kimg_window_cus_scope() { window_cus_call = before; }
 
 extern "C" int kimg_set_window_cus(int cus)
 {

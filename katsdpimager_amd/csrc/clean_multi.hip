@@ -315,8 +315,10 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
         // (too many to rank, which 64 + 254 allow in principle, or too few left: scan)
         scan = na > MC_CAP || (na < MC_LOW && old_floor != 0);
         if (scan) {
+            // (about 0.7 of the floor so far; the first answer with enough entries to last a while is
+            // taken: every attempt is a pass over the tile maxima)
             tau = lower_tau(tau);
-            nmin = MC_TOP;
+            nmin = MC_TOP / 2;
         }
     }
     for (int attempt = 0; scan && attempt < 100; attempt++) {
@@ -1139,7 +1141,7 @@ int enqueue_launch(const multi_args &a, hipStream_t s, int parity)
 }
 
 // hipGraphs of MULTI_GRAPH launches, cached per argument set (as cycles_graph in clean.hip)
-constexpr int MULTI_GRAPH = 8;
+constexpr int MULTI_GRAPH = 16;
 static_assert(MULTI_GRAPH % 2 == 0, "launches alternate two state buffers");
 constexpr int MULTI_CACHE = 32;
 

@@ -278,6 +278,9 @@ extern "C" int kimg_grid(void *grid, int64_t grid_row_stride, int64_t grid_pol_s
 {
     KIMG_CHECK_ARG(grid && weights_grid && uv && w_plane && vis && convolve_kernel);
     KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
+    KIMG_CHECK_ARG(variant >= 0 && (variant >> 8) <= 256);
+    const kimg_window_cus_scope cus(variant >> 8);      // KIMG_WINDOW_CUS(n): this call's share of the CUs
+    variant &= 0xff;
     KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
                    || variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,
@@ -337,6 +340,9 @@ extern "C" int kimg_degrid(const void *grid, int64_t grid_row_stride, int64_t gr
 {
     KIMG_CHECK_ARG(grid && uv && w_plane && weights && vis && convolve_kernel);
     KIMG_CHECK_ARG(arith == KIMG_ARITH_FP32 || arith == KIMG_ARITH_SPLIT_FP16);
+    KIMG_CHECK_ARG(variant >= 0 && (variant >> 8) <= 256);
+    const kimg_window_cus_scope cus(variant >> 8);
+    variant &= 0xff;
     KIMG_CHECK_ARG(variant == KIMG_VARIANT_AUTO || variant == KIMG_VARIANT_GENERIC
                    || variant == KIMG_VARIANT_MFMA || variant == KIMG_VARIANT_BINNED);
     int rc = check_grid_args(grid_size, num_polarizations, num_vis, w_planes, oversample,

@@ -20,6 +20,12 @@ static inline int kimg_divup(int64_t a, int64_t b) { return (int) ((a + b - 1) /
 // CUs the window kernels (gridder, degridder) may fill with their resident workgroups
 // (kimg_set_window_cus; api.hip)
 int kimg_window_cus_now();
+// (set for the duration of one kimg_grid / kimg_degrid call, on the calling thread)
+struct kimg_window_cus_scope {
+    explicit kimg_window_cus_scope(int cus);
+    ~kimg_window_cus_scope();
+    int before;
+};
 
 // The multi-component form of the CLEAN loop (clean_multi.hip), reached through kimg_clean_cycles
 int kimg_clean_multi_components(int patch_width, int patch_height, int tiles_x, int tiles_y);

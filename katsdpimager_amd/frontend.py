@@ -256,7 +256,7 @@ WINDOW_CUS_SHARED = 192
 
 
 def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stagger=None,
-                           window_cus=None):
+                           window_cus=None, device=None):
     """Image ``channels`` (any number) with at most ``workers`` of them in flight AND in memory.
 
     :func:`process_channels` takes ready-made jobs, i.e. one imager per channel; a band of
@@ -269,9 +269,13 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
     the channels in flight share their launches (see :func:`process_channels`).  ``stagger``: the
     channels in flight take turns at their throughput-bound stages (``clean.CleanBatcher``
     ``phased``) so that one channel grids while the others CLEAN; None = on for up to four
-    channels in flight.  ``window_cus``: how many CUs the gridder and degridder fill while several
-    channels are in flight (``kimg_set_window_cus``; None = 192 of 256, so that the other
-    channels' CLEAN launches find room).  Returns the results in ``channels`` order.
+    channels in flight.  ``window_cus``: how many CUs the gridder and degridder of the imagers in
+    flight fill while there are several (``Imaging.set_window_cus``: it travels with every
+    kimg_grid / kimg_degrid call of those imagers, so two streams in one process -- on the same or
+    on different GPUs -- do not see each other's setting; None = 192 of 256, so that the other
+    channels' CLEAN launches find room).  ``device``: the GPU the jobs are made on (an imager built
+    lazily inside ``make_job`` must find its device current in the worker thread, where HIP starts
+    on device 0); None = the caller's current device.  Returns the results in ``channels`` order.
     """
     import inspect
     import queue
@@ -287,6 +291,15 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
     for item in enumerate(channels):
         todo.put(item)
     count = max(1, min(int(workers), len(channels)))
+    if device is None:
+        try:
+            import torch
+            device = torch.cuda.current_device() if torch.cuda.is_available() else None
+        except Exception:       # noqa: B902 -- no GPU runtime: nothing to make current
+            device = None
+    if window_cus is None:
+        window_cus = WINDOW_CUS_SHARED
+    shared_cus = int(window_cus) if count > 1 else 0
     batcher = None
     if batch_clean and count > 1:
         if stagger is None:
@@ -295,6 +308,31 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
             stagger = count <= 4
         batcher = clean.CleanBatcher(count, phased=bool(stagger))
 
+    def one(index, channel, worker):
+        job = make_job(channel, worker) if takes_worker else make_job(channel)
+        kwargs = dict(job)          # (the caller's dict is left as it is)
+        if batcher is not None and kwargs.get('batched_clean', True):
+            kwargs.setdefault('clean_batcher', batcher)
+        imager = kwargs.get('imager')
+        restore = None
+        if imager is not None and hasattr(imager, 'set_window_cus'):
+            # The gridder's and degridder's workgroups stay on their CUs for a whole launch and
+            # leave no room for another channel's CLEAN workgroups, whose chain of launches then
+            # stands still: with several channels in flight those kernels keep off a quarter of
+            # the device (7.2 -> 6.1 ms per channel with four in flight).
+            restore = getattr(imager, '_window_cus', 0)
+            imager.set_window_cus(shared_cus)
+        try:
+            if imager is not None and hasattr(imager, 'command_queue'):
+                import torch
+                with torch.cuda.device(imager.command_queue.context.device):
+                    results[index] = process_channel(**kwargs)
+            else:
+                results[index] = process_channel(**kwargs)
+        finally:
+            if restore is not None:
+                imager.set_window_cus(restore)
+
     def work(worker):
         try:
             while not errors:
@@ -302,19 +340,15 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
                     index, channel = todo.get_nowait()
                 except queue.Empty:
                     return
-                job = make_job(channel, worker) if takes_worker else make_job(channel)
-                kwargs = dict(job)          # (the caller's dict is left as it is)
-                if batcher is not None and kwargs.get('batched_clean', True):
-                    kwargs.setdefault('clean_batcher', batcher)
-                imager = kwargs.get('imager')
-                if imager is not None and hasattr(imager, 'command_queue'):
-                    # the current HIP device is per host thread (new threads start on device 0)
+                # the current HIP device is per host thread and new threads start on device 0:
+                # everything of a channel, the making of its job included (an imager built lazily
+                # there allocates, plans transforms and launches), runs with the stream's device
+                if device is not None:
                     import torch
-                    with torch.cuda.device(imager.command_queue.context.device):
-                        results[index] = process_channel(**kwargs)
+                    with torch.cuda.device(device):
+                        one(index, channel, worker)
                 else:
-                    results[index] = process_channel(**kwargs)
-                del job, kwargs, imager
+                    one(index, channel, worker)
         except BaseException as exc:        # noqa: B902 -- re-raised in the caller's thread
             errors.append(exc)
         finally:
@@ -324,24 +358,17 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
     if count == 1:
         work(0)
     else:
-        # The gridder's and degridder's workgroups stay on their CUs for a whole launch and leave no
-        # room for another channel's CLEAN workgroups, whose chain of launches then stands still:
-        # with several channels in flight those kernels keep off a quarter of the device
-        # (kimg_set_window_cus: 7.2 -> 6.1 ms per channel with four in flight).
-        from ._lib import lib, check
-        before = lib().kimg_get_window_cus()
-        if window_cus is None:
-            window_cus = WINDOW_CUS_SHARED
-        check(lib().kimg_set_window_cus(int(window_cus)), 'kimg_set_window_cus')
+        # (daemon threads: an interrupt of the caller must not leave the process waiting for them)
+        threads = [threading.Thread(target=work, args=(w,), name='kimg-channel-%d' % w, daemon=True)
+                   for w in range(count)]
+        for t in threads:
+            t.start()
         try:
-            threads = [threading.Thread(target=work, args=(w,), name='kimg-channel-%d' % w)
-                       for w in range(count)]
-            for t in threads:
-                t.start()
             for t in threads:
                 t.join()
-        finally:
-            lib().kimg_set_window_cus(before)
+        except BaseException as exc:        # noqa: B902 -- KeyboardInterrupt in the caller
+            errors.append(exc)              # (the workers draw no further channels)
+            raise
     #: (channels, cycles) of every shared CLEAN launch sequence of the last call, for reports
     process_channel_stream.last_batches = list(batcher.batches) if batcher is not None else []
     if errors:

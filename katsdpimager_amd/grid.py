@@ -330,6 +330,10 @@ class GridDegrid(VisOperation):
         self.locality_hint = None
         #: variant the last call took ('mfma', 'binned' or 'generic'), for tests and reports
         self.last_variant = None
+        #: CUs (of 256) the window kernel of THIS operation fills with its resident workgroups;
+        #: 0 = the process default (all).  It travels with every call (KIMG_WINDOW_CUS): an imager
+        #: that shares its GPU with other channels in flight leaves room for their CLEAN launches.
+        self.window_cus = 0
 
     def _binned_workspace(self):
         """The scratch of the binned variant, allocated on first use."""
@@ -419,7 +423,7 @@ class Gridder(GridDegrid):
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('vis').ptr,
             self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None,
-            self._workspace_bytes, variant, self.template.arith,
+            self._workspace_bytes, variant | int(self.window_cus) << 8, self.template.arith,
             self.command_queue.handle)
         check(rc, 'kimg_grid')
         self._note_variant(variant)
@@ -477,6 +481,6 @@ class Degridder(GridDegrid):
             self.buffer('uv').ptr, self.buffer('w_plane').ptr, self.buffer('weights').ptr,
             self.buffer('vis').ptr, self.num_vis, table, W, OV, K,
             self._workspace.ptr if self._workspace is not None else None, self._workspace_bytes,
-            variant, self.template.arith, self.command_queue.handle)
+            variant | int(self.window_cus) << 8, self.template.arith, self.command_queue.handle)
         check(rc, 'kimg_degrid')
         self._note_variant(variant)

@@ -263,6 +263,7 @@ class Imaging(accel.OperationSequence):
         self._bound = True
         if self._side_args is not None and self._side is None:
             self._side = _SidePipeline(self, *self._side_args)
+            self.set_window_cus(getattr(self, '_window_cus', 0))
             self._fence()
 
     # ---- two-stream bookkeeping ---------------------------------------------------------
@@ -278,6 +279,18 @@ class Imaging(accel.OperationSequence):
         if self._side is not None:
             self._prologue = self.command_queue.enqueue_marker()
             self._side_synced = False
+
+    def set_window_cus(self, cus):
+        """CUs (of 256; 0 = all) the gridder and degridder launches of THIS imager fill
+        (``Gridder.window_cus``): ``frontend.process_channel_stream`` sets 192 on the imagers it keeps
+        in flight together, so that the other channels' CLEAN launches find room."""
+        self._window_cus = int(cus)
+        ops = [self._gridder, self._predict]
+        if self._side is not None:
+            ops += [self._side.gridder, self._side.predict]
+        for op in ops:
+            if hasattr(op, 'window_cus'):
+                op.window_cus = self._window_cus
 
     def _use_side(self):
         """True if the current chunk belongs to the side pipeline (and make it ready)."""

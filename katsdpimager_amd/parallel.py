@@ -18,6 +18,21 @@ def world():
     return 0, 1
 
 
+def _collective():
+    """Do the helpers below go through torch.distributed?  Whenever a process group exists, also
+    one of a single rank (the backend's code path then runs on the one device there is: how the
+    RCCL path is exercised on a one-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def free_port():
+    """A TCP port nobody listens on, for a rendezvous on 127.0.0.1 started without a launcher."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def assign_channels(num_channels, world_size, rank):
     """Channels imaged by `rank`: c with c mod world_size == rank."""
     if not 0 <= rank < world_size:
@@ -35,9 +50,8 @@ def channel_frequency_scale(channel, num_channels, spread=0.03):
 
 def broadcast_shared(tensors, src=0):
     """Broadcast channel-independent tables (dict name -> tensor, allocated with the right
-    shape/dtype on every rank) from `src`, in place.  No-op for a single process."""
-    rank, size = world()
-    if size == 1:
+    shape/dtype on every rank) from `src`, in place.  No-op without a process group."""
+    if not _collective():
         return tensors
     for name in sorted(tensors):
         dist.broadcast(tensors[name], src=src)
@@ -46,8 +60,7 @@ def broadcast_shared(tensors, src=0):
 
 def max_over_ranks(value, device='cpu'):
     """Maximum of a Python float over all ranks (timings)."""
-    rank, size = world()
-    if size == 1:
+    if not _collective():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -59,7 +72,7 @@ def gather_stats(values, device='cpu'):
     minor cycles); returns a [world_size][len(values)] tensor on every rank."""
     rank, size = world()
     t = torch.tensor([values], dtype=torch.float64, device=device)
-    if size == 1:
+    if not _collective():
         return t
     out = [torch.empty_like(t) for _ in range(size)]
     dist.all_gather(out, t)

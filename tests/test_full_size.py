@@ -288,6 +288,55 @@ def test_c2_forms_repeatable_at_scale():
     assert int((split[0] != 0).sum()) == int((exact[0] != 0).sum())
 
 
+def test_c2_true_length_one_launch():
+    """BASELINE config 2 at its TRUE length -- the launch bench.py times: 50 M visibilities of one
+    W-slice in ONE gridder launch (4096^2, 32 planes, K = 28, one polarization).  (i) The float64
+    checksum of the whole grid (linear in N; evaluated with torch in float64 on the device,
+    independently of the kernel); (ii) the same cells, values within 4e-6 of the peak, as
+    `vis_block` launches of 1 M; (iii) the 1 M chunk in the MIDDLE of the 50 M against the oracle."""
+    import torch
+    from katsdpimager_amd import accel
+    n = 50_000_000
+    ctx, q, obs, fn_chunked, wg = _setup(4096, n, 32, 1)
+    _, _, _, fn, _ = _setup(4096, n, 32, 1, vis_block=n, variant='mfma')
+    fn.bind(weights_grid=wg)
+    got = _grid_all(ctx, q, obs, fn).clone()                    # one launch
+    assert fn.last_variant == 'mfma'
+    # (i)
+    dev = ctx.device
+    rowsum = torch.from_numpy(fn.convolve_kernel.data.astype(np.complex128).sum(axis=2)).to(dev)
+    Gg = wg.shape[-1]
+    uv, wp = obs.uv.long(), obs.w_plane.long()
+    w = wg.tensor[0][uv[:, 1] + Gg // 2, uv[:, 0] + Gg // 2].double()
+    want_sum = complex((obs.vis[:, 0].to(torch.complex128) * w * torch.conj(rowsum[wp, uv[:, 3]])
+                        * torch.conj(rowsum[wp, uv[:, 2]])).sum())
+    got_sum = complex(got[0].sum(dtype=torch.complex128))
+    assert abs(got_sum - want_sum) <= 2e-5 * abs(want_sum), (got_sum, want_sum)
+    del uv, wp, w
+    # (ii)
+    want = _grid_all(ctx, q, obs, fn_chunked)
+    peak = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 4e-6 * peak
+    assert int((got != 0).sum()) == int((want != 0).sum())
+    del got, want
+    # (iii)
+    vb = fn_chunked.max_vis
+    s = slice(24 * vb, 25 * vb)
+    fn_chunked.buffer('grid').zero(q)
+    fn_chunked.bind(uv=accel.DeviceArray(ctx, (vb, 4), np.int16, tensor=obs.uv[s]),
+                    w_plane=accel.DeviceArray(ctx, (vb,), np.int16, tensor=obs.w_plane[s]),
+                    vis=accel.DeviceArray(ctx, (vb, 1), np.complex64, tensor=obs.vis[s]))
+    fn_chunked.num_vis = vb
+    fn_chunked()
+    mid = fn_chunked.buffer('grid').get(q)
+    ref = np.zeros_like(mid)
+    uvh = obs.uv[s].cpu().numpy()
+    orc.grid(fn_chunked.convolve_kernel.data, ref, wg.tensor.cpu().numpy(),
+             np.ascontiguousarray(uvh[:, :2]), np.ascontiguousarray(uvh[:, 2:]),
+             obs.w_plane[s].cpu().numpy(), obs.vis[s].cpu().numpy())
+    assert relerr(mid, ref) < 1e-5
+
+
 @pytest.mark.parametrize('K,W', [(28, 32), (60, 256)])
 @pytest.mark.parametrize('arith', ['fp32', 'split_fp16'])
 def test_long_launch_work_by_the_chunk(arith, K, W):

@@ -96,6 +96,50 @@ def test_window_kernels_on_part_of_the_device(cus):
         lib().kimg_set_window_cus(0)
 
 
+@pytest.mark.gpu
+def test_window_cus_travel_with_the_call():
+    """`Gridder.window_cus` / KIMG_WINDOW_CUS: the share of the CUs is an argument of every
+    kimg_grid / kimg_degrid call, not process state -- two imagers of one process with different
+    settings, gridding concurrently from two host threads on two streams, each get the results of
+    the whole device, the process-wide default stays what it was, and a value outside 1 .. 256 is
+    refused."""
+    import threading
+    from katsdpimager_amd._lib import lib
+    c = gi.make_config(512, 0.0001, 0.01, 2, 28, 16, grid_cover=300, n_vis=60000)
+    t = gi.grid_track(c)
+    fn, q = _gridder(c, 'mfma', max_vis=65536)
+    whole = _run_gridder(fn, q, t)
+    ops = []
+    ip, gp, ap = make_params(c)
+    for cus in (5, 192):
+        qq = fn.template.context.create_command_queue()        # a stream of its own
+        op = fn.template.instantiate(qq, ap, ip, gp, 65536)
+        op.ensure_all_bound()
+        op.window_cus = cus
+        ops.append((op, qq))
+    out, errors = {}, []
+
+    def work(k):
+        try:
+            import torch
+            with torch.cuda.device(0):
+                for _ in range(6):
+                    out[k] = _run_gridder(ops[k][0], ops[k][1], t)
+        except Exception as exc:        # noqa: B902
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert relerr(out[0], whole) < 2e-6 and relerr(out[1], whole) < 2e-6
+    assert lib().kimg_get_window_cus() == 256
+    ops[0][0].window_cus = 257
+    with pytest.raises(Exception):
+        _run_gridder(ops[0][0], ops[0][1], t)
+
+
 @pytest.mark.parametrize('variant', ['generic', 'mfma', 'mfma:split_fp16'])
 @pytest.mark.parametrize('P', [1, 2, 3, 4])
 def test_gridder_bruteforce(variant, P):

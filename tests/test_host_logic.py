@@ -717,6 +717,57 @@ def test_process_channel_stream_bounds_live_jobs(monkeypatch):
     assert got == {c: 2 * c for c in range(7)}
 
 
+def test_channel_stream_makes_jobs_on_the_streams_device(monkeypatch):
+    """process_channel_stream: everything of a channel -- the making of its job included, where an
+    imager may be built lazily -- runs with the stream's device current in the worker thread (new
+    host threads start on HIP device 0), and the imagers in flight together are told their share of
+    the CUs per imager (no process-wide setting)."""
+    import contextlib
+    import threading
+    import torch
+    from katsdpimager_amd import frontend
+    current = threading.local()
+    seen = []
+
+    @contextlib.contextmanager
+    def fake_device(index):
+        before = getattr(current, 'index', 0)
+        current.index = index
+        try:
+            yield
+        finally:
+            current.index = before
+    monkeypatch.setattr(torch.cuda, 'device', fake_device)
+
+    class FakeImager:
+        def __init__(self):
+            self.cus = []
+
+        def set_window_cus(self, cus):
+            self._window_cus = cus
+            self.cus.append(cus)
+    imagers = {}
+
+    def make_job(channel, worker):
+        seen.append(('make', channel, getattr(current, 'index', 0)))
+        imagers[channel] = FakeImager()
+        return dict(channel=channel, imager=imagers[channel])
+
+    def fake_process_channel(channel, imager, clean_batcher=None):
+        seen.append(('run', channel, getattr(current, 'index', 0), imager._window_cus))
+        return channel
+    monkeypatch.setattr(frontend, 'process_channel', fake_process_channel)
+    assert frontend.process_channel_stream(make_job, range(6), workers=3, device=5,
+                                           batch_clean=False) == list(range(6))
+    assert all(e[2] == 5 for e in seen) and len(seen) == 12
+    assert all(e[3] == frontend.WINDOW_CUS_SHARED for e in seen if e[0] == 'run')
+    assert all(im.cus == [frontend.WINDOW_CUS_SHARED, 0] for im in imagers.values())
+    # one channel at a time: the whole device
+    seen.clear()
+    frontend.process_channel_stream(make_job, [9], workers=4, device=2, batch_clean=False)
+    assert seen == [('make', 9, 2), ('run', 9, 2, 0)]
+
+
 def test_window_cus_setting():
     """kimg_set_window_cus / kimg_get_window_cus (host state only): 0 means all 256, values outside
     0 ... 256 are refused and leave the setting alone."""

@@ -55,11 +55,9 @@ class Observation:
     """
 
 
-def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
-                     wavelength=0.21, cover=0.30, seed=2, device='cpu', w_slices=1,
-                     channel_scale=1.0):
-    """`cover`: longest baseline as a fraction of the grid size in cells (0.30, SURVEY 8d).
-    `channel_scale`: relative frequency of this channel (scales uvw in wavelengths)."""
+def track_uvw(n_vis, device='cpu'):
+    """The channel-independent part of an observation: UVW in metres, float32 [n_vis][3], in loader
+    order (baseline-major earth-rotation tracks), what SURVEY 8e has the loading rank broadcast."""
     dev = torch.device(device)
     bl = torch.from_numpy(baselines_equatorial()).to(dev)                 # [B][3] f64
     nb = bl.shape[0]
@@ -71,6 +69,22 @@ def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
     u = (sh * lx + ch * ly).reshape(-1)[:n_vis]
     v = (-sd * ch * lx + sd * sh * ly + cd * lz).reshape(-1)[:n_vis]
     w = (cd * ch * lx - cd * sh * ly + sd * lz).reshape(-1)[:n_vis]
+    return torch.stack([u.to(torch.float32), v.to(torch.float32), w.to(torch.float32)], dim=1).contiguous()
+
+
+def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
+                     wavelength=0.21, cover=0.30, seed=2, device='cpu', w_slices=1,
+                     channel_scale=1.0, uvw=None):
+    """`cover`: longest baseline as a fraction of the grid size in cells (0.30, SURVEY 8d).
+    `channel_scale`: relative frequency of this channel (scales uvw in wavelengths).
+    `uvw`: the tracks in metres (:func:`track_uvw`) if they were made elsewhere (broadcast by the
+    loading rank); made here otherwise."""
+    dev = torch.device(device)
+    bl = torch.from_numpy(baselines_equatorial()).to(dev)                 # [B][3] f64
+    if uvw is None:
+        uvw = track_uvw(n_vis, dev)
+    assert tuple(uvw.shape) == (n_vis, 3) and uvw.dtype == torch.float32
+    u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
     # array-wide scales are taken over the full tracks so that they do not depend on n_vis
     longest = float(torch.sqrt((bl ** 2).sum(dim=1)).max())
     max_w = float(torch.sqrt((bl ** 2).sum(dim=1)).max())
@@ -87,10 +101,7 @@ def make_observation(pixels, n_vis, w_planes, num_polarizations=1, oversample=8,
     obs.oversample = oversample
 
     # preprocess.cpp:435-507 in float32
-    u = u.to(torch.float32)
-    v = v.to(torch.float32)
-    w = w.to(torch.float32)
-    obs.uvw = torch.stack([u, v, w], dim=1).contiguous()      # raw metres, loader order
+    obs.uvw = uvw                                             # raw metres, loader order
     flip = w < 0
     u = torch.where(flip, -u, u)
     v = torch.where(flip, -v, v)
