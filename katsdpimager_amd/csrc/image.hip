@@ -4,6 +4,9 @@
 // The arithmetic order follows the reference HOST classes (image.py:781-799, 836-848) so that
 // float32 results agree to rounding; this file is built with -ffp-contract=off.
 #include "kimg_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -1336,12 +1339,25 @@ int fft_plan_for(int G, hipStream_t s, fft_plan *out)
     return 0;
 }
 
+// (once per kernel, device and size: the attribute is set when a launch needs more dynamic LDS than
+// any before it, not with every transform)
+std::mutex fft_attribute_mutex;
+std::map<std::pair<const void *, int>, size_t> fft_attribute_set;
+
 template<typename Kernel>
 int fft_lds_attribute(Kernel kernel, size_t lds)
 {
-    if (lds > 64 * 1024)
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    if (lds <= 64 * 1024)
+        return 0;
+    int device = 0;
+    KIMG_HIP(hipGetDevice(&device));
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(fft_attribute_mutex);
+    size_t &have = fft_attribute_set[std::make_pair(fn, device)];
+    if (lds > have) {
+        KIMG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        have = lds;
+    }
     return 0;
 }
 

@@ -110,13 +110,20 @@ __global__ __launch_bounds__(256) void store_gather_kernel(
 // head[i] = 1 when sorted record i starts a run of equal coordinates.  Out-of-range sub-pixel or
 // plane indices were masked into the key; the comparison is on the records themselves, so two
 // such records are only merged when they are truly equal.
+// A run also ends at every multiple of STORE_MAX_RUN sorted positions: one thread sums a run left
+// to right (float32, arrival order: that order IS the result), so a run of a million equal
+// coordinates -- autocorrelations or zero-length baselines at uv = 0, a snapshot's PSF, synthetic
+// data with constant uv -- would be one thread working for seconds while the device idles.  Cut
+// runs are simply several records at the same coordinates: gridding, weights and degridding are
+// linear in them.
+constexpr int64_t STORE_MAX_RUN = 4096;
 struct head_flag {
     const unsigned *index;
     const int2 *uv;
     const int16_t *w_plane;
     __device__ unsigned operator()(int64_t i) const
     {
-        if (i == 0)
+        if ((i & (STORE_MAX_RUN - 1)) == 0)
             return 1u;
         const unsigned a = index[i - 1], b = index[i];
         const int2 ra = uv[a], rb = uv[b];

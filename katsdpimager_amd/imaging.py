@@ -315,6 +315,14 @@ class Imaging(accel.OperationSequence):
             self._ready()
         return super().buffer(name)
 
+    def bind(self, **kwargs):
+        """As the operations' ``bind``; a deferred :meth:`clear_dirty` belongs to the buffer that was
+        bound when it was asked for (the reference zeroes at call time, imaging.py:258-261): it is
+        carried out before 'dirty' is bound to another buffer."""
+        if 'dirty' in kwargs and getattr(self, '_dirty_cleared', False) and getattr(self, '_bound', False):
+            self._ready()
+        super().bind(**kwargs)
+
     # ---- visibilities ---------------------------------------------------------------
     @property
     def num_vis(self):

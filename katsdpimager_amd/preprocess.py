@@ -157,8 +157,23 @@ class _SliceStore:
             self.ordered = True
             return self.length
         n = self.length
-        out, kept = reorder_device_arrays(self.queue, self.P, n, self.arrays, kernel_width,
-                                          oversample, w_planes, merge, rows=n + self.slack)
+        try:
+            out, kept = reorder_device_arrays(self.queue, self.P, n, self.arrays, kernel_width,
+                                              oversample, w_planes, merge, rows=n + self.slack)
+        except (ValueError, MemoryError, RuntimeError) as exc:
+            # The re-order needs a second copy of the slice and 28 bytes of scratch per record while
+            # it runs, and kimg_store_reorder takes at most 2^31 - 1 records: a slice that does not
+            # allow it stays in arrival order, as the reference's store is (results are the same,
+            # the window kernels run slower on it).  Other errors are not memory's: re-raised.
+            too_big = isinstance(exc, ValueError) or 'out of memory' in str(exc).lower()
+            if not too_big:
+                raise
+            import logging
+            logging.getLogger(__name__).warning(
+                'slice of %d records left in arrival order (%s)', n, exc)
+            accel._torch().cuda.empty_cache()
+            self.ordered = False
+            return n
         self.arrays = out
         self.capacity = n + self.slack
         self.length = kept

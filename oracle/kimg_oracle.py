@@ -827,9 +827,13 @@ def _bits_for(values):
     return b
 
 
+STORE_MAX_RUN = 4096
+
+
 def store_reorder(uv4, w_plane, weights, vis, kernel_width, oversample, w_planes, merge):
     """uv4 int16 [N][4] = (u, v, sub_u, sub_v).  Returns (uv4, w_plane, weights, vis) in store
-    order; with ``merge`` runs of equal coordinates are summed left to right in float32."""
+    order; with ``merge`` runs of equal coordinates are summed left to right in float32 (a run
+    also ends at every multiple of STORE_MAX_RUN sorted positions: csrc/store.hip)."""
     width = store_strip_width(kernel_width)
     u = uv4[:, 0].astype(np.int64) + 32768
     v = uv4[:, 1].astype(np.int64) + 32768
@@ -848,6 +852,7 @@ def store_reorder(uv4, w_plane, weights, vis, kernel_width, oversample, w_planes
         return uv_s, wp_s, w_s, vis_s
     head = np.ones(len(order), bool)
     head[1:] = np.any(uv_s[1:] != uv_s[:-1], axis=1) | (wp_s[1:] != wp_s[:-1])
+    head[::STORE_MAX_RUN] = True
     starts = np.flatnonzero(head)
     lengths = np.diff(np.append(starts, len(order)))
     out_w = w_s[starts].copy()
