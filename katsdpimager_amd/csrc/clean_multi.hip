@@ -314,9 +314,32 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
         MC_STAMP(12);
         // (too many to rank, which 64 + 254 allow in principle, or too few left: scan)
         scan = na > MC_CAP || (na < MC_LOW && old_floor != 0);
+#ifdef KIMG_MC_STAMPS
+        {
+            // (test build: how the list changes from launch to launch)
+            __shared__ int s_fresh, s_above;
+            if (tid == 0)
+                s_fresh = s_above = 0;
+            __syncthreads();
+            if (fresh)
+                atomicAdd(&s_fresh, 1);
+            if (dkey >= MC_REAL && (dkey >> 32) > (old_floor >> 32))
+                atomicAdd(&s_above, 1);
+            __syncthreads();
+            MC_COUNT(5, s_fresh);
+            MC_COUNT(6, na);
+            MC_COUNT(7, old_n);
+            MC_COUNT(17, (long long) __uint_as_float((unsigned) (old_floor >> 32)) * 1000);
+            MC_COUNT(18, nflux);
+        }
+#endif
         if (scan) {
             // (about 0.7 of the floor so far; the first answer with enough entries to last a while is
-            // taken: every attempt is a pass over the tile maxima)
+            // taken: every attempt is a pass over the tile maxima, 60 KB through one CU's memory
+            // pipe.  A deep CLEAN brings ever more sources down to one common level, just above
+            // the floor of a list that holds MC_TOP of them: the list then loses what a launch
+            // commits and is rebuilt every (MC_TOP - MC_LOW) / 8 launches -- 7 % of the launches
+            // of the bench image's 1000 cycles, which take 26 us instead of 8.)
             tau = lower_tau(tau);
             nmin = MC_TOP / 2;
         }

@@ -62,6 +62,10 @@ for row, label in ((0, 'K (keeper)'), (1, 'B (block (0, 0) of the first planned 
         continue
     print('%s: %d workgroups; planned %.2f, committed %.2f per launch; scans per launch %.2f (in %.2f of the launches), listed %.1f' % (
         label, n, raw[row][17] / n, raw[row][18] / n, raw[row][15] / n, raw[row][19] / n, raw[row][14] / max(n, 1)))
+    if row == 2:
+        print('   old list %.1f entries, merged %.1f of which %.1f from delta records; floor %.3f on average; %.1f lattices folded' % (
+            raw[row][7] / n, raw[row][6] / n, raw[row][5] / n, raw[row][17] / n / 1000, raw[row][18] / n))
+        raw[row][5] = raw[row][6] = raw[row][7] = 0
     for i in (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 8, 9, 10, 11):
         if raw[row][i]:
             print('   %-40s %8.0f cycles' % (names[i], raw[row][i] / n))
