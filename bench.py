@@ -558,7 +558,10 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
         q.finish()
         t0 = time.perf_counter()
         if not per_cycle:
-            done = len(op.run_cycles(patch_, 0.0, n))
+            # (the loop, the host's share of it and the read-back of what it logged, as arrays:
+            # the per-cycle tuples of the reference's API are made from them on demand)
+            op.run_cycles(patch_, 0.0, n, collect=False)
+            done = len(op._collect_cycle_arrays()[0])
         else:
             done = 0
             for _ in range(n):

@@ -498,11 +498,11 @@ class Clean(accel.OperationSequence):
         q = self.command_queue
         self._state.used_on(q)
         with torch.cuda.stream(q.stream):
-            head = self._state.tensor.reshape(-1)[:1140].cpu().numpy().view(np.int32)
+            head = self._state.tensor.reshape(-1)[:1660].cpu().numpy().view(np.int32)
         if head[4] != 0x4d554c54:       # mc_scratch.pad[0], set by mc_init_kernel
             return None
-        # mc_state.launches of the two state buffers (byte offsets 64 + 28 and 64 + 4416 + 28)
-        return int(max(head[16 + 7], head[16 + 1104 + 7]))
+        # mc_state.launches of the two state buffers (byte offsets 64 + 28 and 64 + 6464 + 28)
+        return int(max(head[16 + 7], head[16 + 1616 + 7]))
 
     def _collect_cycles(self):
         """The same as a list of (peak_value, (y, x), model_pixel), the reference's per-cycle

@@ -54,7 +54,7 @@ constexpr int MC_MAX = 8;               // components per launch
 constexpr int MC_THREADS = 256;         // threads of a workgroup = records of a launch
 constexpr int MC_REST = 24;             // entries of the list (lanes 8 .. 31 of a wave load one each)
 constexpr int MC_POOL_REST = 8;         // of which the first that survive enter the candidate pool
-constexpr int MC_TOP = 128;             // entries of the list the lister maintains
+constexpr int MC_TOP = 192;             // entries of the list the lister maintains
 constexpr int MC_LOW = 24;              // fewer than this left: the lister scans the tile maxima again
 constexpr int MC_CAP = 256;             // tiles the keeper sorts: one per thread
 constexpr mkey_t MC_REAL = 1024;        // smaller keys stand for "nothing" (distinct fillers)
@@ -173,7 +173,7 @@ struct __attribute__((aligned(16))) mc_state {      // written by the keeper of 
     mc_record top[MC_TOP];  // the best tiles of the image, sorted: key + pixel values at the tile's peak
 };
 
-static_assert(sizeof(mc_state) == 4416, "Clean.last_launches reads `launches` at fixed offsets");
+static_assert(sizeof(mc_state) == 6464, "Clean.last_launches reads `launches` at fixed offsets");
 
 struct mc_scratch {
     int head[4];            // count, done, limit, threshold bits: what the host reads, as the other forms'
@@ -289,50 +289,103 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
         const mc_cand oc = mc_decode(o.key, g.border);
         const bool keep = o.key >= MC_REAL && !rect_hits(oc.tx, oc.ty);
         const bool fresh = dkey >= MC_REAL && dkey > old_floor;
+        // The old list is sorted, and few entries change: an old entry's new rank is its old one
+        // minus the entries dropped before it plus the fresh ones above it; a fresh one finds its
+        // place among the old by bisection.  (Ranking everything against everything was the longest
+        // step of the launch.)  LDS: key[t] = old key t as it was, idx[t] = entries dropped before
+        // t, key[MC_TOP + f] = fresh key f.
+        const bool dropped = tid < old_n && !keep;
+        const unsigned long long drops = __builtin_amdgcn_ballot_w64(dropped);
+        const int wave = tid >> 6, lane = tid & 63;
+        __shared__ int s_wave_drops[MC_THREADS / 64];
+        if (lane == 0)
+            s_wave_drops[wave] = __builtin_popcountll(drops);
+        if (tid < MC_TOP)
+            s.key[tid] = tid < old_n ? o.key : 0;
         __syncthreads();
-        // (two reservations of ONE slot each: a sum of per-lane counts would be gathered lane by lane)
-        if (keep) {
-            const int slot = atomicAdd(&s.na, 1);
-            if (slot < MC_CAP) {
-                s.key[slot] = o.key;
-                s.idx[slot] = INT_MIN;
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-                    s.pix[slot][p] = o.pix[p];
-            }
-        }
+        int before = __builtin_popcountll(drops & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++)
+            before += s_wave_drops[w];
+        if (tid < MC_TOP)
+            s.idx[tid] = before;
+        int fslot = -1;
         if (fresh) {
-            const int slot = atomicAdd(&s.na, 1);
-            if (slot < MC_CAP) {
-                s.key[slot] = dkey;
-                s.idx[slot] = INT_MIN;
-                *reinterpret_cast<float4 *>(s.pix[slot]) = dpix;
-            }
+            fslot = atomicAdd(&s.na, 1);
+            if (fslot < MC_CAP - MC_TOP)
+                s.key[MC_TOP + fslot] = dkey;
         }
         __syncthreads();
-        na = s.na;
+        const int nf = s.na;
+        int total_drops = 0;
+        for (int w = 0; w < MC_THREADS / 64; w++)
+            total_drops += s_wave_drops[w];
+        na = old_n - total_drops + nf;
         MC_STAMP(12);
-        // (too many to rank, which 64 + 254 allow in principle, or too few left: scan)
-        scan = na > MC_CAP || (na < MC_LOW && old_floor != 0);
+        // (more fresh entries than there is room to rank, or too few entries left: scan)
+        scan = nf > MC_CAP - MC_TOP || (na < MC_LOW && old_floor != 0);
 #ifdef KIMG_MC_STAMPS
-        {
-            // (test build: how the list changes from launch to launch)
-            __shared__ int s_fresh, s_above;
-            if (tid == 0)
-                s_fresh = s_above = 0;
-            __syncthreads();
-            if (fresh)
-                atomicAdd(&s_fresh, 1);
-            if (dkey >= MC_REAL && (dkey >> 32) > (old_floor >> 32))
-                atomicAdd(&s_above, 1);
-            __syncthreads();
-            MC_COUNT(5, s_fresh);
-            MC_COUNT(6, na);
-            MC_COUNT(7, old_n);
-            MC_COUNT(17, (long long) __uint_as_float((unsigned) (old_floor >> 32)) * 1000);
-            MC_COUNT(18, nflux);
-        }
+        MC_COUNT(5, nf);
+        MC_COUNT(6, na);
+        MC_COUNT(7, old_n);
+        MC_COUNT(17, (long long) __uint_as_float((unsigned) (old_floor >> 32)) * 1000);
+        MC_COUNT(18, nflux);
 #endif
+        if (!scan) {
+            auto fresh_above = [&](mkey_t k) {
+                int c = 0;
+                for (int f = 0; f < nf; f++)
+                    c += s.key[MC_TOP + f] > k ? 1 : 0;
+                return c;
+            };
+            auto put = [&](int rank, mkey_t k, const float *pix) {
+                if (rank < MC_TOP) {
+                    mc_record r;
+                    r.key = k;
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        r.pix[p] = pix[p];
+                    r.pad[0] = r.pad[1] = 0;
+                    next->top[rank] = r;
+                }
+                // (an entry that is dropped is above everything that stays out)
+                if (rank == MC_TOP)
+                    next->top_floor = k | 0x3ffu;
+                if (rank == MC_REST)
+                    next->rest_floor = k | 0x3ffu;
+            };
+            if (keep)
+                put(tid - before + fresh_above(o.key), o.key, o.pix);
+            if (fresh) {
+                // old keys above this one: the list is sorted, largest first
+                int lo_i = 0, hi_i = old_n;
+                while (lo_i < hi_i) {
+                    const int mid = (lo_i + hi_i) >> 1;
+                    if (s.key[mid] > dkey)
+                        lo_i = mid + 1;
+                    else
+                        hi_i = mid;
+                }
+                const int dropped_above = lo_i < old_n ? s.idx[lo_i] : total_drops;
+                const float fp[4] = {dpix.x, dpix.y, dpix.z, dpix.w};
+                put(lo_i - dropped_above + fresh_above(dkey), dkey, fp);
+            }
+            if (tid == 0) {
+                next->top_n = na < MC_TOP ? na : MC_TOP;
+                if (na <= MC_TOP)
+                    next->top_floor = old_floor;
+                if (na <= MC_REST)
+                    next->rest_floor = old_floor;
+                next->tau = tau;
+                next->pad2 = 0;
+            }
+            MC_STAMP(9);
+            MC_COUNT(14, na);
+            MC_STAMP(10);
+            return;
+        }
+        __syncthreads();
+        if (tid == 0)
+            s.na = 0;
         if (scan) {
             // (about 0.7 of the floor so far; the first answer with enough entries to last a while is
             // taken: every attempt is a pass over the tile maxima, 60 KB through one CU's memory
@@ -341,7 +394,7 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
             // commits and is rebuilt every (MC_TOP - MC_LOW) / 8 launches -- 7 % of the launches
             // of the bench image's 1000 cycles, which take 26 us instead of 8.)
             tau = lower_tau(tau);
-            nmin = MC_TOP / 2;
+            nmin = 64;
         }
     }
     for (int attempt = 0; scan && attempt < 100; attempt++) {
@@ -558,7 +611,8 @@ constexpr int ROLE_KEEPER = 0, ROLE_FOLDER = 1, ROLE_LISTER = 2, ROLE_NEW = 3, R
 // One block of pixels: dirty (+ a pending subtraction, written back) (- a planned subtraction, in
 // registers), and the block's tile record after it.  256 threads, four pixels each in row-major
 // order (first strict maximum in that order, clean.py:953-958).
-template <int MODE>
+// PMAX: 1 when there is one polarization (no loop over planes, a third of the instructions), else 4.
+template <int MODE, int PMAX>
 __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, const float *__restrict__ psf, const mc_geom &g,
                                 int tx, int ty, bool has_pend, int pend_y, int pend_x,
                                 const float *pend_scale, bool has_new, int new_y, int new_x,
@@ -572,7 +626,7 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
     const int bx0 = new_x - g.patch_w / 2, by0 = new_y - g.patch_h / 2;
     const int adx = g.psf_w / 2 - pend_x, ady = g.psf_h / 2 - pend_y;          // psf index = image index + d
     const int bdx = g.psf_w / 2 - new_x, bdy = g.psf_h / 2 - new_y;
-    float dv[4][4], pa[4][4], pb[4][4];
+    float dv[4][PMAX], pa[4][PMAX], pb[4][PMAX];
     bool inside[4], in_a[4], in_b[4];
     const int x = ox + (tid & 31);
 #pragma unroll
@@ -583,11 +637,11 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
         in_b[k] = has_new && inside[k] && x >= bx0 && x < bx0 + g.patch_w && y >= by0 && y < by0 + g.patch_h;
         const int64_t ia = (int64_t) y * g.row_stride + x;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < PMAX; p++) {
             dv[k][p] = 0.0f;
             pa[k][p] = 0.0f;
             pb[k][p] = 0.0f;
-            if (p < g.P) {
+            if (PMAX == 1 || p < g.P) {
                 if (inside[k])
                     dv[k][p] = dirty[p * g.pol_stride + ia];
                 if (in_a[k])
@@ -610,8 +664,8 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
         const int64_t ia = (int64_t) y * g.row_stride + x;
         float metric = 0.0f;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            if (p < g.P) {
+        for (int p = 0; p < PMAX; p++) {
+            if (PMAX == 1 || p < g.P) {
                 if (in_a[k]) {
                     const float t = pend_scale[p] * pa[k][p];      // clean.py:1044-1046: two roundings
                     dv[k][p] -= t;
@@ -669,14 +723,16 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
             o.key = mc_key(__uint_as_float((unsigned) (tb >> 32)), tx, ty, widx >> 5, widx & 31);
 #pragma unroll
             for (int p = 0; p < 4; p++)
-                o.pix[p] = kk == 0 ? dv[0][p] : kk == 1 ? dv[1][p] : kk == 2 ? dv[2][p] : dv[3][p];
+                o.pix[p] = p >= PMAX ? 0.0f
+                           : kk == 0 ? dv[0][p < PMAX ? p : 0] : kk == 1 ? dv[1][p < PMAX ? p : 0]
+                           : kk == 2 ? dv[2][p < PMAX ? p : 0] : dv[3][p < PMAX ? p : 0];
         }
         *out = o;
     }
     MC_STAMP(7);
 }
 
-template <int MODE>
+template <int MODE, int PMAX>
 __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     float *dirty, float *model, const float *__restrict__ psf, float *tile_max, int32_t *tile_pos,
     mc_geom g, mc_scratch *scratch, int parity, float *log, unsigned long long *progress)
@@ -1016,7 +1072,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             ns[i] = g.loop_gain * ns[i];
         }
         MC_STAMP(5);
-        mc_block<MODE>(dirty, psf, g, tx, ty, hit != 0, lane_int(pc.y, pend), lane_int(pc.x, pend), ps,
+        mc_block<MODE, PMAX>(dirty, psf, g, tx, ty, hit != 0, lane_int(pc.y, pend), lane_int(pc.x, pend), ps,
                        true, ny, nx, ns,
                        &scratch->deltas[parity ^ 1][comp * g.seg + (int) blockIdx.y * g.lat_x + (int) blockIdx.x],
                        s, dbg_v, dbg_t0);
@@ -1034,7 +1090,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
 #pragma unroll
         for (int i = 0; i < 4; i++)
             ps[i] = g.loop_gain * lane_float(ppix[i], comp);
-        mc_block<MODE>(dirty, psf, g, tx, ty, true, lane_int(pc.y, comp), lane_int(pc.x, comp), ps, false,
+        mc_block<MODE, PMAX>(dirty, psf, g, tx, ty, true, lane_int(pc.y, comp), lane_int(pc.x, comp), ps, false,
                        0, 0, ps, nullptr, s, dbg_v, dbg_t0);
         return;
     }
@@ -1134,7 +1190,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
 #else
     long long *dbg_v = nullptr;
 #endif
-    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), MC_TOP, INT_MIN / 2,
+    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), 128, INT_MIN / 2,
                   INT_MIN / 2, 0, 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), false, make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), 0, 0, st, sr, dbg_v, 0);
 }
 
@@ -1154,12 +1210,17 @@ struct multi_args {
 int enqueue_launch(const multi_args &a, hipStream_t s, int parity)
 {
     const dim3 grid(a.g.lat_x, a.g.lat_y, 1 + 2 * a.g.mmax);
-    if (a.mode == KIMG_CLEAN_I)
-        cycle_multi_kernel<KIMG_CLEAN_I><<<grid, MC_THREADS, 0, s>>>(
-            a.dirty, a.model, a.psf, a.tile_max, a.tile_pos, a.g, a.scratch, parity, a.log, a.progress);
+#define LAUNCH(MODE, PMAX) cycle_multi_kernel<MODE, PMAX><<<grid, MC_THREADS, 0, s>>>( \
+        a.dirty, a.model, a.psf, a.tile_max, a.tile_pos, a.g, a.scratch, parity, a.log, a.progress)
+    if (a.mode == KIMG_CLEAN_I && a.g.P == 1)
+        LAUNCH(KIMG_CLEAN_I, 1);
+    else if (a.mode == KIMG_CLEAN_I)
+        LAUNCH(KIMG_CLEAN_I, 4);
+    else if (a.g.P == 1)
+        LAUNCH(KIMG_CLEAN_SUMSQ, 1);
     else
-        cycle_multi_kernel<KIMG_CLEAN_SUMSQ><<<grid, MC_THREADS, 0, s>>>(
-            a.dirty, a.model, a.psf, a.tile_max, a.tile_pos, a.g, a.scratch, parity, a.log, a.progress);
+        LAUNCH(KIMG_CLEAN_SUMSQ, 4);
+#undef LAUNCH
     return kimg_launch_status();
 }
 

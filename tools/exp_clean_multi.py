@@ -50,9 +50,11 @@ for form, comps in [('one_launch', 0)] + [('multi', c) for c in (1, 2, 4, 6, 8)]
         cl.reset()
         q.finish()
         t0 = time.perf_counter()
-        got = cl.run_cycles(patch, 0.0, cycles)
+        cl.run_cycles(patch, 0.0, cycles, collect=False)
+        arrays = cl._collect_cycle_arrays()         # (read-back included)
         q.finish()
-        rates.append(len(got) / (time.perf_counter() - t0))
+        rates.append(len(arrays[0]) / (time.perf_counter() - t0))
+        got = list(zip(arrays[0], [tuple(p) for p in arrays[1].tolist()], arrays[2]))
     launches = cl.last_launches()
     sig = [(round(float(v), 6), tuple(p)) for v, p, m in got]
     first = first or sig

@@ -48,7 +48,7 @@ for rep in range(3):
     q.finish()
     dt = time.perf_counter() - t0
 tiles = op.buffer('tile_max').shape
-offset = (64 + 2 * 4416 + 2 * 256 * 32 + tiles[0] * tiles[1] * 16) // 4
+offset = (64 + 2 * 6464 + 2 * 256 * 32 + tiles[0] * tiles[1] * 16) // 4
 raw = op._state.get(q)[offset:offset + 192].view(np.int64).reshape(3, 32)
 launches = op.last_launches()
 print('%d components in %d launches, %.1f us per launch, %.0f cycles/s' % (
