@@ -1488,23 +1488,31 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             continue;
         }
         // nothing to enqueue: wait for the device
-        if (now_s() - t_progress > 2e-3 && hipStreamQuery(s) == hipSuccess) {
-            // the stream is idle but the word has not moved: read the state itself
-            int head[8];
-            mc_state st0;
-            he = hipMemcpy(head, a.scratch->head, sizeof(int) * 4, hipMemcpyDeviceToHost);
-            if (he == hipSuccess)
+        if (now_s() - t_progress > 2e-3) {
+            const hipError_t busy = hipStreamQuery(s);
+            if (busy != hipSuccess && busy != hipErrorNotReady) {
+                rc = -(int) busy;       // (a launch failed: the word will never move)
+                break;
+            }
+            if (busy == hipSuccess) {
+                // the stream is idle but the word has not moved: read the state itself
+                mc_state st0;
                 he = hipMemcpy(&st0, &a.scratch->st[enqueued & 1], 32, hipMemcpyDeviceToHost);
-            if (he != hipSuccess) {
-                rc = -(int) he;
+                if (he != hipSuccess) {
+                    rc = -(int) he;
+                    break;
+                }
+                *seen = progress_word(st0.launches, (int) gen, st0.done != 0, st0.count);
+                if (st0.launches < enqueued && now_s() - t_progress > 10.0) {
+                    rc = KIMG_ETIMEOUT; // (everything enqueued has run, and the state says it has not)
+                    break;
+                }
+                continue;
+            }
+            if (now_s() - t_progress > 120.0) {
+                rc = KIMG_ETIMEOUT;     // (the stream is busy with something that does not end)
                 break;
             }
-            *seen = progress_word(st0.launches, (int) gen, st0.done != 0, st0.count);
-            if (now_s() - t_progress > 30.0) {
-                rc = KIMG_ETIMEOUT;
-                break;
-            }
-            continue;
         }
         sched_yield();
     }
