@@ -79,6 +79,33 @@ def test_multi_many_sources(G, P, mode, border, patch, n_sources, cycles, compon
         assert launches < 0.7 * cycles, launches     # several components per launch did happen
 
 
+@pytest.mark.parametrize('P,mode', [(1, 0), (2, 1)])
+def test_multi_bench_image_vs_oracle(P, mode):
+    """The bench's CLEAN problem at its true size -- 4096^2, 200 sources of similar brightness
+    convolved with the PSF + noise, 133 x 111 patch, 1000 cycles, i.e. about 140 launches of 7
+    components, a handful of them with the list of best tiles rebuilt -- and a bright source on top
+    that takes the first few dozen cycles alone (every plan beyond it is mispredicted): components,
+    residual image, model and tile arrays against the restated CleanHost, bit for bit."""
+    G = 4096
+    rs = np.random.RandomState(4)
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
+    psf = np.outer(g1, g1)[None].repeat(P, axis=0).astype(np.float32)
+    psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
+    psf[:, G // 2, G // 2] = 1.0
+    sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
+    for i in range(200):
+        y, x = rs.randint(100, G - 100, 2)
+        amp = rs.uniform(0.5, 2.0) if i else 30.0
+        sky[:, y - 30:y + 31, x - 30:x + 31] += amp * psf[:, G // 2 - 30:G // 2 + 31, G // 2 - 30:G // 2 + 31]
+    fn, q = _clean(G, P, mode, 0.02, 0.1, sky, psf, None)
+    patch = (P, 111, 133)
+    want = reference_run(G, 0.02, 0.1, mode, sky, psf, patch, 0.0, 1000)
+    got = fn.run_cycles(patch, 0.0, 1000)
+    _check(fn, q, got, want)
+    launches = fn.last_launches()
+    assert launches is not None and launches < 300, launches
+
+
 def test_multi_continues_and_stops():
     """Consecutive calls continue where the last one stopped; thresholds and cycle limits stop the
     loop at exactly the reference's component, whatever had been planned beyond it."""
