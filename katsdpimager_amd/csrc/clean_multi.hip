@@ -1472,8 +1472,10 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             need = 2 * MULTI_GRAPH - in_flight;
         if (in_flight == 0 && need < 2)
             need = 2;
+#ifndef KIMG_MC_NO_GRAPH
         if (need >= MULTI_GRAPH && !graph)
             graph = multi_graph_for(a, s);
+#endif
         if (need >= MULTI_GRAPH && graph) {
             he = hipGraphLaunch(graph->exec, s);
             if (he != hipSuccess)

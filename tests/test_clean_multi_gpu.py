@@ -62,6 +62,7 @@ def test_multi_fuzz(seed, components):
     (512, 4, 0, 0.1, (95, 31), 60, 150, 4),
     (1024, 1, 0, 0.02, (161, 191), 50, 200, 0),      # 7 x 7 = 49 blocks: four components per launch
     (1024, 1, 0, 0.02, (225, 321), 50, 120, 0),      # 9 x 12 = 108 blocks: two per launch
+    (1536, 1, 0, 0.02, (351, 415), 60, 100, 0),      # 12 x 14 = 168 blocks: one per launch
     (1024, 1, 0, 0.013, (65, 97), 120, 400, 0),      # border 13
 ])
 def test_multi_many_sources(G, P, mode, border, patch, n_sources, cycles, components):

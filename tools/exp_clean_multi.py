@@ -2,23 +2,28 @@
 one-launch-per-cycle form, by the cap on the components per launch, on the bench's CLEAN image
 (4096^2, 200 point sources (x) PSF + noise), with the launches taken and the components per launch.
 
-    python tools/exp_clean_multi.py [patch height] [patch width] [cycles]"""
+    python tools/exp_clean_multi.py [patch height] [patch width] [cycles] [image size] [polarizations]"""
 import os
 import sys
 import time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from katsdpimager_amd import _lib as _kl
+if os.environ.get('KIMG_VARIANT_LIB'):
+    _kl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build_variants',
+                                'libkimg_%s.so' % os.environ['KIMG_VARIANT_LIB'])
 from katsdpimager_amd import accel, clean, parameters
 
 ph = int(sys.argv[1]) if len(sys.argv) > 1 else 111
 pw = int(sys.argv[2]) if len(sys.argv) > 2 else 133
 cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-G, P = 4096, 1
+G = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 ctx = accel.create_some_context()
 q = ctx.create_command_queue()
 rs = np.random.RandomState(4)
 g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
-psf = np.outer(g1, g1)[None].astype(np.float32)
+psf = np.outer(g1, g1)[None].repeat(P, axis=0).astype(np.float32)
 psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
 psf[:, G // 2, G // 2] = 1.0
 sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
@@ -32,7 +37,7 @@ class _IP:      # what CleanTemplate.instantiate reads of the image parameters
     pixels = G
 
     class fixed:
-        polarizations = [0]
+        polarizations = list(range(P))
         real_dtype = np.float32
 
 
