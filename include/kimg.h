@@ -366,7 +366,7 @@ int kimg_convolve_beam(float *image, int64_t row_stride, int size, float amplitu
                        float b, float c, void *workspace, size_t workspace_bytes, void *stream);
 
 /* 2-D complex-to-complex FFT plans (katsdpsigproc.fft.FftTemplate, image.py:585-600,629,698)
- * on rocFFT through hipFFT; unnormalised, in place.  direction: -1 forward, +1 inverse. */
+ * on rocFFT (called directly); unnormalised, in place.  direction: -1 forward, +1 inverse. */
 int kimg_fft_plan_create(void **plan, int size_y, int size_x);
 int kimg_fft_exec(void *plan, void *layer, int direction, void *stream);
 int kimg_fft_plan_destroy(void *plan);

@@ -3,7 +3,7 @@
 The HIP extension is mandatory: there is no CPU fallback.  ``lib()`` raises
 :class:`KimgLibraryError` if the shared library has not been built or cannot
 be loaded.  PyTorch-ROCm is imported first so that libkimg.so resolves the HIP
-runtime and hipFFT already loaded by torch (same SONAMEs) -- device pointers
+runtime and rocFFT already loaded by torch (same SONAMEs) -- device pointers
 and streams created by torch are then valid inside the library.
 """
 import ctypes
@@ -122,7 +122,7 @@ def lib():
             'libkimg.so has not been built (run `python -m katsdpimager_amd.build`); '
             'katsdpimager_amd has no CPU fallback')
     try:
-        import torch  # noqa: F401  (loads torch's libamdhip64 / libhipfft first)
+        import torch  # noqa: F401  (loads torch's libamdhip64 / librocfft first)
     except ImportError:
         pass
     try:

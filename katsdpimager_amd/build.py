@@ -53,7 +53,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on ' + src)
-    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lhipfft']
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lrocfft']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

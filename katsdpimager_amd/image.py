@@ -188,7 +188,7 @@ class _PlanPool:
     """Idle rocFFT plans by shape.  Creating and destroying a 2-D plan costs ~7 + ~11 ms of host
     time, more than the device work of a small channel, so a plan released by one channel's
     ``Imaging`` is handed to the next one instead of being destroyed.  A plan is owned by one
-    :class:`FftPlan` at a time (hipfftSetStream + exec on a shared plan is not thread safe)."""
+    :class:`FftPlan` at a time (a plan carries ONE execution info: set-stream + execute on a shared plan is not thread safe)."""
     MAX_IDLE = 4
 
     def __init__(self):

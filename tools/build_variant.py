@@ -28,5 +28,5 @@ for src in build.SOURCES:
 for p in procs:
     assert p.wait() == 0
 lib = os.path.join(out_dir, 'libkimg_%s.so' % name)
-subprocess.check_call([build.hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-lhipfft'])
+subprocess.check_call([build.hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-lrocfft'])
 print(lib)
