@@ -958,6 +958,50 @@ def other_configs(args, ctx, q, dev):
         out['c4'] = one(8192, 64, 4, 0.30, 12)
         out['c4']['workload'] = ('C4: 8192^2 image, 64 W-planes, 4 polarizations, K={}, {} vis, one '
                                  'pass = all polarizations').format(args.kernel_width, args.vis)
+        out['c4'].update(c4_clean(args, ctx, q))
+    return out
+
+
+def c4_clean(args, ctx, q):
+    """CLEAN at BASELINE config 4's image: 8192^2, four polarizations, sum-of-squares peak metric
+    (clean.py:28-31), 200 sources (x) PSF + noise, 133 x 111 patch: minor cycles per second of the
+    device-resident loop (read-back included) as `auto` runs it and with one component per launch."""
+    from katsdpimager_amd import clean, parameters
+    G, P = 8192, 4
+    rs = np.random.RandomState(14)
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 6.0) ** 2).astype(np.float32)
+    psf = np.repeat(np.outer(g1, g1)[None].astype(np.float32), P, axis=0)
+    sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
+    h = 30
+    for _ in range(200):
+        y, x = rs.randint(100, G - 100, 2)
+        amp = (rs.uniform(0.5, 2.0) * np.array([1.0, 0.3, -0.2, 0.1], np.float32))[:, None, None]
+        sky[:, y - h:y + h + 1, x - h:x + h + 1] += amp * psf[:, G // 2 - h:G // 2 + h + 1, G // 2 - h:G // 2 + h + 1]
+    fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
+    ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
+    cp = parameters.CleanParameters(args.clean_cycles, 0.1, 0.85, 5.0, 1, 0.01, 0.5, 0.02)
+    out = {}
+    patch = (P, 111, 133)
+    for name, tuning in (('clean_cycles_per_s', None), ('clean_one_component_per_launch_cycles_per_s',
+                                                        {'form': 'one_launch'})):
+        op = clean.CleanTemplate(ctx, cp, np.float32, P, tuning).instantiate(q, ip)
+        op.ensure_all_bound()
+        op.buffer('psf').set(q, psf)
+        best = 0.0
+        for rep in range(2):
+            op.buffer('dirty').set(q, sky)
+            op.buffer('model').zero(q)
+            op.reset()
+            q.finish()
+            t0 = time.perf_counter()
+            op.run_cycles(patch, 0.0, args.clean_cycles, collect=False)
+            done = len(op._collect_cycle_arrays()[0])
+            q.finish()
+            best = max(best, done / (time.perf_counter() - t0))
+        out[name] = round(best, 1)
+        if tuning is None and op.last_launches():
+            out['clean_components_per_launch'] = round(args.clean_cycles / op.last_launches(), 2)
+        del op
     return out
 
 
