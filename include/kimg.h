@@ -83,8 +83,14 @@ extern "C" {
                                      * results bit-identical to the other forms.  At most 256 lattice
                                      * blocks per patch (8 components per launch up to 32 blocks, 4
                                      * up to 64, 2 up to 128) and 2047 tiles per axis; falls back to
-                                     * AUTO's other choices otherwise.  `form | n << 8` caps the
-                                     * components per launch at n (1..8).  AUTO takes this form when
+                                     * AUTO's other choices otherwise.  A planned component may be
+                                     * stepped several times in a launch (its peak's value follows a
+                                     * scalar recursion every workgroup evaluates; up to 8 steps, 4
+                                     * with several polarizations).  `form | n << 8` caps the
+                                     * components per launch at n (1..8), `| r << 16` the steps per
+                                     * component at r (1..8; the loop goes over to repeated steps
+                                     * only while it sees few components per launch: `| 1 << 20`
+                                     * makes it take them from the first launch on).  AUTO takes this form when
                                      * at least 2 components fit and at least 4 cycles are asked for.
                                      * HOST-PACED: the number of launches depends on the data, so the
                                      * call watches a progress word the device writes and returns

@@ -345,14 +345,19 @@ class CleanTemplate:
     """clean.py:729-753.  ``tuning`` may hold ``{'form': 'auto'|'two_launch'|'one_launch'|
     'persistent'|'one_workgroup'|'multi'}``, the form of the device-resident loop of :meth:`Clean.run_cycles`
     (results are identical; ``auto`` takes the fastest one the PSF patch allows), and with ``multi``
-    ``'components'``: the most components a launch may plan (1 to 8, default 8)."""
+    ``'components'``: the most lattices a launch may plan (1 to 8, default 8); ``'repeats'``: the
+    most steps it may take at one peak (1 to 8, default: as many as the form takes -- 8, or 4 with
+    several polarizations; the loop takes repeated steps only while the field shows few components per
+    launch, ``'repeats_always'``: from the first launch on, whatever the field looks like)."""
     def __init__(self, context, clean_parameters, dtype, num_polarizations, tuning=None):
         types.require_float32(dtype, 'CleanTemplate')
         tuning = tuning or {}
-        if set(tuning) - {'form', 'components'} or tuning.get('form', 'auto') not in CLEAN_FORMS \
-                or not 0 <= int(tuning.get('components', 0)) <= 8:
+        if set(tuning) - {'form', 'components', 'repeats', 'repeats_always'} or tuning.get('form', 'auto') not in CLEAN_FORMS \
+                or not 0 <= int(tuning.get('components', 0)) <= 8 \
+                or not 0 <= int(tuning.get('repeats', 0)) <= 8:
             raise ValueError('bad CleanTemplate tuning {}'.format(tuning))
-        self.form = CLEAN_FORMS[tuning.get('form', 'auto')] | int(tuning.get('components', 0)) << 8
+        self.form = CLEAN_FORMS[tuning.get('form', 'auto')] | int(tuning.get('components', 0)) << 8 \
+            | int(tuning.get('repeats', 0)) << 16 | (1 << 20 if tuning.get('repeats_always') else 0)
         self.context = context
         self.clean_parameters = clean_parameters
         self.dtype = np.dtype(dtype)

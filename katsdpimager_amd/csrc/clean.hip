@@ -2277,7 +2277,10 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
                    && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
     KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
-    const int components = (form >> 8) & 0xff;      // KIMG_CLEAN_FORM_MULTI: components per launch
+    const int components = (form >> 8) & 0xff;      // KIMG_CLEAN_FORM_MULTI: lattices per launch
+    // ... and steps per lattice (0: as many as the form takes); bit 4: the repeated-steps kernel from
+    // the first launch on, whatever the field looks like (tests)
+    const int repeats = (form >> 16) & 0x1f;
     form &= 0xff;
     KIMG_CHECK_ARG(form == KIMG_CLEAN_FORM_AUTO || form == KIMG_CLEAN_FORM_TWO_LAUNCH
                    || form == KIMG_CLEAN_FORM_ONE_LAUNCH || form == KIMG_CLEAN_FORM_PERSISTENT
@@ -2294,7 +2297,7 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                 dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf,
                 psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
                 border, mode, loop_gain, threshold, tile_max, tile_pos, tiles_x, tiles_y,
-                max_cycles, components, state, log, s);
+                max_cycles, components, repeats, state, log, s);
             if (rc != KIMG_EUNSUPPORTED)
                 return rc;
         }

@@ -50,7 +50,10 @@ namespace {
 typedef unsigned long long mkey_t;
 
 constexpr int TILE = 32;                // clean.py:996
-constexpr int MC_MAX = 8;               // components per launch
+constexpr int MC_MAX = 8;               // lattices per launch
+constexpr int MC_STEPS = 8;             // subtractions at one peak per launch (4 with several polarizations)
+constexpr int MC_COOL = 4;              // launches with single steps after repeated ones went wrong: twice this, ...
+constexpr int MC_COOL_MAX = 64;         // ... doubled each time in a row up to this
 constexpr int MC_THREADS = 256;         // threads of a workgroup = records of a launch
 constexpr int MC_REST = 24;             // entries of the list (lanes 8 .. 31 of a wave load one each)
 constexpr int MC_POOL_REST = 8;         // of which the first that survive enter the candidate pool
@@ -166,9 +169,10 @@ struct __attribute__((aligned(16))) mc_state {      // written by the keeper of 
     int launches;
     mkey_t rest_floor;      // for a reader of the first MC_REST entries: every other tile has a key <= this
     int gen;                // the call's tag in the progress word
-    int pad;
+    int aux;                // most steps of a planned lattice | launches of single steps left << 8 | penalty << 16
     mkey_t top_floor;       // every tile that is not in `top` has a key <= this
-    mkey_t pad2;
+    int repeated;           // steps committed so far beyond the first of their lattice and launch
+    int pad2;
     mc_record plan[MC_MAX]; // the planned components: key + pixel values at the peak
     mc_record top[MC_TOP];  // the best tiles of the image, sorted: key + pixel values at the tile's peak
 };
@@ -191,7 +195,8 @@ struct mc_geom {
     int tiles_x, tiles_y;
     int lat_x, lat_y;       // lattice blocks of a patch
     int seg;                // record slots per lattice: a power of two >= 16
-    int mmax;               // components per launch
+    int mmax;               // lattices per launch
+    int rmax;               // steps per lattice and launch
     float loop_gain;
 };
 
@@ -376,7 +381,6 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
                 if (na <= MC_REST)
                     next->rest_floor = old_floor;
                 next->tau = tau;
-                next->pad2 = 0;
             }
             MC_STAMP(9);
             MC_COUNT(14, na);
@@ -592,7 +596,6 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
         if (nvalid <= MC_REST)
             next->rest_floor = gathered;
         next->tau = tau;
-        next->pad2 = 0;
     }
     MC_STAMP(10);
 }
@@ -600,6 +603,10 @@ __device__ __attribute__((always_inline)) inline void mc_build_rest(
 // ---- what every workgroup of a launch works out for itself --------------------------------------
 struct mc_lds {
     mkey_t row[16], row2[16];           // per 16 records: best key; best of the non-best
+    unsigned rowf[16];                  // per 16 records: the fail bits of their blocks
+    unsigned fails[MC_THREADS / 64];    // block reduction of the pixel phase: fail bits
+    __attribute__((aligned(16))) mkey_t seqk[MC_MAX * MC_STEPS];   // keeper: the committed steps' keys
+    float seqp[MC_MAX * MC_STEPS][4];   // ... and the pixel values at the peak before each step
     float row_pix[16][4];               // pixel values of a row's best record
     mc_record pool[MC_THREADS / 64][MC_POOL_REST];      // per wave: the list's surviving entries
     mkey_t keys[MC_THREADS / 64];       // block reduction of the pixel phase
@@ -608,33 +615,64 @@ struct mc_lds {
 constexpr int ROLE_KEEPER = 0, ROLE_FOLDER = 1, ROLE_LISTER = 2, ROLE_NEW = 3, ROLE_COMMIT = 4;
 
 
-// One block of pixels: dirty (+ a pending subtraction, written back) (- a planned subtraction, in
-// registers), and the block's tile record after it.  256 threads, four pixels each in row-major
-// order (first strict maximum in that order, clean.py:953-958).
-// PMAX: 1 when there is one polarization (no loop over planes, a third of the instructions), else 4.
+// One subtraction at a peak, as the lattice workgroups compute it for that pixel (clean.py:1044-1046:
+// scale = gain * value, separately rounded product with the PSF's centre): v becomes the values
+// after it; returns the metric there.
 template <int MODE, int PMAX>
+__device__ inline float mc_peak_step(float (&v)[PMAX], const float (&centre)[PMAX], float gain, int P)
+{
+    float metric = 0.0f;
+#pragma unroll
+    for (int p = 0; p < PMAX; p++) {
+        if (PMAX == 1 || p < P) {
+            const float scale = gain * v[p];
+            const float t = scale * centre[p];
+            v[p] -= t;
+            if (MODE == KIMG_CLEAN_I) {
+                if (p == 0)
+                    metric = fabsf(v[0]);
+            } else {
+                metric += v[p] * v[p];
+            }
+        }
+    }
+    return metric;
+}
+
+// One block of pixels: dirty (+ the pending subtractions of a committed lattice, written back) (- the
+// steps of a planned lattice, in registers), and the block's tile record after them.  256 threads,
+// four pixels each in row-major order (first strict maximum in that order, clean.py:953-958).
+// Between the steps of the planned lattice every pixel is held against the value the peak has by
+// then (`peak_bits`, metric bits after k steps): a pixel that comes before the peak in the
+// reference's order (larger metric, lower tile, earlier pixel) sets fail bit k of the record.
+// PMAX: 1 when there is one polarization (no loop over planes, a third of the instructions), else 4.
+template <int MODE, int PMAX, int STEPS>
 __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, const float *__restrict__ psf, const mc_geom &g,
-                                int tx, int ty, bool has_pend, int pend_y, int pend_x,
-                                const float *pend_scale, bool has_new, int new_y, int new_x,
-                                const float *new_scale, mc_record *out, mc_lds &s,
-                                long long *dbg_v, long long dbg_t0)
+                                int tx, int ty, int pend_n, int pend_y, int pend_x,
+                                const float (&pend_scale)[STEPS][PMAX], bool has_new, int new_n, int new_y,
+                                int new_x, const float (&new_scale)[STEPS][PMAX],
+                                const unsigned (&peak_bits)[STEPS], int peak_tile, int peak_idx,
+                                mc_record *out, mc_lds &s, long long *dbg_v, long long dbg_t0)
 {
     const int tid = threadIdx.x;
     const int ox = tx * TILE + g.border, oy = ty * TILE + g.border;
     const bool is_tile = tx >= 0 && tx < g.tiles_x && ty >= 0 && ty < g.tiles_y;
+    const bool has_pend = pend_n > 0;
     const int ax0 = pend_x - g.patch_w / 2, ay0 = pend_y - g.patch_h / 2;      // clean.py:1024-1027
     const int bx0 = new_x - g.patch_w / 2, by0 = new_y - g.patch_h / 2;
     const int adx = g.psf_w / 2 - pend_x, ady = g.psf_h / 2 - pend_y;          // psf index = image index + d
     const int bdx = g.psf_w / 2 - new_x, bdy = g.psf_h / 2 - new_y;
     float dv[4][PMAX], pa[4][PMAX], pb[4][PMAX];
-    bool inside[4], in_a[4], in_b[4];
+    bool inside[4], in_a[4], in_b[4], in_tile[4];
     const int x = ox + (tid & 31);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int y = oy + (tid >> 5) + 8 * k;
         inside[k] = x >= 0 && x < g.width && y >= 0 && y < g.height;
         in_a[k] = has_pend && inside[k] && x >= ax0 && x < ax0 + g.patch_w && y >= ay0 && y < ay0 + g.patch_h;
-        in_b[k] = has_new && inside[k] && x >= bx0 && x < bx0 + g.patch_w && y >= by0 && y < by0 + g.patch_h;
+        in_b[k] = has_new && new_n > 0 && inside[k] && x >= bx0 && x < bx0 + g.patch_w && y >= by0
+                  && y < by0 + g.patch_h;
+        in_tile[k] = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
         const int64_t ia = (int64_t) y * g.row_stride + x;
 #pragma unroll
         for (int p = 0; p < PMAX; p++) {
@@ -658,23 +696,82 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
         best = 1.0f;                    // (the loads have to complete before the stamp)
     MC_STAMP(6);
 #endif
+    // the pending steps, one after the other (each was a cycle of its own: clean.py:1044-1046, two
+    // roundings per step), written back
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+        if (st < pend_n) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int p = 0; p < PMAX; p++) {
+                    if ((PMAX == 1 || p < g.P) && in_a[k]) {
+                        const float t = pend_scale[st][p] * pa[k][p];
+                        dv[k][p] -= t;
+                    }
+                }
+            }
+        }
+    }
+    if (has_pend) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = oy + (tid >> 5) + 8 * k;
+            const int64_t ia = (int64_t) y * g.row_stride + x;
+#pragma unroll
+            for (int p = 0; p < PMAX; p++)
+                if ((PMAX == 1 || p < g.P) && in_a[k])
+                    dirty[p * g.pol_stride + ia] = dv[k][p];
+        }
+    }
+    // the planned steps, in registers; between them, is the peak still the first pixel of its lattice?
+    unsigned fail = 0;
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+        if (st < new_n) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int p = 0; p < PMAX; p++) {
+                    if ((PMAX == 1 || p < g.P) && in_b[k]) {
+                        const float t = new_scale[st][p] * pb[k][p];
+                        dv[k][p] -= t;
+                    }
+                }
+            }
+            if (STEPS > 1 && st + 1 < new_n) {
+                const int t = ty * g.tiles_x + tx;
+                bool beaten = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float metric = 0.0f;
+#pragma unroll
+                    for (int p = 0; p < PMAX; p++) {
+                        if (PMAX == 1 || p < g.P) {
+                            if (MODE == KIMG_CLEAN_I) {
+                                if (p == 0)
+                                    metric = fabsf(dv[k][0]);
+                            } else {
+                                metric += dv[k][p] * dv[k][p];
+                            }
+                        }
+                    }
+                    // (non-negative floats order like their bit patterns)
+                    const unsigned bits = __float_as_uint(metric);
+                    const bool ties = t < peak_tile || (t == peak_tile && tid + 256 * k < peak_idx);
+                    beaten = beaten || (in_tile[k] && (bits > peak_bits[st + 1] || (bits == peak_bits[st + 1] && ties)));
+                }
+                if (__builtin_amdgcn_ballot_w64(beaten))
+                    fail |= 1u << (st + 1);
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int y = oy + (tid >> 5) + 8 * k;
-        const int64_t ia = (int64_t) y * g.row_stride + x;
         float metric = 0.0f;
 #pragma unroll
         for (int p = 0; p < PMAX; p++) {
             if (PMAX == 1 || p < g.P) {
-                if (in_a[k]) {
-                    const float t = pend_scale[p] * pa[k][p];      // clean.py:1044-1046: two roundings
-                    dv[k][p] -= t;
-                    dirty[p * g.pol_stride + ia] = dv[k][p];
-                }
-                if (in_b[k]) {
-                    const float t = new_scale[p] * pb[k][p];
-                    dv[k][p] -= t;
-                }
                 if (MODE == KIMG_CLEAN_I) {
                     if (p == 0)
                         metric = fabsf(dv[k][0]);
@@ -683,8 +780,7 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
                 }
             }
         }
-        const bool in_tile = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
-        if (in_tile && metric > best) {
+        if (in_tile[k] && metric > best) {
             best = metric;
             best_k = k;
         }
@@ -705,14 +801,17 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
     mkey_t k = best_k >= 0 ? ((mkey_t) __float_as_uint(best) << 32) | (unsigned) ~(tid + 256 * best_k) : 0;
     k = row_max(k);
     const mkey_t w = kmax(kmax(lane_key(k, 0), lane_key(k, 16)), kmax(lane_key(k, 32), lane_key(k, 48)));
-    if ((tid & 63) == 0)
+    if ((tid & 63) == 0) {
         s.keys[tid >> 6] = w;
+        s.fails[tid >> 6] = fail;       // (wave-uniform)
+    }
     lds_barrier();
     const mkey_t tb = kmax(kmax(s.keys[0], s.keys[1]), kmax(s.keys[2], s.keys[3]));
     const int widx = ~(int) (unsigned) tb;
     if (tb == 0 ? tid == 0 : tid == (widx & 255)) {
         mc_record o;
-        o.pad[0] = o.pad[1] = 0;
+        o.pad[0] = (int) (s.fails[0] | s.fails[1] | s.fails[2] | s.fails[3]);
+        o.pad[1] = 0;
         if (tb == 0) {
             // no positive metric: value 0 and the (x0, y0) position of clean.py:950, which the key
             // implies; the pixel there is read when (if ever) this tile wins
@@ -732,7 +831,12 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
     MC_STAMP(7);
 }
 
-template <int MODE, int PMAX>
+// STEPS: the most steps a lattice takes per launch.  Two instances are built: STEPS = 1 plans and
+// verifies single steps only and is what a field of many comparable sources needs (everything that
+// serves the repeated steps costs a launch 1.5 us of instruction issue); STEPS = 8 (4 with several
+// polarizations) is for fields with a few dominant sources.  Either reads what the other leaves behind
+// as long as the plan it finds has single steps (the host sees to that: kimg_clean_multi_run).
+template <int MODE, int PMAX, int STEPS>
 __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     float *dirty, float *model, const float *__restrict__ psf, float *tile_max, int32_t *tile_pos,
     mc_geom g, mc_scratch *scratch, int parity, float *log, unsigned long long *progress)
@@ -776,9 +880,10 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     // ---- round trip 1: state, this thread's record, the previous plan and the list ----------
     const int4 st = *reinterpret_cast<const int4 *>(cur);                  // count, done, limit, threshold
     const int4 st2 = *reinterpret_cast<const int4 *>(&cur->planned);       // planned, rest_n, tau, launches
-    const int4 st3 = *reinterpret_cast<const int4 *>(&cur->rest_floor);    // floor, gen
+    const int4 st3 = *reinterpret_cast<const int4 *>(&cur->rest_floor);    // floor, gen, aux
     const mkey_t rest_floor = ((mkey_t) (unsigned) st3.y << 32) | (unsigned) st3.x;
     const int gen = st3.z;
+    const int steps_max = st3.w & 0xff, cool = (st3.w >> 8) & 0xff, penalty = (st3.w >> 16) & 0xff;
     const mc_record *dp = &scratch->deltas[parity][tid];
     const int4 d0 = reinterpret_cast<const int4 *>(dp)[0];
     const int4 d1 = reinterpret_cast<const int4 *>(dp)[1];
@@ -786,7 +891,16 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     const mc_record *pp = l < MC_MAX ? &cur->plan[l] : &cur->top[l - MC_MAX];
     const int4 p0 = reinterpret_cast<const int4 *>(pp)[0];
     const int4 p1 = reinterpret_cast<const int4 *>(pp)[1];
+    // the PSF's centre: what a subtraction does to the value at its own peak
+    float centre[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; p++)
+        centre[p] = (STEPS > 1 && (PMAX == 1 || p < g.P))
+                        ? psf[p * g.psf_pol_stride + (int64_t) (g.psf_h / 2) * g.psf_row_stride + g.psf_w / 2]
+                        : 0.0f;
     int4 old0 = make_int4(0, 0, 0, 0), old1 = old0, st4 = old0;
+    // (the keeper's own share: the count it carries on)
+    const int repeated0 = (role == ROLE_KEEPER && tid == 0) ? cur->repeated : 0;
     if (role == ROLE_LISTER) {
         // the lister's own share of the round trip: its entry of the list, the list's floor
         if (tid < MC_TOP) {
@@ -804,6 +918,8 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             *reinterpret_cast<int4 *>(next) = st;
             *reinterpret_cast<int4 *>(&next->planned) = make_int4(0, 0, tau, st2.w + 1);
             next->gen = gen;
+            next->aux = 0;
+            next->repeated = repeated0;
             if (progress)
                 __hip_atomic_store(progress, progress_word(st2.w + 1, gen, true, count0),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -821,51 +937,148 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     const mkey_t pkey = ((mkey_t) (unsigned) p0.y << 32) | (unsigned) p0.x;
     const float ppix[4] = {__int_as_float(p0.z), __int_as_float(p0.w), __int_as_float(p1.x),
                            __int_as_float(p1.y)};
+    const bool planned_lane = lane < MC_MAX && lane < Mp;       // this lane holds a component of the plan
+    const int pr = planned_lane ? p1.z : 0;                     // ... of so many steps
     // this lane's record as a candidate: its tile and the lattice of the component it would make
     const mc_cand pc = mc_decode(pkey, g.border);
     const int plx = lat_origin(pc.x, g.patch_w, g.border), ply = lat_origin(pc.y, g.patch_h, g.border);
     {
-        // first exchange: the best record of every 16, with its pixel values
+        // first exchange: the best record of every 16, with its pixel values; the fail bits
         const mkey_t r = row_max(dkey);
         if (e == 0)
             s.row[tid >> 4] = r;
         if (dkey != 0 && dkey == r)
             *reinterpret_cast<float4 *>(s.row_pix[tid >> 4]) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
+        if (STEPS > 1 && steps_max > 1) {
+            unsigned f = live ? (unsigned) d1.z : 0u;
+            f |= (unsigned) __builtin_amdgcn_mov_dpp((int) f, 0xB1, 0xf, 0xf, true);
+            f |= (unsigned) __builtin_amdgcn_mov_dpp((int) f, 0x4E, 0xf, 0xf, true);
+            f |= (unsigned) __builtin_amdgcn_mov_dpp((int) f, 0x141, 0xf, 0xf, true);
+            f |= (unsigned) __builtin_amdgcn_mov_dpp((int) f, 0x140, 0xf, 0xf, true);
+            if (e == 0)
+                s.rowf[tid >> 4] = f;
+        }
+    }
+    // (meanwhile) the value at each planned peak before its step s: kq[s], with the pixel values
+    // pq[s] -- the scalar recursion of mc_peak_step, as far as any lattice of the plan goes
+    mkey_t kq[STEPS + 1];
+    float pq[STEPS][PMAX];
+#pragma unroll
+    for (int st_ = 0; st_ < STEPS; st_++) {
+        kq[st_ + 1] = 0;
+#pragma unroll
+        for (int p = 0; p < PMAX; p++)
+            pq[st_][p] = ppix[p];
+    }
+    kq[0] = pkey;
+    if (STEPS > 1 && steps_max > 1) {
+        float v[PMAX];
+#pragma unroll
+        for (int p = 0; p < PMAX; p++)
+            v[p] = ppix[p];
+#pragma unroll
+        for (int st_ = 1; st_ < STEPS; st_++) {
+            if (st_ < steps_max) {
+                const float m = mc_peak_step<MODE, PMAX>(v, centre, g.loop_gain, g.P);
+                kq[st_] = ((mkey_t) __float_as_uint(m) << 32) | (unsigned) pkey;
+#pragma unroll
+                for (int p = 0; p < PMAX; p++)
+                    pq[st_][p] = v[p];
+            }
+        }
     }
     lds_barrier();
     MC_STAMP(1);
 
-    // ---- verify: the longest prefix of the previous plan that held ------------------------------
+    // ---- verify: the steps of the previous plan that held -------------------------------------------
     mkey_t a = 0;                       // lane e < 8: best record of lattice e ...
     int arow = 0;
-    for (int r = 0; r < q; r++) {
-        const int row = e * q + r;
-        const mkey_t v = e < MC_MAX && row < 16 ? s.row[row & 15] : 0;
-        if (v > a) {
-            a = v;
-            arow = row;
+    unsigned afail = 0;                 // ... and the fail bits of its blocks
+    mkey_t mine = 0;                    // best record of this thread's lattice
+    // (q = 1, 2, 4, 8 or 16 rows per lattice; four reads in flight at a time, none of them conditional)
+    for (int r0 = 0; r0 < q; r0 += 4) {
+        mkey_t v[4], w[4];
+        unsigned f[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[i] = s.row[(e * q + r0 + i) & 15];
+            w[i] = s.row[(li * q + r0 + i) & 15];
+            f[i] = (STEPS > 1 && steps_max > 1) ? s.rowf[(e * q + r0 + i) & 15] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = e * q + r0 + i;
+            const bool valid = e < MC_MAX && r0 + i < q && row < 16;
+            if (valid && v[i] > a) {
+                a = v[i];
+                arow = row;
+            }
+            afail |= valid ? f[i] : 0u;
+            mine = kmax(mine, r0 + i < q ? w[i] : 0);
         }
     }
     const float4 apix = *reinterpret_cast<const float4 *>(s.row_pix[arow & 15]);   // ... and its pixel values
-    mkey_t mine = 0;                    // best record of this thread's lattice
-    for (int r = 0; r < q; r++)
-        mine = kmax(mine, s.row[(li * q + r) & 15]);
-    int j;
-    {
+    // Lattice i allows the steps whose keys are above its level: the key before the step after
+    // which one of its blocks saw the peak beaten (that step itself still held), else whatever
+    // its blocks hold after all of its steps (its own steps are never cut by that).  The steps
+    // above every lattice's level are committed: a prefix of the plan's order.
+    int held;                           // lanes 0 .. 7: steps of this lane's lattice that are committed
+    unsigned fullm, pendm, partm;       // lattices with all / at least one / some but not all steps committed
+    int committed = 0;
+    if (STEPS == 1 || steps_max <= 1) {
+        // Single steps, planned in the order of their keys: component i + 1 held iff the records of
+        // lattices 1 .. i are all below its key (the same as the levels below say: the committed
+        // steps are a prefix).  A plan without steps (lattices evaluated again) is all there.
         mkey_t pre = a;                 // inclusive prefix maximum over lanes 0 .. e of the row
         pre = kmax(pre, kdpp<0x111>(pre));          // row_shr:1
         pre = kmax(pre, kdpp<0x112>(pre));          // row_shr:2
         pre = kmax(pre, kdpp<0x114>(pre));          // row_shr:4
         const mkey_t before = kdpp<0x111>(pre);     // lattices 0 .. e - 1
-        const bool ok = lane < MC_MAX && lane < Mp && (lane == 0 || before < pkey);
-        const unsigned held = (unsigned) __builtin_amdgcn_ballot_w64(ok) & 0xffu;
-        j = __builtin_ctz(~held);       // leading run of ones
+        const bool ok = planned_lane && (lane == 0 || before < pkey);
+        const unsigned run = (unsigned) __builtin_amdgcn_ballot_w64(ok) & 0xffu;
+        const int j = steps_max == 0 ? 0 : __builtin_ctz(~run);       // leading run of ones
+        held = (planned_lane && lane < j) ? 1 : 0;
+        pendm = (1u << j) - 1u;
+        fullm = steps_max == 0 ? (Mp >= 8 ? 0xffu : (1u << Mp) - 1u) : pendm;
+        partm = 0;
+        committed = j;
+    } else {
+        mkey_t level = 0;
+        if (planned_lane && pr > 0) {
+            const unsigned f = afail & ((1u << pr) - 2u);       // bits 1 .. pr - 1
+            mkey_t last = kq[0], cut = kq[0];
+#pragma unroll
+            for (int st_ = 1; st_ < STEPS; st_++) {
+                if (st_ < pr)
+                    last = kq[st_];
+                if (f && st_ == __builtin_ctz(f | 0x80000000u) - 1)
+                    cut = kq[st_];
+            }
+            level = f ? cut - 1 : (a < last - 1 ? a : last - 1);
+        }
+        level = row_max(level);
+        level = lane_key(level, 0);
+        held = 0;
+#pragma unroll
+        for (int st_ = 0; st_ < STEPS; st_++) {
+            if (st_ < steps_max) {
+                const bool ok = st_ < pr && kq[st_] > level;
+                held += ok ? 1 : 0;
+                committed += __builtin_popcountll(__builtin_amdgcn_ballot_w64(planned_lane && ok));
+            }
+        }
+        fullm = (unsigned) __builtin_amdgcn_ballot_w64(planned_lane && held == pr) & 0xffu;
+        pendm = (unsigned) __builtin_amdgcn_ballot_w64(planned_lane && held > 0) & 0xffu;
+        partm = (unsigned) __builtin_amdgcn_ballot_w64(planned_lane && held > 0 && held < pr) & 0xffu;
     }
-    const int count = count0 + j;
+    const int count = count0 + committed;
+    const bool mispredicted = fullm != (Mp >= 8 ? 0xffu : (1u << Mp) - 1u);
+    const bool repair = STEPS > 1 && partm != 0;        // (a plan of single steps is never partly committed)
     MC_STAMP(2);
     if (role == ROLE_FOLDER) {
-        // the committed records go to the base arrays (nobody in this launch reads them there)
-        if (live && li < j) {
+        // the records of wholly committed lattices go to the base arrays (nobody in this launch
+        // reads them there)
+        if (live && (fullm >> li & 1u)) {
             const mc_cand c = mc_decode(dkey, g.border);
             const int t = c.ty * g.tiles_x + c.tx;
             tile_max[t] = c.value;
@@ -875,27 +1088,29 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         return;
     }
     if (role == ROLE_LISTER) {
-        // the list for the next launch, next to (not behind) everybody's planning
+        // the list for the next launch, next to (not behind) everybody's planning: entries inside
+        // lattices whose pixels change go (wholly committed: their records come in; partly: their
+        // records come with the next launch)
+        const bool changing = planned_lane && ((fullm | partm) >> lane & 1u);
         mc_build_rest(tile_max, tile_pos, tile_pix, scratch->deltas[parity], g, tau, 1,
-                      lane < j ? plx : INT_MIN / 2, lane < j ? ply : INT_MIN / 2, j,
-                      (live && li < j) ? dkey : 0, make_float4(dpix[0], dpix[1], dpix[2], dpix[3]), true,
+                      changing ? plx : INT_MIN / 2, changing ? ply : INT_MIN / 2, Mp,
+                      (live && (fullm >> li & 1u)) ? dkey : 0, make_float4(dpix[0], dpix[1], dpix[2], dpix[3]), true,
                       old0, old1, top_n,
                       ((mkey_t) (unsigned) st4.y << 32) | (unsigned) st4.x, next, sr, dbg_v, dbg_t0);
         MC_STAMP(11);
         MC_FLUSH();
         return;
     }
-    if (role == ROLE_COMMIT && comp >= j)
+    if (role == ROLE_COMMIT && !(pendm >> comp & 1u))
         return;
     {
-        const mkey_t second = (live && li < j && dkey != mine) ? dkey : 0;
+        const mkey_t second = (live && (fullm >> li & 1u) && dkey != mine) ? dkey : 0;
         const mkey_t r = row_max(second);
         if (e == 0)
             s.row2[tid >> 4] = r;
     }
     // (meanwhile) which entries of the list survive: those outside every lattice of the previous
     // plan, committed or not -- their values stand; the first MC_POOL_REST of them enter the pool
-    const bool mispredicted = j < Mp;
     bool surv = l >= MC_MAX && l - MC_MAX < rest_n && pkey >= MC_REAL && !mispredicted;
 #pragma unroll
     for (int i = 0; i < MC_MAX; i++) {
@@ -926,25 +1141,53 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     MC_STAMP(3);
 
     // ---- plan -------------------------------------------------------------------------------------
-    mkey_t bound;
-    {
-        const mkey_t r = row_max(s.row2[e]);
-        bound = kmax(lane_key(r, 0), list_floor);
+    // lane e < 8: the best of the records of lattice e that are not its best one (they bound what can
+    // be proven unless the lattice is planned again as it is, see below)
+    mkey_t sec = 0;
+    for (int r0 = 0; STEPS > 1 && r0 < q; r0 += 4) {
+        mkey_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            v[i] = s.row2[(e * q + r0 + i) & 15];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            sec = kmax(sec, (e < MC_MAX && r0 + i < q && e * q + r0 + i < 16) ? v[i] : 0);
     }
     // the pool, one candidate per lane of the first row: the committed lattices' best records and
-    // the surviving entries of the list (after a misprediction: those records and the first
+    // the surviving entries of the list.  After a misprediction: those records and the best
     // component that was not committed, which was the best tile outside the committed lattices;
-    // exactly one component is then planned)
+    // exactly one component is then planned.  With partly committed lattices: those, to be
+    // evaluated again without steps, and nothing else.
     mkey_t cand = 0;
     float cpix[4] = {apix.x, apix.y, apix.z, apix.w};
-    if (e < MC_MAX) {
-        cand = e < j ? a : 0;
-    } else if (mispredicted) {
-        if (e == MC_MAX) {
-            cand = lane_key(pkey, j & 7);
+    // (lanes 0 .. 7 of the wave hold the plan: the best of its lattices without any committed step)
+    mkey_t left = 0;
+    unsigned left_at = 0;
+    float left_pix[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (mispredicted && !repair) {
+        left = (planned_lane && held == 0 && pr > 0) ? pkey : 0;
+        left = lane_key(row_max(left), 0);
+        left_at = (unsigned) __builtin_amdgcn_ballot_w64(planned_lane && left >= MC_REAL && pkey == left);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            left_pix[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ppix[i]),
+                                                                   left_at ? __builtin_ctz(left_at) : 0));
+    }
+    if (repair) {
+        if (lane < MC_MAX && (partm >> lane & 1u)) {
+            cand = pkey;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                cpix[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ppix[i]), j & 7));
+                cpix[i] = ppix[i];
+        }
+    } else if (e < MC_MAX) {
+        cand = (fullm >> e & 1u) ? a : 0;
+    } else if (mispredicted) {
+        if (e == MC_MAX && left_at) {
+            cand = left;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                cpix[i] = left_pix[i];
         }
     } else if (e - MC_MAX < nsurv) {
         const mc_record *r = &s.pool[wave][e - MC_MAX];
@@ -970,15 +1213,11 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     }
     const mc_cand c = mc_decode(sk, g.border);
     const int cbx = lat_origin(c.x, g.patch_w, g.border), cby = lat_origin(c.y, g.patch_h, g.border);
+    if (role == ROLE_NEW)
+        MC_STAMP(8);
     // Everything the walk below needs, as masks over the sorted positions (bit p = candidate p):
     // per-candidate properties by one compare each, and per pivot k the candidates whose tile lies
     // inside lattice k / whose lattice meets lattice k.  The walk itself is scalar and branch-free.
-    const mkey_t overflow = lane_key(sk, MC_MAX);
-    const mkey_t bound2 = kmax(bound, overflow >= MC_REAL ? overflow | 0x3ffu : 0);
-    const unsigned m_real = (unsigned) __builtin_amdgcn_ballot_w64(sk >= MC_REAL) & 0xffu;
-    const unsigned m_above = (unsigned) __builtin_amdgcn_ballot_w64(sk > bound2) & 0xffu;
-    const unsigned m_thr = (unsigned) __builtin_amdgcn_ballot_w64(!(c.value < threshold)) & 0xffu;
-    const unsigned m_zero = (unsigned) __builtin_amdgcn_ballot_w64(c.value == 0.0f) & 0xffu;
     unsigned m_ins[MC_MAX], m_ovl[MC_MAX];
 #pragma unroll
     for (int k = 0; k < MC_MAX; k++) {
@@ -990,10 +1229,52 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
                    & (unsigned) __builtin_amdgcn_ballot_w64(
                        (unsigned) (cby - pby + g.lat_y - 1) < (unsigned) (2 * g.lat_y - 1));
     }
+    // What bounds a proof: the list's floor, the pool's overflow, and the second-best records of
+    // the committed lattices -- except where a lattice's best record is a candidate that would be
+    // planned with the very same lattice and that no earlier candidate's lattice holds: it is then
+    // planned (the other records lie inside a planned lattice, and the next verification covers
+    // them), or the walk ends at or before it (and what ends the walk bounds everything after).
+    if (role == ROLE_NEW)
+        MC_STAMP(9);
+    const mkey_t overflow = lane_key(sk, MC_MAX);
+    mkey_t bound2 = kmax(list_floor, overflow >= MC_REAL ? overflow | 0x3ffu : 0);
+    if (STEPS == 1) {
+        // (single steps: every second-best record bounds)
+        bound2 = kmax(bound2, lane_key(row_max(s.row2[e]), 0));
+    } else {
+        mkey_t second = lane_key(row_max(lane < MC_MAX ? sec : 0), 0);
+        if (second > bound2 && !mispredicted) {
+            bool lifted = false;
+            if (lane < MC_MAX && (fullm >> lane & 1u) && rank < MC_MAX) {
+                const mc_cand ac = mc_decode(a, g.border);
+                const bool same = lat_origin(ac.x, g.patch_w, g.border) == plx
+                                  && lat_origin(ac.y, g.patch_h, g.border) == ply;
+                bool held_by_earlier = false;
+#pragma unroll
+                for (int k = 0; k < MC_MAX; k++)
+                    held_by_earlier = held_by_earlier || (k < rank && (m_ins[k] >> rank & 1u));
+                lifted = same && !held_by_earlier;
+            }
+            second = lane_key(row_max((lane < MC_MAX && !lifted) ? sec : 0), 0);
+        }
+        bound2 = kmax(bound2, second);
+    }
+    if (role == ROLE_NEW)
+        MC_STAMP(10);
+    const unsigned m_real = (unsigned) __builtin_amdgcn_ballot_w64(sk >= MC_REAL) & 0xffu;
+    const unsigned m_above = (unsigned) __builtin_amdgcn_ballot_w64(sk > bound2) & 0xffu;
+    const unsigned m_thr = (unsigned) __builtin_amdgcn_ballot_w64(!(c.value < threshold)) & 0xffu;
+    const unsigned m_zero = (unsigned) __builtin_amdgcn_ballot_w64(c.value == 0.0f) & 0xffu;
     unsigned picked = 0;
     int M = 0;
     bool done_now, zero_special;
-    {
+    unsigned skipped = 0;
+    if (repair) {
+        picked = m_real;
+        M = __builtin_popcount(picked);
+        done_now = false;
+        zero_special = false;
+    } else {
         // (the first candidate is the largest tile of the image if it beats every tile that is not
         // listed; with an entry of the list in the pool it does)
         const bool first_proven = nsurv > 0 || mispredicted || lane_key(sk, 0) > list_floor;
@@ -1014,7 +1295,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             // one whose lattice meets a planned lattice ends the walk; one without any positive
             // metric is taken only alone, and only while nothing is pending (its pixel is read
             // from the image, which must be up to date)
-            const unsigned zero_ok = (p == 0 && j == 0) ? 1u : 0u;
+            const unsigned zero_ok = (p == 0 && pendm == 0) ? 1u : 0u;
             const unsigned take = c1 & ~sk1 & ~st1 & (~z1 | zero_ok) & 1u;
             picked |= take << p;
             M += (int) take;
@@ -1025,12 +1306,109 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             alive &= c1 & ~halt & 1u;
         }
         zero_special = zs != 0;
-        if (!(m_real & 1u) && j == 0 && rest_floor == 0)
+        skipped = skip;
+        if (!(m_real & 1u) && pendm == 0 && rest_floor == 0)
             done_now = true;            // no tiles at all
+    }
+    if (role == ROLE_NEW)
+        MC_STAMP(11);
+    // ---- how many steps each planned lattice takes -------------------------------------------------
+    // The plan is the merge of the planned lattices' sequences sq[0] > sq[1] > ... (the value at the
+    // peak before each of its steps) above a level below which nothing is proven: the bound of the
+    // walk; the first candidate that is neither planned nor inside a planned lattice; for every
+    // planned lattice the value its peak has when it may not be stepped again (the last allowed step,
+    // the threshold, a value that does not come down).
+    mkey_t sq[STEPS + 1];
+    float psq[STEPS][PMAX];
+    int rsteps = 0;                     // lane p < 8: steps of the candidate at sorted position p
+    int next_steps_max = 0;
+#pragma unroll
+    for (int st_ = 0; st_ < STEPS; st_++) {
+        sq[st_ + 1] = 0;
+#pragma unroll
+        for (int p = 0; p < PMAX; p++)
+            psq[st_][p] = spix[p];
+    }
+    sq[0] = sk;
+    if (STEPS == 1) {
+        // (single steps, as the walk planned them; a lattice a higher peak's next value would beat
+        // is found out by the next verification)
+        rsteps = (!repair && lane < MC_MAX && (picked >> lane & 1u)) ? 1 : 0;
+        next_steps_max = (!repair && M > 0) ? 1 : 0;
+    } else if (!repair) {
+        const bool mine_picked = lane < MC_MAX && (picked >> lane & 1u);
+        const int rmax = (mispredicted || zero_special || cool > 0 || limit - count < g.mmax * g.rmax)
+                             ? 1 : min(g.rmax, STEPS);
+        mkey_t level = bound2;
+        {
+            const unsigned u = m_real & ~picked & ~skipped;
+            if (u)
+                level = kmax(level, lane_key(sk, __builtin_ctz(u)) | 0x3ffu);
+        }
+        float v[PMAX];
+#pragma unroll
+        for (int p = 0; p < PMAX; p++)
+            v[p] = spix[p];
+        const float m1 = mc_peak_step<MODE, PMAX>(v, centre, g.loop_gain, g.P);
+        sq[1] = ((mkey_t) __float_as_uint(m1) << 32) | (unsigned) sk;
+        // Nearly always no planned peak is still above the level after one step: one step each, as
+        // the walk planned them (what the rest of this block works out then comes to just that).
+        if (!__builtin_amdgcn_ballot_w64(mine_picked && (sq[1] > level || sq[1] >= sq[0]))) {
+            rsteps = mine_picked ? 1 : 0;
+            next_steps_max = M > 0 ? 1 : 0;
+        } else {
+            int end = 0;                // first step this lattice may not take (0: not known yet)
+            mkey_t lev = 0;
+            int depth = 1;
+            float m = m1;
+#pragma unroll
+            for (int st_ = 1; st_ <= STEPS; st_++) {
+                if (depth == st_) {
+                    if (st_ > 1) {
+                        m = mc_peak_step<MODE, PMAX>(v, centre, g.loop_gain, g.P);
+                        sq[st_] = ((mkey_t) __float_as_uint(m) << 32) | (unsigned) sk;
+                    }
+                    if (st_ < STEPS) {
+#pragma unroll
+                        for (int p = 0; p < PMAX; p++)
+                            psq[st_ < STEPS ? st_ : 0][p] = v[p];
+                    }
+                    if (end == 0 && (st_ == rmax || m < threshold || sq[st_] >= sq[st_ - 1])) {
+                        end = st_;
+                        lev = sq[st_] >= sq[st_ - 1] ? sq[st_ - 1] - 1 : sq[st_];
+                    }
+                    // deeper only while some planned lattice is still above the level there
+                    if (st_ < rmax && __builtin_amdgcn_ballot_w64(mine_picked && end == 0 && sq[st_] > level))
+                        depth = st_ + 1;
+                }
+            }
+            if (end == 0) {
+                // (not above the level at this depth: bounds nothing new)
+                end = depth;
+                lev = 0;
+            }
+            {
+                const mkey_t r = row_max(mine_picked ? lev : 0);
+                level = kmax(level, lane_key(r, 0));
+            }
+#pragma unroll
+            for (int st_ = 0; st_ < STEPS; st_++)
+                if (st_ < depth)
+                    rsteps += (mine_picked && st_ < end && sq[st_] > level) ? 1 : 0;
+            // (the walk's first pick stands where nothing else can be said: it is the largest tile)
+            if ((mispredicted || zero_special) && picked && lane == __builtin_ctz(picked))
+                rsteps = 1;
+            picked = (unsigned) __builtin_amdgcn_ballot_w64(lane < MC_MAX && rsteps > 0) & 0xffu;
+            M = __builtin_popcount(picked);
+#pragma unroll
+            for (int st_ = 1; st_ <= STEPS; st_++)
+                if (st_ <= depth && __builtin_amdgcn_ballot_w64(lane < MC_MAX && rsteps >= st_))
+                    next_steps_max = st_;
+        }
     }
     MC_STAMP(4);
     MC_COUNT(17, M);
-    MC_COUNT(18, j);
+    MC_COUNT(18, committed);
     // the sorted position of planned component m: the m-th set bit of `picked`
     auto position = [&](int m) {
         unsigned x = picked;
@@ -1042,6 +1420,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     auto lane_float = [&](float v, int from) {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
     };
+    const unsigned no_bits[STEPS] = {};
 
     if (role == ROLE_NEW) {
         if (comp >= M)
@@ -1049,33 +1428,58 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         const int p = position(comp);
         const int ny = lane_int(c.y, p), nx = lane_int(c.x, p);
         const int tx = lane_int(cbx, p) + (int) blockIdx.x, ty = lane_int(cby, p) + (int) blockIdx.y;
-        float ns[4];
+        const int nsteps = lane_int(rsteps, p);
+        float ns[STEPS][PMAX];
+        unsigned peak_bits[STEPS];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            ns[i] = lane_float(spix[i], p);
+        for (int st_ = 0; st_ < STEPS; st_++) {
+            peak_bits[st_] = 0;
+#pragma unroll
+            for (int i = 0; i < PMAX; i++)
+                ns[st_][i] = 0.0f;
+            if (st_ < nsteps) {
+                peak_bits[st_] = (unsigned) lane_int((int) (unsigned) (sq[st_] >> 32), p);
+#pragma unroll
+                for (int i = 0; i < PMAX; i++)
+                    ns[st_][i] = g.loop_gain * lane_float(psq[st_][i], p);     // clean.py:1044
+            }
+        }
         if (zero_special) {
             // a tile without any positive metric won: its record holds the (x0, y0) start position
             // of clean.py:950, whose pixel is read now (nothing is pending: the image is up to date)
             const bool ok = ny >= 0 && ny < g.height && nx >= 0 && nx < g.width;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                ns[i] = ok && i < g.P ? dirty[i * g.pol_stride + (int64_t) ny * g.row_stride + nx] : 0.0f;
+            for (int i = 0; i < PMAX; i++)
+                ns[0][i] = g.loop_gain
+                           * (ok && i < g.P ? dirty[i * g.pol_stride + (int64_t) ny * g.row_stride + nx] : 0.0f);
         }
-        // the pending subtraction of a committed lattice that holds this block, if any
+        // the pending steps of a committed lattice that holds this block, if any
         const unsigned hit = (unsigned) __builtin_amdgcn_ballot_w64(
-            lane < j && (unsigned) (tx - plx) < (unsigned) g.lat_x && (unsigned) (ty - ply) < (unsigned) g.lat_y);
+            lane < MC_MAX && (pendm >> lane & 1u) && (unsigned) (tx - plx) < (unsigned) g.lat_x
+            && (unsigned) (ty - ply) < (unsigned) g.lat_y);
         const int pend = hit ? __builtin_ctz(hit) : 0;
-        float ps[4];
+        const int pend_n = hit ? lane_int(held, pend) : 0;
+        float ps[STEPS][PMAX];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            ps[i] = g.loop_gain * lane_float(ppix[i], pend);              // clean.py:1044
-            ns[i] = g.loop_gain * ns[i];
+        for (int st_ = 0; st_ < STEPS; st_++) {
+#pragma unroll
+            for (int i = 0; i < PMAX; i++)
+                ps[st_][i] = 0.0f;
+            if (st_ < pend_n) {
+#pragma unroll
+                for (int i = 0; i < PMAX; i++)
+                    ps[st_][i] = g.loop_gain * lane_float(pq[st_][i], pend);
+            }
         }
+        const unsigned plo = (unsigned) lane_int((int) (unsigned) sk, p);
+        const unsigned ptile = ~(plo >> 10) & 0x3FFFFFu;
         MC_STAMP(5);
-        mc_block<MODE, PMAX>(dirty, psf, g, tx, ty, hit != 0, lane_int(pc.y, pend), lane_int(pc.x, pend), ps,
-                       true, ny, nx, ns,
-                       &scratch->deltas[parity ^ 1][comp * g.seg + (int) blockIdx.y * g.lat_x + (int) blockIdx.x],
-                       s, dbg_v, dbg_t0);
+        mc_block<MODE, PMAX, STEPS>(dirty, psf, g, tx, ty, pend_n, lane_int(pc.y, pend),
+                                    lane_int(pc.x, pend), ps, true, nsteps, ny, nx, ns, peak_bits,
+                                    (int) (ptile >> 11) * g.tiles_x + (int) (ptile & 2047u), (int) (plo & 1023u),
+                                    &scratch->deltas[parity ^ 1][comp * g.seg + (int) blockIdx.y * g.lat_x
+                                                                 + (int) blockIdx.x],
+                                    s, dbg_v, dbg_t0);
         MC_FLUSH();
         return;
     }
@@ -1086,34 +1490,95 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             && (unsigned) (ty - cby) < (unsigned) g.lat_y);
         if (covered)
             return;                     // a workgroup of the new lattice writes this block
-        float ps[4];
+        const int pend_n = lane_int(held, comp);
+        float ps[STEPS][PMAX];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            ps[i] = g.loop_gain * lane_float(ppix[i], comp);
-        mc_block<MODE, PMAX>(dirty, psf, g, tx, ty, true, lane_int(pc.y, comp), lane_int(pc.x, comp), ps, false,
-                       0, 0, ps, nullptr, s, dbg_v, dbg_t0);
+        for (int st_ = 0; st_ < STEPS; st_++) {
+#pragma unroll
+            for (int i = 0; i < PMAX; i++)
+                ps[st_][i] = 0.0f;
+            if (st_ < pend_n) {
+#pragma unroll
+                for (int i = 0; i < PMAX; i++)
+                    ps[st_][i] = g.loop_gain * lane_float(pq[st_][i], comp);
+            }
+        }
+        mc_block<MODE, PMAX, STEPS>(dirty, psf, g, tx, ty, pend_n, lane_int(pc.y, comp),
+                                    lane_int(pc.x, comp), ps, false, 0, 0, 0, ps, no_bits, 0, 0, nullptr, s,
+                                    dbg_v, dbg_t0);
         return;
     }
 
-    // ---- keeper: the committed components, the planned ones, the next state -------------------------
-    if (tid < j) {
-        // (lane tid of wave 0 holds component tid of the previous plan)
-        float *entry = log + (int64_t) (count0 + tid) * (3 + g.P);
-        entry[0] = pc.value;
-        entry[1] = __int_as_float(pc.y);
-        entry[2] = __int_as_float(pc.x);
-        for (int p = 0; p < g.P; p++) {
-            const float sc = g.loop_gain * ppix[p];
-            float *mp = model + p * g.pol_stride + (int64_t) pc.y * g.row_stride + pc.x;
-            entry[3 + p] = sc;
-            *mp += sc;                                          // clean.py:1047
+    // ---- keeper: the committed steps, the planned components, the next state ------------------------
+    // The committed steps in the order of their keys: lane i of wave 0 holds lattice i of the
+    // previous plan; its steps go through LDS to one thread each, which finds its place in the log.
+    if (STEPS == 1 || steps_max <= 1) {
+        // (single steps: the plan is in the order of its keys)
+        if (tid < MC_MAX && held > 0) {
+            float *entry = log + (int64_t) (count0 + __builtin_popcount(pendm & ((1u << tid) - 1u))) * (3 + g.P);
+            entry[0] = pc.value;
+            entry[1] = __int_as_float(pc.y);
+            entry[2] = __int_as_float(pc.x);
+            for (int p = 0; p < g.P; p++) {
+                const float sc = g.loop_gain * ppix[p];
+                float *mp = model + p * g.pol_stride + (int64_t) pc.y * g.row_stride + pc.x;
+                entry[3 + p] = sc;
+                *mp += sc;                                          // clean.py:1047
+            }
+        }
+    } else {
+        if (tid < MC_MAX) {
+#pragma unroll
+            for (int st_ = 0; st_ < STEPS; st_++) {
+                s.seqk[tid * MC_STEPS + st_] = st_ < held ? kq[st_] : 0;
+#pragma unroll
+                for (int p = 0; p < PMAX; p++)
+                    s.seqp[tid * MC_STEPS + st_][p] = pq[st_][p];
+            }
+#pragma unroll
+            for (int st_ = STEPS; st_ < MC_STEPS; st_++)
+                s.seqk[tid * MC_STEPS + st_] = 0;
+            if (held > 0) {
+                for (int p = 0; p < g.P && p < PMAX; p++) {
+                    float *mp = model + p * g.pol_stride + (int64_t) pc.y * g.row_stride + pc.x;
+                    float m = *mp;
+#pragma unroll
+                    for (int st_ = 0; st_ < STEPS; st_++)
+                        if (st_ < held)
+                            m += g.loop_gain * pq[st_][p];          // clean.py:1047
+                    *mp = m;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < MC_MAX * MC_STEPS) {
+            const mkey_t own = s.seqk[tid];
+            if (own >= MC_REAL) {
+                int place = 0;
+                const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(s.seqk);
+#pragma unroll 4
+                for (int i = 0; i < MC_MAX * MC_STEPS; i += 2) {
+                    const ulonglong2 two = pairs[i >> 1];
+                    place += two.x > own ? 1 : 0;
+                    place += two.y > own ? 1 : 0;
+                }
+                // (the position: that of the lattice's first step, whose key is never a made-up one)
+                const mc_cand oc = mc_decode(s.seqk[tid & ~(MC_STEPS - 1)], g.border);
+                float *entry = log + (int64_t) (count0 + place) * (3 + g.P);
+                entry[0] = __uint_as_float((unsigned) (own >> 32));
+                entry[1] = __int_as_float(oc.y);
+                entry[2] = __int_as_float(oc.x);
+                for (int p = 0; p < g.P && p < PMAX; p++)
+                    entry[3 + p] = g.loop_gain * s.seqp[tid][p];
+            }
         }
     }
     if (tid < MC_MAX && (picked >> tid & 1u)) {
         // (lane p of wave 0 holds the candidate at sorted position p)
         mc_record r;
         r.key = sk;
-        r.pad[0] = r.pad[1] = 0;
+        r.pad[0] = rsteps;
+        r.pad[1] = 0;
         const bool ok = c.y >= 0 && c.y < g.height && c.x >= 0 && c.x < g.width;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -1124,15 +1589,34 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         next->plan[__builtin_popcount(picked & ((1u << tid) - 1u))] = r;
     }
     if (tid == 0) {
+        // repeated steps that went wrong cost a launch that commits nothing: single steps for a
+        // while after that, for longer each time in a row
+        int cool_next = cool > 0 && !repair ? cool - 1 : cool, penalty_next = penalty ? penalty : MC_COOL;
+        if (repair) {
+            penalty_next = min(MC_COOL_MAX, 2 * penalty_next);
+            cool_next = penalty_next;
+        } else if (steps_max > 1 && !mispredicted) {
+            penalty_next = MC_COOL;
+        }
         *reinterpret_cast<int4 *>(next) = make_int4(count, done_now ? 1 : 0, limit, st.w);
         next->planned = M;
         next->launches = st2.w + 1;
         next->gen = gen;
+        next->aux = (repair ? 0 : next_steps_max) | cool_next << 8 | penalty_next << 16;
+        const int repeated = repeated0 + committed - __builtin_popcount(pendm);
+        next->repeated = repeated;
+        next->pad2 = 0;
         // (what the host reads goes out last: the word in host memory is a long way off)
         *reinterpret_cast<int4 *>(scratch->head) = make_int4(count, done_now ? 1 : 0, limit, st.w);
-        if (progress)
+        if (progress) {
+            // (the second word first, and only when it moves: whoever sees the launch counted finds
+            // its other figures there)
+            if (STEPS > 1 && repeated != repeated0)
+                __hip_atomic_store(progress + 1, ((unsigned long long) (unsigned) gen << 32) | (unsigned) repeated,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(progress, progress_word(st2.w + 1, gen, done_now, count),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     MC_STAMP(6);
     MC_FLUSH();
@@ -1158,7 +1642,7 @@ __global__ __launch_bounds__(256) void mc_tile_pix_kernel(
 __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_max,
                                                             const int32_t *tile_pos, mc_geom g,
                                                             mc_scratch *scratch, int limit,
-                                                            float threshold, int gen,
+                                                            float threshold, int gen, int mode,
                                                             unsigned long long *progress)
 {
     __shared__ rest_lds sr;
@@ -1181,9 +1665,6 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
         st->gen = gen;
         *reinterpret_cast<int4 *>(scratch->head) = make_int4(0, 0, limit, __float_as_int(threshold));
         scratch->pad[0] = 0x4d554c54;   // "MULT": which form the buffer holds (Clean.last_launches)
-        if (progress)
-            __hip_atomic_store(progress, progress_word(0, gen, false, 0), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef KIMG_MC_STAMPS
     long long dbg_v[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1192,6 +1673,27 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
 #endif
     mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), 128, INT_MIN / 2,
                   INT_MIN / 2, 0, 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), false, make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), 0, 0, st, sr, dbg_v, 0);
+    // What the host starts from (the word of launch 0 carries it in place of a count): how many steps
+    // the eight best tiles could take, each at its own peak, before they are down to the ninth -- a
+    // field with a few sources far above the rest is worth the repeated-steps kernel from the start.
+    __syncthreads();
+    if (tid == 0 && progress) {
+        const int n = st->top_n;
+        const float ref = n > MC_MAX ? __uint_as_float((unsigned) (st->top[MC_MAX].key >> 32))
+                                     : __uint_as_float((unsigned) (st->top_floor >> 32));
+        // (a step takes the value at the peak down by the loop gain; the metric is the value, or its square)
+        const float per_step = -logf(fmaxf(1.0f - g.loop_gain, 1e-3f)) * (mode == KIMG_CLEAN_I ? 1.0f : 2.0f);
+        float steps = 0.0f;
+        for (int i = 0; i < n && i < MC_MAX; i++) {
+            const float v = __uint_as_float((unsigned) (st->top[i].key >> 32));
+            if (ref > 0.0f && v > ref && per_step > 0.0f)
+                steps += fminf(logf(v / ref) / per_step, 1000.0f);
+        }
+        __hip_atomic_store(progress + 1, (unsigned long long) (unsigned) gen << 32, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(progress, progress_word(0, gen, false, (int) steps), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---- host --------------------------------------------------------------------------------------
@@ -1205,21 +1707,29 @@ struct multi_args {
     float *log;
     unsigned long long *progress;
     int mode;
+    int repeats;            // the kernel built for repeated steps (else: single steps)
 };
 
-int enqueue_launch(const multi_args &a, hipStream_t s, int parity)
+// One launch.  `repeats`: with the kernel that plans up to `rmax` steps per lattice (rmax = 1: that
+// kernel, which reads any plan, leaving a plan of single steps behind, which either kernel reads).
+int enqueue_launch(const multi_args &a, hipStream_t s, int parity, bool repeats, int rmax)
 {
     const dim3 grid(a.g.lat_x, a.g.lat_y, 1 + 2 * a.g.mmax);
-#define LAUNCH(MODE, PMAX) cycle_multi_kernel<MODE, PMAX><<<grid, MC_THREADS, 0, s>>>( \
-        a.dirty, a.model, a.psf, a.tile_max, a.tile_pos, a.g, a.scratch, parity, a.log, a.progress)
+    mc_geom g = a.g;
+    g.rmax = repeats ? rmax : 1;
+#define LAUNCH(MODE, PMAX, STEPS) cycle_multi_kernel<MODE, PMAX, STEPS><<<grid, MC_THREADS, 0, s>>>( \
+        a.dirty, a.model, a.psf, a.tile_max, a.tile_pos, g, a.scratch, parity, a.log, a.progress)
+#define LAUNCH2(MODE, PMAX) do { if (repeats) LAUNCH(MODE, PMAX, (PMAX == 1 ? MC_STEPS : MC_STEPS / 2)); \
+                                 else LAUNCH(MODE, PMAX, 1); } while (0)
     if (a.mode == KIMG_CLEAN_I && a.g.P == 1)
-        LAUNCH(KIMG_CLEAN_I, 1);
+        LAUNCH2(KIMG_CLEAN_I, 1);
     else if (a.mode == KIMG_CLEAN_I)
-        LAUNCH(KIMG_CLEAN_I, 4);
+        LAUNCH2(KIMG_CLEAN_I, 4);
     else if (a.g.P == 1)
-        LAUNCH(KIMG_CLEAN_SUMSQ, 1);
+        LAUNCH2(KIMG_CLEAN_SUMSQ, 1);
     else
-        LAUNCH(KIMG_CLEAN_SUMSQ, 4);
+        LAUNCH2(KIMG_CLEAN_SUMSQ, 4);
+#undef LAUNCH2
 #undef LAUNCH
     return kimg_launch_status();
 }
@@ -1261,8 +1771,10 @@ multi_graph *multi_graph_for(const multi_args &a, hipStream_t s)
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return nullptr;
     int rc = 0;
+    // (the last launch of a graph of the repeated-steps kernel plans single steps: whatever comes
+    // next, of either kind, can read what it leaves behind)
     for (int i = 0; i < MULTI_GRAPH && rc == 0; i++)
-        rc = enqueue_launch(a, s, i & 1);
+        rc = enqueue_launch(a, s, i & 1, a.repeats != 0, i == MULTI_GRAPH - 1 ? 1 : a.g.rmax);
     const hipError_t ended = hipStreamEndCapture(s, &graph);
     if (ended != hipSuccess || rc != 0) {
         if (ended == hipSuccess && graph != nullptr)
@@ -1401,8 +1913,8 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          int64_t psf_row_stride, int64_t psf_pol_stride, int psf_width,
                          int psf_height, int patch_width, int patch_height, int border, int mode,
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
-                         int tiles_x, int tiles_y, int max_cycles, int components, void *state,
-                         float *log, hipStream_t s)
+                         int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
+                         void *state, float *log, hipStream_t s)
 {
     int mmax = kimg_clean_multi_components(patch_width, patch_height, tiles_x, tiles_y);
     if (mmax < 1 || ((uintptr_t) tile_max & 15) || ((uintptr_t) tile_pos & 7))
@@ -1421,6 +1933,11 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
     while (a.g.seg < a.g.lat_x * a.g.lat_y)
         a.g.seg *= 2;
     a.g.mmax = mmax; a.g.loop_gain = loop_gain;
+    // (a peak is stepped up to MC_STEPS times per launch, half that with several polarizations)
+    a.g.rmax = num_polarizations == 1 ? MC_STEPS : MC_STEPS / 2;
+    if ((repeats & 0xf) > 0 && (repeats & 0xf) < a.g.rmax)
+        a.g.rmax = repeats & 0xf;
+    const bool always_repeat = (repeats & 0x10) != 0 && a.g.rmax > 1;
     a.scratch = static_cast<mc_scratch *>(state); a.log = log; a.mode = mode;
     unsigned gen = 0;
     const int slot = progress_acquire(state, &gen);
@@ -1441,29 +1958,83 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
             tiles_x * tiles_y, a.scratch);
         mc_init_kernel<<<1, MC_THREADS, 0, s>>>(tile_max, tile_pos, a.g, a.scratch, max_cycles,
-                                                threshold, (int) gen, a.progress);
+                                                threshold, (int) gen, mode, a.progress);
         rc = kimg_launch_status();
     }
     // Pace: keep the device a graph or two ahead of what has been seen to complete, and stop when
     // the keeper says done.  Near the end the number of launches still needed is estimated from the
     // components per launch so far, so that few launches run after the loop has ended (each costs a
     // kernel boundary).
-    multi_graph *graph = nullptr;
+    // Which kernel: single steps until the field shows few components per launch (a few sources far
+    // above the rest); then the repeated-steps kernel for as long as repeated steps are what gets
+    // committed, judged over windows of launches that ran wholly under the choice; a try that did
+    // not help is not repeated for a while (twice as long each time in a row).
+    multi_graph *graphs[2] = {nullptr, nullptr};
+    multi_args variants[2] = {a, a};
+    variants[1].repeats = 1;
+    const bool can_repeat = a.g.rmax > 1 && !always_repeat;
+    bool repeating = always_repeat, hinted = false;
+    int choice_from = 0;                // launches enqueued before the current choice
+    int wait_until = 0, backoff = 1;    // no new try before so many launches are enqueued
+    int win_l = 0, win_c = 0, win_r = 0;
     int enqueued = 0;
     const double t_start = now_s();
     double t_progress = t_start;
     unsigned long long last = ~0ull;
     while (rc == 0) {
-        const unsigned long long word = *seen;
+        const unsigned long long word = seen[0];
         if (word != last) {
             last = word;
             t_progress = now_s();
         }
         const bool started = ((word >> 32) & 0xffu) == gen;     // (else: a word of an earlier call)
         const int launches = started ? (int) (word >> 40) : 0;
-        const int count = started ? (int) (word & 0x7fffffffu) : 0;
+        // (the word of launch 0 carries the start-up kernel's estimate of the steps there are to repeat)
+        const int count = started && launches > 0 ? (int) (word & 0x7fffffffu) : 0;
         if (started && (word & 0x80000000u))
             break;
+        if (can_repeat && !hinted) {
+            if (started) {
+                hinted = true;
+                if ((int) (word & 0x7fffffffu) >= MULTI_GRAPH && launches == 0)
+                    repeating = true;
+            } else if (now_s() - t_start < 5e-3) {
+                sched_yield();          // (the start-up kernel has not finished: tens of microseconds)
+                continue;
+            } else {
+                hinted = true;          // (something else holds the stream up: go ahead)
+            }
+        }
+        if (can_repeat && started && launches > 0) {
+            const unsigned long long word1 = seen[1];           // (written before the word read above)
+            const int repeated = (word1 >> 32) == gen ? (int) (unsigned) word1 : win_r;
+            if (win_l < choice_from) {
+                if (launches >= choice_from) {
+                    win_l = launches;
+                    win_c = count;
+                    win_r = repeated;
+                }
+            } else if (launches - win_l >= 8) {
+                const double rate = (double) (count - win_c) / (launches - win_l);
+                const double share = count > win_c ? (double) (repeated - win_r) / (count - win_c) : 0.0;
+                if (!repeating) {
+                    if (rate < 4.0 && enqueued >= wait_until) {
+                        repeating = true;
+                        choice_from = enqueued;
+                    }
+                } else if (share < 0.1) {
+                    repeating = false;
+                    choice_from = enqueued;
+                    wait_until = enqueued + MULTI_GRAPH * backoff;
+                    backoff = backoff < 32 ? 2 * backoff : 32;
+                } else {
+                    backoff = 1;
+                }
+                win_l = launches;
+                win_c = count;
+                win_r = repeated;
+            }
+        }
         const int in_flight = enqueued - launches;
         // components per launch so far (at least 1, optimistic before anything is known)
         const double per = launches > 0 && count > 0 ? (double) count / launches : (double) mmax;
@@ -1472,21 +2043,25 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             need = 2 * MULTI_GRAPH - in_flight;
         if (in_flight == 0 && need < 2)
             need = 2;
+        const int v = repeating ? 1 : 0;
 #ifndef KIMG_MC_NO_GRAPH
-        if (need >= MULTI_GRAPH && !graph)
-            graph = multi_graph_for(a, s);
+        if (need >= MULTI_GRAPH && !graphs[v])
+            graphs[v] = multi_graph_for(variants[v], s);
 #endif
-        if (need >= MULTI_GRAPH && graph) {
-            he = hipGraphLaunch(graph->exec, s);
+        if (need >= MULTI_GRAPH && graphs[v]) {
+            he = hipGraphLaunch(graphs[v]->exec, s);
             if (he != hipSuccess)
                 rc = -(int) he;
             enqueued += MULTI_GRAPH;
             continue;
         }
         if (need >= 2 || (need > 0 && in_flight == 0)) {
-            for (int i = 0; i < 2 && rc == 0; i++)
-                rc = enqueue_launch(a, s, i);
-            enqueued += 2;
+            // (short of a graph: two launches, or four with repeated steps, the last of which plans
+            // single steps again)
+            const int n = repeating && need >= 4 ? 4 : 2;
+            for (int i = 0; i < n && rc == 0; i++)
+                rc = enqueue_launch(a, s, i & 1, repeating, i == n - 1 ? 1 : a.g.rmax);
+            enqueued += n;
             continue;
         }
         // nothing to enqueue: wait for the device
@@ -1504,7 +2079,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                     rc = -(int) he;
                     break;
                 }
-                *seen = progress_word(st0.launches, (int) gen, st0.done != 0, st0.count);
+                seen[0] = progress_word(st0.launches, (int) gen, st0.done != 0, st0.count);
                 if (st0.launches < enqueued && now_s() - t_progress > 10.0) {
                     rc = KIMG_ETIMEOUT; // (everything enqueued has run, and the state says it has not)
                     break;
@@ -1518,8 +2093,9 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         }
         sched_yield();
     }
-    if (graph)
-        multi_graph_release(graph, s);
+    for (int v = 0; v < 2; v++)
+        if (graphs[v])
+            multi_graph_release(graphs[v], s);
     progress_release(slot);
     return rc;
 }

@@ -35,8 +35,8 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          int64_t psf_row_stride, int64_t psf_pol_stride, int psf_width,
                          int psf_height, int patch_width, int patch_height, int border, int mode,
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
-                         int tiles_x, int tiles_y, int max_cycles, int components, void *state,
-                         float *log, hipStream_t s);
+                         int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
+                         void *state, float *log, hipStream_t s);
 
 constexpr int WAVE = 64;    // gfx950 wavefront
 

@@ -34,6 +34,22 @@ workgroups produced = "deltas", the sorted list R of the best tiles outside its 
            candidate's scaled PSF in registers only; the block's new tile record is its delta.
            Blocks of committed lattices that no new lattice covers are written by workgroups of
            their own.  No workgroup waits for another one.
+  repeat   (round 4, second half) a planned lattice may carry SEVERAL steps: after a subtraction at
+           its peak the value there follows the scalar recursion v <- v - fl(fl(gain v) psf_centre),
+           which every workgroup can evaluate for itself, so the plan is the merge of the planned
+           lattices' decreasing sequences kappa_i(0) > kappa_i(1) > ... cut at a level below which
+           nothing is proven (everything outside the plan, the value a peak has after its last
+           allowed step, the threshold).  A block applies its lattice's steps one after the other in
+           registers and notes, per step, whether any of its pixels beat the peak's value after that
+           step ("fail" bits); its record is the tile after all steps.  Verification: lattice i
+           allows the steps above L_i = kappa_i(k-1) - 1 if a block failed after k steps, else above
+           min(best record of the lattice, kappa_i(r_i - 1) - 1); the steps above C = max L_i are
+           committed (a prefix of the merged order).  A lattice of which only some steps were
+           committed has pixels to write but no valid records: the next launch plans exactly those
+           lattices again WITHOUT steps (its workgroups write the pending pixels and publish the
+           records), and the launch after that carries on.
+           Such a launch costs what a launch costs and commits nothing, so after one the plans take
+           single steps for a while (8 launches, doubling up to 64 while it keeps happening).
   list     the lister builds R for the next launch: the best tiles of the whole image as the
            commits so far leave it, sorted, with a floor (every tile not listed has a key <= floor).
            It does not know this launch's plan: the next launch drops the entries that lie inside
@@ -51,20 +67,24 @@ def key_of(value, tile):
 
 class Entry:
     """A tile record: what a candidate is known by."""
-    __slots__ = ('key', 'value', 'tile', 'y', 'x', 'pix')
+    __slots__ = ('key', 'value', 'tile', 'y', 'x', 'pix', 'steps', 'seq', 'fail')
 
-    def __init__(self, value, tile, y, x, pix):
+    def __init__(self, value, tile, y, x, pix, steps=1):
         self.value = np.float32(value)
         self.tile = int(tile)
         self.y = int(y)
         self.x = int(x)
         self.pix = np.array(pix, np.float32)
         self.key = key_of(value, tile)
+        self.steps = steps              # of a planned component: subtractions at this peak
+        self.seq = None                 # of a planned component: (key, value, pix) before step s
+        self.fail = 0                   # of a record: bit k = a pixel beat the peak after k steps
 
 
 class MultiClean:
     def __init__(self, pixels, border, loop_gain, mode, image, psf, model, psf_patch, threshold,
-                 limit, max_components=8, rest_entries=24, pool_rest=8, pool_entries=8, rng=None):
+                 limit, max_components=8, rest_entries=24, pool_rest=8, pool_entries=8, rng=None,
+                 max_steps=4, refine=True):
         self.loop_gain = np.float32(loop_gain)
         self.mode = mode
         self.image = image              # lags one launch behind the committed components
@@ -80,6 +100,12 @@ class MultiClean:
         self.threshold = np.float32(threshold)
         self.limit = int(limit)
         self.max_components = max_components
+        self.max_steps = max_steps      # subtractions per lattice and launch
+        self.refine = refine            # second-best records inside a lattice planned again do not bound
+        self.cool = 0                   # launches left without repeated steps (after one went wrong)
+        self.penalty = 4                # that many, doubled each time in a row, up to 64
+        self.steps_planned = 0
+        self.repairs = 0                # launches that only re-evaluated partly committed lattices
         self.rest_entries = rest_entries
         self.pool_rest = pool_rest      # entries of the list that enter the candidate pool
         self.pool_entries = pool_entries
@@ -184,51 +210,128 @@ class MultiClean:
         floor = keys[n][0] if len(keys) > n else 0
         return [self._entry(t) for _, t in keys[:n]], floor
 
+    # ---- the value at a peak, step after step ------------------------------------------------
+    def _metric(self, pix):
+        if self.mode == 0:
+            return np.abs(pix[0])
+        m = np.float32(0)
+        for p in range(self.P):
+            m = m + pix[p] * pix[p]
+        return m
+
+    def _sequence(self, e, n):
+        """(key, value, pix) at the peak of component e before step s = 0 .. n: what the lattice
+        workgroups compute for that pixel, as a scalar recursion (clean.py:1044-1046)."""
+        centre = self.psf[:, self.psf.shape[1] // 2, self.psf.shape[2] // 2]
+        pix = e.pix.copy()
+        seq = [(e.key, e.value, pix.copy())]
+        for _ in range(n):
+            scale = (self.loop_gain * pix).astype(np.float32)
+            pix = (pix - scale * centre).astype(np.float32)
+            v = self._metric(pix)
+            seq.append((key_of(v, e.tile), np.float32(v), pix.copy()))
+        return seq
+
+    def _fails(self, tx, ty, pixels, x0, y0, peak, peak_value):
+        """Does any pixel of tile (tx, ty) -- block pixels [P][..][..] with corner (x0, y0) -- come
+        before the peak pixel, whose metric is now `peak_value`, in the reference's order (larger
+        metric; lower tile; earlier pixel in row-major order)?"""
+        t = ty * self.tiles_x + tx
+        tx0, ty0 = tx * TILE + self.border, ty * TILE + self.border
+        tx1 = min(tx0 + TILE, self.W - self.border)
+        ty1 = min(ty0 + TILE, self.H - self.border)
+        sub = pixels[:, ty0 - y0:ty1 - y0, tx0 - x0:tx1 - x0]
+        if sub.shape[1] == 0 or sub.shape[2] == 0:
+            return False
+        if self.mode == 0:
+            metric = np.abs(sub[0])
+        else:
+            metric = np.zeros(sub.shape[1:], np.float32)
+            for p in range(self.P):
+                metric = metric + sub[p] * sub[p]
+        wins = metric > peak_value
+        if t < peak.tile:
+            wins |= metric == peak_value
+        elif t == peak.tile:
+            yy, xx = np.indices(metric.shape)
+            earlier = (yy * TILE + xx) < ((peak.y - ty0) * TILE + (peak.x - tx0))
+            wins |= (metric == peak_value) & earlier
+        return bool(wins.any())
+
     # ---- one launch -------------------------------------------------------------------------
     def launch(self):
         self.launches += 1
-        # verify
-        j = 0
-        if self.plan:
-            j = 1
-            top = 0
-            for i in range(1, len(self.plan)):
-                top = max([top] + [d.key for d in self.deltas[i - 1]])
-                if top < self.plan[i].key:
-                    j = i + 1
-                else:
-                    break
-            self.wasted += len(self.plan) - j
+        # verify: the level above which the steps of the last plan are proven
+        level = 0
+        for e, recs in zip(self.plan, self.deltas):
+            if e.steps == 0:
+                continue
+            fail = 0
+            for d in recs:
+                fail |= d.fail
+            first_fail = next((k for k in range(1, e.steps) if fail >> k & 1), None)
+            if first_fail is not None:
+                lev = e.seq[first_fail - 1][0] - 1
+            else:
+                lev = min(max([0] + [d.key for d in recs]), e.seq[e.steps - 1][0] - 1)
+            level = max(level, lev)
+        held = [sum(1 for s in range(e.steps) if e.seq[s][0] > level) for e in self.plan]
+        full = [k == e.steps for k, e in zip(held, self.plan)]
+        partial = [0 < k < e.steps for k, e in zip(held, self.plan)]
+        self.wasted += sum(1 for k, e in zip(held, self.plan) if k == 0 and e.steps > 0)
         # commit: log + model (keeper), base tile arrays (folder); pixels become pending
-        committed = self.plan[:j]
-        for e in committed:
-            scale = self._scale(e)
-            self.log.append((e.value, (e.y, e.x), scale))
+        steps = [(e.seq[s][0], i, s) for i, e in enumerate(self.plan) for s in range(held[i])]
+        steps.sort(reverse=True)
+        for _, i, s in steps:
+            e = self.plan[i]
+            scale = (self.loop_gain * e.seq[s][2]).astype(np.float32)
+            self.log.append((e.seq[s][1], (e.y, e.x), scale))
             self.model[:, e.y, e.x] += scale
             self.count += 1
-        for i in range(j):
-            for d in self.deltas[i]:
-                self._store(d)
-        pending = [(e, self._lattice(e), self._scale(e)) for e in committed]
+        for i, e in enumerate(self.plan):
+            if full[i]:
+                for d in self.deltas[i]:
+                    self._store(d)
+        pending = [(e, self._lattice(e), [(self.loop_gain * e.seq[s][2]).astype(np.float32)
+                                          for s in range(held[i])])
+                   for i, e in enumerate(self.plan) if held[i] > 0]
         # plan
         picks = []
-        if not self.done:
-            if j < len(self.plan):
-                # misprediction: the next component is the best of the committed deltas and the
-                # first candidate that was not committed (the best tile outside lattices 1..j)
-                pool = [d for i in range(j) for d in self.deltas[i]] + [self.plan[j]]
-                bound = None
+        if self.done:
+            pass
+        elif any(partial):
+            # partly committed lattices: their pixels are pending, their records unknown; they are
+            # evaluated again, without steps, and nothing else can be proven meanwhile
+            self.repairs += 1
+            self.penalty = min(64, 2 * self.penalty)
+            self.cool = self.penalty
+            for i, e in enumerate(self.plan):
+                if partial[i]:
+                    picks.append(Entry(e.value, e.tile, e.y, e.x, e.pix, steps=0))
+        else:
+            mispredicted = not all(full)
+            if mispredicted:
+                # the next component is the best of the committed records and the best candidate
+                # that was not committed (the best tile outside the committed lattices)
+                left = [e for i, e in enumerate(self.plan) if not full[i]]
+                pool = [d for i in range(len(self.plan)) if full[i] for d in self.deltas[i]]
+                pool.append(max(left, key=lambda e: e.key))
+                bound = 0
                 pool.sort(key=lambda e: -e.key)
                 pool = pool[:1]
                 first_proven = True
             else:
-                best, second = [], 0
-                for i in range(j):
+                best, seconds = [], []
+                for i in range(len(self.plan)):
                     ds = sorted(self.deltas[i], key=lambda e: -e.key)
                     if ds:
                         best.append(ds[0])
                     if len(ds) > 1:
-                        second = max(second, ds[1].key)
+                        # (what bounds, and the best record of the same lattice: where that one
+                        # would be planned again with the very same lattice, the other records lie
+                        # inside a planned lattice, and the next verification covers them)
+                        same = self._lattice(ds[0]) == self._lattice(self.plan[i])
+                        seconds.append((ds[1].key, ds[0] if same and self.refine else None))
                 # the list knows nothing of the last launch's lattices: entries inside them are
                 # dropped (all planned lattices, committed or not -- here all are committed)
                 last = [self._lattice(e) for e in self.plan]
@@ -238,12 +341,21 @@ class MultiClean:
                     floor = alive[self.pool_rest].key
                     alive = alive[:self.pool_rest]
                 pool = sorted(best + alive, key=lambda e: -e.key)
-                bound = max(second, floor)
+                bound = floor
                 first_proven = bool(alive) or (pool and pool[0].key > floor) or floor == 0
                 if len(pool) > self.pool_entries:
                     bound = max(bound, pool[self.pool_entries].key)
                     pool = pool[:self.pool_entries]
+                for k, top in seconds:
+                    # a second-best record does not bound if its lattice's best record is a candidate
+                    # that no earlier candidate's lattice holds (it is then planned, or the walk ends
+                    # at or before it -- and what ends the walk bounds everything after)
+                    at = next((i for i, e in enumerate(pool) if e is top), None)
+                    if at is None or any(self._inside(top.tile, self._lattice(e)) for e in pool[:at]):
+                        bound = max(bound, k)
             lats = []
+            zero_special = False
+
             for e in pool:
                 first = not picks
                 if len(picks) >= self.max_components:
@@ -268,17 +380,47 @@ class MultiClean:
                         pix = self.image[:, e.y, e.x] if ok else np.zeros(self.P, np.float32)
                         picks.append(Entry(e.value, e.tile, e.y, e.x, pix))
                         lats.append(lat)
+                        zero_special = True
                     break
-                picks.append(e)
+                picks.append(Entry(e.value, e.tile, e.y, e.x, e.pix))
                 lats.append(lat)
             if not pool and not pending and self.rest_floor == 0:
                 self.done = True                # no tiles at all
+            # how many steps each planned lattice takes: everything in the pool that is neither
+            # planned nor inside a planned lattice bounds the steps from below, and so does the
+            # value a peak has when it may not be stepped again
+            halting = max([0] + [e.key for e in pool
+                                 if not any(e.tile == q.tile for q in picks)
+                                 and not any(self._inside(e.tile, l2) for l2 in lats)])
+            rmax = self.max_steps
+            if any(e.steps > 1 for e in self.plan) and not mispredicted:
+                self.penalty = 4            # (repeated steps held)
+            if (mispredicted or zero_special or self.cool > 0
+                    or self.limit - self.count < self.max_components * rmax):
+                rmax = 1
+            self.cool = max(self.cool - 1, 0)
+            level = max(bound, halting)
+            ends = []
+            for e in picks:
+                e.seq = self._sequence(e, rmax)
+                end = next(s for s in range(1, rmax + 1)
+                           if s == rmax or e.seq[s][1] < self.threshold or e.seq[s][0] >= e.seq[s - 1][0])
+                if e.seq[end][0] >= e.seq[end - 1][0]:
+                    level = max(level, e.seq[end - 1][0] - 1)      # (a peak that does not come down)
+                else:
+                    level = max(level, e.seq[end][0])
+                ends.append(end)
+            for i, (e, end) in enumerate(zip(picks, ends)):
+                e.steps = sum(1 for s in range(end) if e.seq[s][0] > level)
+                if i == 0 and (mispredicted or zero_special):
+                    e.steps = 1
+            picks = [e for e in picks if e.steps > 0]
+            self.steps_planned += sum(e.steps for e in picks)
         # execute
         new_image_blocks = {}
         deltas = []
         covered = set()
         for e, lat in zip(picks, [self._lattice(e) for e in picks]):
-            scale = self._scale(e)
             recs = []
             for by in range(self.lat_y):
                 for bx in range(self.lat_x):
@@ -287,16 +429,25 @@ class MultiClean:
                     if x0 >= x1 or y0 >= y1:
                         continue
                     pixels = self.image[:, y0:y1, x0:x1]
-                    for pe, plat, pscale in pending:
+                    for pe, plat, pscales in pending:
                         if plat[0] <= tx < plat[0] + self.lat_x and plat[1] <= ty < plat[1] + self.lat_y:
-                            pixels = self._subtracted(pixels, x0, y0, x1, y1, pe, pscale)
+                            for pscale in pscales:
+                                pixels = self._subtracted(pixels, x0, y0, x1, y1, pe, pscale)
                             new_image_blocks[(tx, ty)] = pixels
                     covered.add((tx, ty))
-                    pixels = self._subtracted(pixels, x0, y0, x1, y1, e, scale)
-                    if 0 <= tx < self.tiles_x and 0 <= ty < self.tiles_y:
-                        recs.append(self._record(tx, ty, pixels, x0, y0))
+                    is_tile = 0 <= tx < self.tiles_x and 0 <= ty < self.tiles_y
+                    fail = 0
+                    for k in range(1, e.steps + 1):
+                        scale = (self.loop_gain * e.seq[k - 1][2]).astype(np.float32)
+                        pixels = self._subtracted(pixels, x0, y0, x1, y1, e, scale)
+                        if k < e.steps and is_tile and self._fails(tx, ty, pixels, x0, y0, e, e.seq[k][1]):
+                            fail |= 1 << k
+                    if is_tile:
+                        rec = self._record(tx, ty, pixels, x0, y0)
+                        rec.fail = fail
+                        recs.append(rec)
             deltas.append(recs)
-        for pe, plat, pscale in pending:
+        for pe, plat, pscales in pending:
             for by in range(self.lat_y):
                 for bx in range(self.lat_x):
                     tx, ty = plat[0] + bx, plat[1] + by
@@ -305,8 +456,10 @@ class MultiClean:
                     x0, y0, x1, y1 = self._block(tx, ty)
                     if x0 >= x1 or y0 >= y1:
                         continue
-                    new_image_blocks[(tx, ty)] = self._subtracted(self.image[:, y0:y1, x0:x1],
-                                                                  x0, y0, x1, y1, pe, pscale)
+                    pixels = self.image[:, y0:y1, x0:x1]
+                    for pscale in pscales:
+                        pixels = self._subtracted(pixels, x0, y0, x1, y1, pe, pscale)
+                    new_image_blocks[(tx, ty)] = pixels
         # (all reads above saw the image as it was at the start of the launch)
         for (tx, ty), pixels in new_image_blocks.items():
             x0, y0, x1, y1 = self._block(tx, ty)

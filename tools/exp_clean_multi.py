@@ -2,7 +2,10 @@
 one-launch-per-cycle form, by the cap on the components per launch, on the bench's CLEAN image
 (4096^2, 200 point sources (x) PSF + noise), with the launches taken and the components per launch.
 
-    python tools/exp_clean_multi.py [patch height] [patch width] [cycles] [image size] [polarizations]"""
+    python tools/exp_clean_multi.py [patch height] [patch width] [cycles] [image size] [polarizations] [dominant]
+
+`dominant` > 0: the first source gets that amplitude (the others: 0.5 .. 2), a field whose first
+cycles all go to one peak -- what the repeated steps of a launch are for."""
 import os
 import sys
 import time
@@ -19,6 +22,7 @@ pw = int(sys.argv[2]) if len(sys.argv) > 2 else 133
 cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+dominant = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 ctx = accel.create_some_context()
 q = ctx.create_command_queue()
 rs = np.random.RandomState(4)
@@ -27,9 +31,12 @@ psf = np.outer(g1, g1)[None].repeat(P, axis=0).astype(np.float32)
 psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
 psf[:, G // 2, G // 2] = 1.0
 sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
-for _ in range(200):
+for i in range(200):
     y, x = rs.randint(100, G - 100, 2)
-    sky[:, y - 30:y + 31, x - 30:x + 31] += rs.uniform(0.5, 2.0) * psf[:, G // 2 - 30:G // 2 + 31,
+    amp = rs.uniform(0.5, 2.0)
+    if i == 0 and dominant > 0:
+        amp = dominant
+    sky[:, y - 30:y + 31, x - 30:x + 31] += amp * psf[:, G // 2 - 30:G // 2 + 31,
                                                                      G // 2 - 30:G // 2 + 31]
 
 
@@ -44,8 +51,11 @@ class _IP:      # what CleanTemplate.instantiate reads of the image parameters
 cp = parameters.CleanParameters(cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
 patch = (P, ph, pw)
 first = None
-for form, comps in [('one_launch', 0)] + [('multi', c) for c in (1, 2, 4, 6, 8)]:
-    cl = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form, 'components': comps}).instantiate(q, _IP)
+for form, comps, reps, always in [('one_launch', 0, 0, False), ('multi', 1, 1, False), ('multi', 4, 1, False),
+                                  ('multi', 8, 1, False), ('multi', 8, 2, True), ('multi', 8, 4, True),
+                                  ('multi', 8, 8, True), ('multi', 8, 0, False)]:
+    cl = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': form, 'components': comps, 'repeats': reps,
+                                                      'repeats_always': always}).instantiate(q, _IP)
     cl.ensure_all_bound()
     cl.buffer('psf').set(q, psf)
     rates = []
@@ -63,8 +73,8 @@ for form, comps in [('one_launch', 0)] + [('multi', c) for c in (1, 2, 4, 6, 8)]
     launches = cl.last_launches()
     sig = [(round(float(v), 6), tuple(p)) for v, p, m in got]
     first = first or sig
-    print('%-10s cap %d: %9.0f cycles/s = %.2f us per cycle; launches %s (%.2f components each, %.2f us per launch)  %s' % (
-        form, comps, max(rates), 1e6 / max(rates), launches,
+    print('%-10s cap %d x %d%s: %9.0f cycles/s = %.2f us per cycle; launches %s (%.2f components each, %.2f us per launch)  %s' % (
+        form, comps, reps, ' always' if always else ' (auto)' if form == 'multi' and reps != 1 else '', max(rates), 1e6 / max(rates), launches,
         len(got) / launches if launches else 1.0,
         1e6 * len(got) / max(rates) / (launches or len(got)),
         'same components' if sig == first else 'DIFFERENT'))

@@ -34,7 +34,7 @@ for _ in range(200):
 fixed = parameters.FixedImageParameters([0], np.float32)
 ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
 cp = parameters.CleanParameters(cycles, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
-op = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'multi', 'components': comps}).instantiate(q, ip)
+op = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'multi', 'components': comps, 'repeats': int(os.environ.get('KIMG_REPEATS', '0')), 'repeats_always': bool(os.environ.get('KIMG_REPEATS_ALWAYS'))}).instantiate(q, ip)
 op.ensure_all_bound()
 op.buffer('psf').set(q, psf)
 patch = (1, 111, 133)
@@ -66,6 +66,7 @@ for row, label in ((0, 'K (keeper)'), (1, 'B (block (0, 0) of the first planned 
         print('   old list %.1f entries, merged %.1f of which %.1f from delta records; floor %.3f on average; %.1f lattices folded' % (
             raw[row][7] / n, raw[row][6] / n, raw[row][5] / n, raw[row][17] / n / 1000, raw[row][18] / n))
         raw[row][5] = raw[row][6] = raw[row][7] = 0
-    for i in (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 8, 9, 10, 11):
+    plan_names = {8: 'B: pool sorted', 9: 'B: masks', 10: 'B: bound', 11: 'B: walked'}
+    for i in ((0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7) if row == 1 else (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 8, 9, 10, 11)):
         if raw[row][i]:
-            print('   %-40s %8.0f cycles' % (names[i], raw[row][i] / n))
+            print('   %-40s %8.0f cycles' % ((plan_names if row == 1 and i in plan_names else names)[i], raw[row][i] / n))

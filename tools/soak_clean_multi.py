@@ -19,11 +19,11 @@ ctx = accel.create_some_context()
 q = ctx.create_command_queue()
 
 
-def run(G, P, mode, border, loop_gain, dirty, psf, patch, threshold, cycles, cap):
+def run(G, P, mode, border, loop_gain, dirty, psf, patch, threshold, cycles, cap, repeats=0, always=False):
     fixed = parameters.FixedImageParameters(list(range(P)), np.float32)
     ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
     cp = parameters.CleanParameters(1000, loop_gain, 0.85, 5.0, mode, 0.01, 0.5, border)
-    fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'multi', 'components': cap}).instantiate(q, ip)
+    fn = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'multi', 'components': cap, 'repeats': repeats, 'repeats_always': always}).instantiate(q, ip)
     fn.ensure_all_bound()
     fn.buffer('dirty').set(q, dirty)
     fn.buffer('psf').set(q, psf)
@@ -49,7 +49,7 @@ for seed in range(first, first + count):
     cap = int(rs.randint(0, 9))
     first_value = float(np.max(np.abs(dirty))) if mode == 0 else float(np.max(np.sum(dirty * dirty, axis=0)))
     threshold = float(rs.choice([0.0, 0.3 * first_value, 2.0 * first_value]))
-    n, l = run(G, P, mode, border, loop_gain, dirty, psf, patch, threshold, cycles, cap)
+    n, l = run(G, P, mode, border, loop_gain, dirty, psf, patch, threshold, cycles, cap, int(rs.randint(0, 9)), bool(seed % 3))
     total += n
     launches += l or 0
     # many sources, random geometry
@@ -60,8 +60,16 @@ for seed in range(first, first + count):
     _, psf2, dirty2 = sources_problem(seed, G=G2, P=P2, n_sources=int(rs2.randint(5, 80)),
                                       sigma=float(rs2.uniform(1.5, 5.0)))
     patch2 = (P2, int(rs2.choice([15, 33, 65, 97, 161])), int(rs2.choice([15, 47, 65, 133, 191])))
+    if seed % 2:
+        # a few sources far above the rest: what repeated steps at one peak are for
+        for _ in range(int(rs2.randint(1, 4))):
+            y, x = rs2.randint(40, G2 - 40, 2)
+            h = 12
+            dirty2[:, y - h:y + h + 1, x - h:x + h + 1] += (rs2.uniform(5.0, 30.0) * psf2[
+                :, G2 // 2 - h:G2 // 2 + h + 1, G2 // 2 - h:G2 // 2 + h + 1]).astype(np.float32)
     n, l = run(G2, P2, mode2, float(rs2.choice([0.0, 0.02, 0.07])), float(rs2.choice([0.05, 0.1, 0.3])),
-               dirty2, psf2, patch2, 0.0, int(rs2.choice([50, 200, 400])), int(rs2.randint(0, 9)))
+               dirty2, psf2, patch2, 0.0, int(rs2.choice([50, 200, 400])), int(rs2.randint(0, 9)),
+               int(rs2.choice([0, 0, 1, 2, 3, 8])), bool(seed % 4 < 2))
     total += n
     launches += l or 0
 print('soak ok: seeds %d..%d, %d components in %d launches' % (first, first + count - 1, total, launches))
