@@ -7,7 +7,7 @@ import pytest
 
 from helpers import context_queue
 from oracle import kimg_oracle as orc
-from test_clean_multi_model import fuzz_problem, reference_run, sources_problem
+from test_clean_multi_model import dominated_problem, fuzz_problem, reference_run, sources_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -158,3 +158,83 @@ def test_multi_is_what_auto_takes():
     got = fn.run_cycles((1, 33, 47), 0.0, 200)
     _check(fn, q, got, want)
     assert fn.last_launches() is not None and fn.last_launches() < 140
+
+
+@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('repeats,always', [(0, True), (2, True), (0, False)])
+def test_multi_fuzz_repeated_steps(seed, repeats, always):
+    """The fuzz problems through the repeated-steps kernel (from the first launch on, or as the
+    loop's own choice makes it alternate with the single-step kernel)."""
+    rs, P, mode, G, border, loop_gain, psf, dirty, patch, cycles = fuzz_problem(40 + seed)
+    fn, q = _clean(G, P, mode, border, loop_gain, dirty, psf,
+                   {'form': 'multi', 'repeats': repeats, 'repeats_always': always})
+    first = float(np.max(fn.buffer('tile_max').get(q)))
+    threshold = float(rs.choice([0.0, 0.3 * first, 2.0 * first]))
+    want = reference_run(G, border, loop_gain, mode, dirty, psf, patch, threshold, cycles)
+    got = fn.run_cycles(patch, threshold, cycles)
+    _check(fn, q, got, want)
+
+
+@pytest.mark.parametrize('G,P,mode,patch,amplitudes,cycles', [
+    (512, 1, 0, (33, 47), (30.0,), 150),
+    (512, 1, 0, (33, 47), (30.0, 12.0, 11.0), 250),
+    (768, 1, 0, (111, 133), (50.0, 20.0), 200),       # the bench's patch
+    (512, 2, 1, (65, 65), (20.0, 15.0), 150),        # sum of squares: four steps per launch
+    (512, 4, 0, (31, 95), (25.0,), 120),
+    (1024, 1, 0, (161, 191), (40.0, 10.0), 150),     # 49 blocks: four lattices per launch
+])
+def test_multi_dominated_field(G, P, mode, patch, amplitudes, cycles):
+    """A few sources far above the rest: a launch steps the same peaks several times (the value at a
+    peak follows a scalar recursion that every workgroup evaluates), and far fewer launches commit
+    the reference's components, bit for bit."""
+    rs, psf, dirty = dominated_problem(G + P, G=G, P=P, n_sources=30, amplitudes=amplitudes)
+    full = (P,) + patch
+    want = reference_run(G, 0.02, 0.1, mode, dirty, psf, full, 0.0, cycles)
+    launches = {}
+    for name, tuning in (('single', {'form': 'multi', 'repeats': 1}),
+                         ('repeated', {'form': 'multi', 'repeats_always': True}),
+                         ('auto', {'form': 'multi'})):
+        fn, q = _clean(G, P, mode, 0.02, 0.1, dirty, psf, tuning)
+        got = fn.run_cycles(full, 0.0, cycles)
+        _check(fn, q, got, want)
+        launches[name] = fn.last_launches()
+    assert launches['repeated'] < 0.75 * launches['single'], launches
+    assert launches['auto'] < 0.9 * launches['single'], launches       # (the start-up estimate saw it)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_multi_repeated_steps_that_fail(seed):
+    """Bright single pixels under a PSF with a skirt: the steps planned at such a peak do not hold
+    (its neighbours soon beat it); what was committed of them is written, the lattice evaluated
+    again, and the result is the reference's."""
+    rs, psf, dirty = dominated_problem(20 + seed, n_sources=[3, 10, 30][seed % 3],
+                                       amplitudes=(5.0, 9.0)[:1 + seed % 2], shaped=False)
+    gain = [0.1, 0.3][seed % 2]
+    want = reference_run(384, 0.02, gain, 0, dirty, psf, (1, 33, 47), 0.0, 150)
+    for tuning in ({'form': 'multi', 'repeats_always': True}, {'form': 'multi'}):
+        fn, q = _clean(384, 1, 0, 0.02, gain, dirty, psf, tuning)
+        got = fn.run_cycles((1, 33, 47), 0.0, 150)
+        _check(fn, q, got, want)
+
+
+def test_multi_repeated_steps_continue_and_stop():
+    """Thresholds and cycle limits inside a run of repeated steps stop the loop at exactly the
+    reference's component; the next call carries on."""
+    G = 512
+    rs, psf, dirty = dominated_problem(5, G=G, n_sources=20, amplitudes=(40.0, 25.0))
+    fn, q = _clean(G, 1, 0, 0.02, 0.1, dirty, psf, {'form': 'multi', 'repeats_always': True})
+    patch = (1, 47, 33)
+    img, model = dirty.copy(), np.zeros_like(dirty)
+    ref = orc.Clean(G, 0.02, 0.1, 0, img, psf, model)
+    ref.reset()
+    first = float(np.max(ref._tile_max))
+    for cycles, threshold in ((1, 0.0), (3, 0.0), (5, 0.0), (70, 0.7 * first), (70, 0.7 * first),
+                              (9, 0.0), (500, 0.2 * first), (100, 0.0)):
+        want = []
+        for _ in range(cycles):
+            v, pos, pix = ref(patch, threshold)
+            if v is None:
+                break
+            want.append((v, ref.last_pos, np.array(pix)))
+        got = fn.run_cycles(patch, threshold, cycles)
+        _check(fn, q, got, (want, img, model, ref._tile_max, ref._tile_pos))

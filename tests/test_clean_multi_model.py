@@ -110,3 +110,60 @@ def test_model_edge_images():
     for dirty in (np.zeros((1, G, G), np.float32),              # the (x0, y0) quirk of clean.py:950
                   np.full((1, G, G), 0.75, np.float32)):        # every tile ties
         check_model(G, 0.05, 0.3, 0, dirty, psf, (1, 5, 5), 0.0, 25)
+
+
+def dominated_problem(seed, G=384, P=1, n_sources=10, amplitudes=(8.0,), shaped=True):
+    """A few sources far above the rest: PSF-shaped (the repeated steps of a launch hold) or single
+    pixels (they do not: the PSF's skirt digs holes next to the peak that soon beat it)."""
+    rs, psf, dirty = sources_problem(seed, G=G, P=P, n_sources=n_sources)
+    h = 12
+    for amp in amplitudes:
+        y, x = rs.randint(40, G - 40, 2)
+        if shaped:
+            dirty[:, y - h:y + h + 1, x - h:x + h + 1] += (
+                amp * psf[:, G // 2 - h:G // 2 + h + 1, G // 2 - h:G // 2 + h + 1]).astype(np.float32)
+        else:
+            dirty[:, y, x] += np.float32(amp)
+    return rs, psf, dirty
+
+
+@pytest.mark.parametrize('max_steps', [1, 2, 4, 8])
+@pytest.mark.parametrize('P,mode', [(1, 0), (3, 1)])
+def test_model_repeated_steps(max_steps, P, mode):
+    """Several subtractions at one peak within a launch: the merge of the planned lattices' own
+    sequences, cut where nothing is proven any more."""
+    rs, psf, dirty = dominated_problem(11, P=P, amplitudes=(30.0, 12.0))
+    mc = check_model(384, 0.02, 0.1, mode, dirty, psf, (P, 33, 47), 0.0, 120, max_steps=max_steps)
+    if max_steps == 1:
+        assert mc.repairs == 0
+    else:
+        assert mc.steps_planned >= 120      # (all of them committed, in far fewer launches)
+    if max_steps == 8 and mode == 0:
+        one = check_model(384, 0.02, 0.1, mode, dirty, psf, (P, 33, 47), 0.0, 120, max_steps=1)
+        assert mc.launches < 0.75 * one.launches, (mc.launches, one.launches)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_model_repeated_steps_that_fail(seed):
+    """Peaks that do not stay the largest pixel of their lattice (single bright pixels under a PSF
+    with a skirt): blocks report the step after which the peak was beaten, the steps up to it are
+    committed, the lattice is evaluated again without steps -- and the plans take single steps for
+    a while, so that what such a field costs stays bounded."""
+    rs, psf, dirty = dominated_problem(20 + seed, n_sources=[3, 10, 30][seed % 3],
+                                       amplitudes=(5.0, 9.0)[:1 + seed % 2], shaped=False)
+    mc = check_model(384, 0.02, [0.1, 0.3][seed % 2], 0, dirty, psf, (1, 33, 47), 0.0, 150, max_steps=8)
+    one = check_model(384, 0.02, [0.1, 0.3][seed % 2], 0, dirty, psf, (1, 33, 47), 0.0, 150, max_steps=1)
+    assert mc.repairs > 0
+    assert mc.launches <= 1.15 * one.launches + 4, (mc.launches, one.launches)
+
+
+@pytest.mark.parametrize('seed', range(20, 32))
+def test_model_fuzz_with_repeated_steps(seed):
+    rs, P, mode, G, border, loop_gain, psf, dirty, patch, cycles = fuzz_problem(seed)
+    first = float(np.max(np.abs(dirty))) if mode == 0 else float(np.max(np.sum(dirty * dirty, axis=0)))
+    threshold = float(rs.choice([0.0, 0.3 * first, 2.0 * first]))
+    for max_steps in (2, 8):
+        check_model(G, border, loop_gain, mode, dirty, psf, patch, threshold, cycles, max_steps=max_steps,
+                    max_components=int(rs.randint(1, 9)))
+        check_model(G, border, loop_gain, mode, dirty, psf, patch, threshold, cycles, max_steps=max_steps,
+                    refine=False, rng=np.random.RandomState(seed))
