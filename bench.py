@@ -549,9 +549,9 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     pp.bind(psf=cl.buffer('psf'))
     patch = pp(cp.psf_cutoff, cp.psf_limit)
 
-    def clean_rate(patch_, per_cycle=False, op=None):
+    def clean_rate(patch_, per_cycle=False, op=None, image=None):
         op = op or cl
-        op.buffer('dirty').set(q, sky)
+        op.buffer('dirty').set(q, sky if image is None else image)
         op.buffer('model').zero(q)
         op.reset()
         n = min(args.clean_cycles, 200) if per_cycle else args.clean_cycles
@@ -597,7 +597,28 @@ def secondary(args, ctx, q, obs, ip, gp, ap, gridder, grid_buf, chunks, whole=No
     one.ensure_all_bound()
     clean_rate(small, op=one)
     out['clean']['small_patch_one_component_per_launch_cycles_per_s'] = round(clean_rate(small, op=one), 1)
-    del one
+    # a field with a few sources far above the rest (the first cycles of any real image): the loop
+    # steps the same peaks several times per launch; next to it the same loop held
+    # to single steps
+    bright = sky.copy()
+    for amp in (100.0, 40.0):
+        y, x = rs.randint(100, G - 100, 2)
+        bright[:, y - 30:y + 31, x - 30:x + 31] += amp * psf[:, G // 2 - 30:G // 2 + 31,
+                                                             G // 2 - 30:G // 2 + 31]
+    clean_rate(small, image=bright)
+    out['clean']['dominated_field_cycles_per_s'] = round(clean_rate(small, image=bright), 1)
+    launches = cl.last_launches()
+    if launches:
+        out['clean']['dominated_field_components_per_launch'] = round(args.clean_cycles / launches, 2)
+    single = clean.CleanTemplate(ctx, cp, np.float32, P, {'form': 'multi', 'repeats': 1}).instantiate(q, ip)
+    single.bind(**{name: cl.buffer(name) for name in ('dirty', 'model', 'psf', 'tile_max', 'tile_pos')})
+    single.ensure_all_bound()
+    clean_rate(small, op=single, image=bright)
+    out['clean']['dominated_field_single_steps_cycles_per_s'] = round(clean_rate(small, op=single, image=bright), 1)
+    launches = single.last_launches()
+    if launches:
+        out['clean']['dominated_field_single_steps_components_per_launch'] = round(args.clean_cycles / launches, 2)
+    del one, single, bright
     # several channels per launch (kimg_clean_cycles_batch: cycle i of C channels in ONE launch, the
     # kernel boundary is paid once): aggregate minor cycles per second over C channels of a band,
     # each with its own dirty image (the same sky at another amplitude and noise), same PSF patch

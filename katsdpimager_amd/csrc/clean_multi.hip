@@ -38,6 +38,32 @@
 //
 // On the 4096^2 bench image (200 sources, 133 x 111 patch) the plan holds 7.1 of 8 components on
 // average and no lattice is evaluated in vain.
+//
+// REPEATED STEPS.  While one source stands far above the rest every cycle goes to the same peak,
+// and the lattices of a launch are all the same one.  But a subtraction changes the value at its own
+// peak by a scalar recursion -- v <- v - fl(fl(gain v) psf_centre), per polarization -- that every
+// workgroup can evaluate for itself, so a planned lattice may carry SEVERAL steps: the plan is the
+// merge of the planned lattices' decreasing sequences kappa_i(0) > kappa_i(1) > ..., cut at a level
+// below which nothing is proven (the bound of the walk, the first candidate that is neither planned
+// nor inside a planned lattice, the value a peak has when it may not be stepped again).  A block
+// applies its lattice's steps one after the other in registers and notes, per step, whether any of
+// its pixels comes before the peak in the reference's order by then ("fail" bits in its record);
+// its record is the tile after all steps.  Verification: lattice i allows the steps above
+// L_i = kappa_i(k - 1) - 1 if a block failed after k steps, else above min(best record of the
+// lattice, kappa_i(r_i - 1) - 1); the steps above max L_i are committed -- a prefix of the merged
+// order, which nobody has to sort but the keeper for its log.  A lattice of which only some steps
+// were committed has pixels to write but no valid records: the next launch plans exactly those
+// lattices again WITHOUT steps (its workgroups write the pending pixels and publish the records),
+// and the plans take single steps for a while after that (8 launches, doubling up to 64 while it
+// keeps happening), so that a field where the repeated steps do not hold (a peak whose neighbours
+// overtake it) costs a few per cent, not a launch per component.
+// The second-best records of a committed lattice bound a proof -- except where the lattice's best
+// record is planned again with the very same lattice (the common case of a repeated peak): they
+// then lie inside a planned lattice and the next verification covers them.
+// All of that costs a launch 1.5 us of instruction issue, so two instances of the kernel are built
+// (STEPS = 1 and 8; 4 with several polarizations) and the host picks: single steps, unless the
+// start-up kernel's estimate (how many steps the eight best tiles could take before they are down
+// to the ninth) or the components per launch it sees say that the field is a dominated one.
 #include "kimg_common.h"
 #include <limits.h>
 #include <string.h>
@@ -663,7 +689,7 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
     const int adx = g.psf_w / 2 - pend_x, ady = g.psf_h / 2 - pend_y;          // psf index = image index + d
     const int bdx = g.psf_w / 2 - new_x, bdy = g.psf_h / 2 - new_y;
     float dv[4][PMAX], pa[4][PMAX], pb[4][PMAX];
-    bool inside[4], in_a[4], in_b[4], in_tile[4];
+    bool inside[4], in_a[4], in_b[4];
     const int x = ox + (tid & 31);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -672,7 +698,6 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
         in_a[k] = has_pend && inside[k] && x >= ax0 && x < ax0 + g.patch_w && y >= ay0 && y < ay0 + g.patch_h;
         in_b[k] = has_new && new_n > 0 && inside[k] && x >= bx0 && x < bx0 + g.patch_w && y >= by0
                   && y < by0 + g.patch_h;
-        in_tile[k] = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
         const int64_t ia = (int64_t) y * g.row_stride + x;
 #pragma unroll
         for (int p = 0; p < PMAX; p++) {
@@ -759,7 +784,9 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
                     // (non-negative floats order like their bit patterns)
                     const unsigned bits = __float_as_uint(metric);
                     const bool ties = t < peak_tile || (t == peak_tile && tid + 256 * k < peak_idx);
-                    beaten = beaten || (in_tile[k] && (bits > peak_bits[st + 1] || (bits == peak_bits[st + 1] && ties)));
+                    const int y = oy + (tid >> 5) + 8 * k;
+                    const bool in_tile = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
+                    beaten = beaten || (in_tile && (bits > peak_bits[st + 1] || (bits == peak_bits[st + 1] && ties)));
                 }
                 if (__builtin_amdgcn_ballot_w64(beaten))
                     fail |= 1u << (st + 1);
@@ -780,7 +807,9 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
                 }
             }
         }
-        if (in_tile[k] && metric > best) {
+        const int y = oy + (tid >> 5) + 8 * k;
+        const bool in_tile = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
+        if (in_tile && metric > best) {
             best = metric;
             best_k = k;
         }
@@ -1438,7 +1467,8 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             for (int i = 0; i < PMAX; i++)
                 ns[st_][i] = 0.0f;
             if (st_ < nsteps) {
-                peak_bits[st_] = (unsigned) lane_int((int) (unsigned) (sq[st_] >> 32), p);
+                if (STEPS > 1)
+                    peak_bits[st_] = (unsigned) lane_int((int) (unsigned) (sq[st_] >> 32), p);
 #pragma unroll
                 for (int i = 0; i < PMAX; i++)
                     ns[st_][i] = g.loop_gain * lane_float(psq[st_][i], p);     // clean.py:1044
@@ -1471,7 +1501,8 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
                     ps[st_][i] = g.loop_gain * lane_float(pq[st_][i], pend);
             }
         }
-        const unsigned plo = (unsigned) lane_int((int) (unsigned) sk, p);
+        // (the peak's tile and pixel, for the blocks' question whether it is still the first pixel)
+        const unsigned plo = STEPS > 1 ? (unsigned) lane_int((int) (unsigned) sk, p) : 0u;
         const unsigned ptile = ~(plo >> 10) & 0x3FFFFFu;
         MC_STAMP(5);
         mc_block<MODE, PMAX, STEPS>(dirty, psf, g, tx, ty, pend_n, lane_int(pc.y, pend),
@@ -1993,16 +2024,13 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         const int count = started && launches > 0 ? (int) (word & 0x7fffffffu) : 0;
         if (started && (word & 0x80000000u))
             break;
-        if (can_repeat && !hinted) {
-            if (started) {
-                hinted = true;
-                if ((int) (word & 0x7fffffffu) >= MULTI_GRAPH && launches == 0)
-                    repeating = true;
-            } else if (now_s() - t_start < 5e-3) {
-                sched_yield();          // (the start-up kernel has not finished: tens of microseconds)
-                continue;
-            } else {
-                hinted = true;          // (something else holds the stream up: go ahead)
+        if (can_repeat && !hinted && started) {
+            // (the estimate arrives with the word of launch 0; if the first launch has overtaken
+            // it, the windows below decide)
+            hinted = true;
+            if (launches == 0 && (int) (word & 0x7fffffffu) >= MULTI_GRAPH) {
+                repeating = true;
+                choice_from = enqueued;
             }
         }
         if (can_repeat && started && launches > 0) {
@@ -2039,8 +2067,11 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         // components per launch so far (at least 1, optimistic before anything is known)
         const double per = launches > 0 && count > 0 ? (double) count / launches : (double) mmax;
         int need = (int) ((max_cycles - count) / per) + 2 - in_flight;
-        if (need > 2 * MULTI_GRAPH - in_flight)
-            need = 2 * MULTI_GRAPH - in_flight;
+        // (two graphs ahead; four launches while the start-up kernel's estimate is not in: what is
+        // enqueued before it runs with single steps)
+        const int ahead = can_repeat && !hinted ? 4 : 2 * MULTI_GRAPH;
+        if (need > ahead - in_flight)
+            need = ahead - in_flight;
         if (in_flight == 0 && need < 2)
             need = 2;
         const int v = repeating ? 1 : 0;
