@@ -750,7 +750,21 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
         }
     }
     // the planned steps, in registers; between them, is the peak still the first pixel of its lattice?
+    // A pixel comes before the peak if its metric is larger, or equal and it is the earlier one (lower
+    // tile, earlier pixel of the same tile): metric bits + 1 for those, against the peak's bits
+    // (non-negative floats order like their bit patterns); pixels that are no tile's count as 0.
     unsigned fail = 0;
+    unsigned keep[4], early[4];
+    if (STEPS > 1 && new_n > 1) {
+        const int t = ty * g.tiles_x + tx;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = oy + (tid >> 5) + 8 * k;
+            const bool in_tile = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
+            keep[k] = in_tile ? 0xffffffffu : 0u;
+            early[k] = (in_tile && (t < peak_tile || (t == peak_tile && tid + 256 * k < peak_idx))) ? 1u : 0u;
+        }
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; st++) {
         if (st < new_n) {
@@ -765,7 +779,6 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
                 }
             }
             if (STEPS > 1 && st + 1 < new_n) {
-                const int t = ty * g.tiles_x + tx;
                 bool beaten = false;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -781,12 +794,7 @@ __device__ __attribute__((always_inline)) inline void mc_block(float *dirty, con
                             }
                         }
                     }
-                    // (non-negative floats order like their bit patterns)
-                    const unsigned bits = __float_as_uint(metric);
-                    const bool ties = t < peak_tile || (t == peak_tile && tid + 256 * k < peak_idx);
-                    const int y = oy + (tid >> 5) + 8 * k;
-                    const bool in_tile = inside[k] && is_tile && x < g.width - g.border && y < g.height - g.border;
-                    beaten = beaten || (in_tile && (bits > peak_bits[st + 1] || (bits == peak_bits[st + 1] && ties)));
+                    beaten = beaten || (__float_as_uint(metric) & keep[k]) + early[k] > peak_bits[st + 1];
                 }
                 if (__builtin_amdgcn_ballot_w64(beaten))
                     fail |= 1u << (st + 1);

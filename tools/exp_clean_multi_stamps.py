@@ -4,7 +4,10 @@ Average shader-clock cycles (and us at the clock measured against the wall clock
 workgroup's first instruction at which each stamped point is reached, for the keeper [K] and for the
 workgroup of block (0, 0) of the first planned lattice [L].
 
-    python tools/exp_clean_multi_stamps.py [components per launch] [cycles]"""
+    python tools/exp_clean_multi_stamps.py [components per launch] [cycles]
+
+Environment: KIMG_REPEATS (cap on the steps per lattice; 1: the single-step kernel), KIMG_REPEATS_ALWAYS (the
+repeated-steps kernel from the first launch on), KIMG_DOMINANT (amplitude of the first source)."""
 import os
 import sys
 import time
@@ -27,9 +30,10 @@ psf = np.outer(g1, g1)[None].astype(np.float32)
 psf += (0.002 * rs.standard_normal(psf.shape)).astype(np.float32)
 psf[:, G // 2, G // 2] = 1.0
 sky = (0.01 * rs.standard_normal((P, G, G))).astype(np.float32)
-for _ in range(200):
+dominant = float(os.environ.get('KIMG_DOMINANT', '0'))      # the first source at this amplitude (else as the others)
+for i in range(200):
     y, x = rs.randint(100, G - 100, 2)
-    sky[:, y - 30:y + 31, x - 30:x + 31] += rs.uniform(0.5, 2.0) * psf[:, G // 2 - 30:G // 2 + 31,
+    sky[:, y - 30:y + 31, x - 30:x + 31] += (dominant if i == 0 and dominant else rs.uniform(0.5, 2.0)) * psf[:, G // 2 - 30:G // 2 + 31,
                                                                      G // 2 - 30:G // 2 + 31]
 fixed = parameters.FixedImageParameters([0], np.float32)
 ip = parameters.ImageParameters(fixed, 1.0, None, 0.2, None, pixel_size=1e-5, pixels=G)
