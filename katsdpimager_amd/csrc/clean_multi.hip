@@ -932,7 +932,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     float centre[PMAX];
 #pragma unroll
     for (int p = 0; p < PMAX; p++)
-        centre[p] = (STEPS > 1 && (PMAX == 1 || p < g.P))
+        centre[p] = ((STEPS > 1 || role == ROLE_KEEPER) && (PMAX == 1 || p < g.P))
                         ? psf[p * g.psf_pol_stride + (int64_t) (g.psf_h / 2) * g.psf_row_stride + g.psf_w / 2]
                         : 0.0f;
     int4 old0 = make_int4(0, 0, 0, 0), old1 = old0, st4 = old0;
@@ -1367,11 +1367,37 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
             psq[st_][p] = spix[p];
     }
     sq[0] = sk;
+    int opportunity = 0;                // (single-step kernel, keeper: the repeated steps that could have been planned)
     if (STEPS == 1) {
         // (single steps, as the walk planned them; a lattice a higher peak's next value would beat
         // is found out by the next verification)
         rsteps = (!repair && lane < MC_MAX && (picked >> lane & 1u)) ? 1 : 0;
         next_steps_max = (!repair && M > 0) ? 1 : 0;
+        if (role == ROLE_KEEPER && M > 0 && !mispredicted && !zero_special && cool == 0) {
+            // What the host goes by when it chooses between the two kernels: how many more steps the
+            // planned peaks could take before they are down to what is not planned (each on its
+            // own; the second-best records left aside: the other kernel mostly lifts them).
+            mkey_t level = kmax(list_floor, overflow >= MC_REAL ? overflow | 0x3ffu : 0);
+            const unsigned u = m_real & ~picked & ~skipped;
+            if (u)
+                level = kmax(level, lane_key(sk, __builtin_ctz(u)) | 0x3ffu);
+            float v[PMAX];
+#pragma unroll
+            for (int p = 0; p < PMAX; p++)
+                v[p] = spix[p];
+            mkey_t before = sk;
+            bool going = lane < MC_MAX && (picked >> lane & 1u);
+            for (int st_ = 1; st_ < (PMAX == 1 ? MC_STEPS : MC_STEPS / 2); st_++) {
+                const float m = mc_peak_step<MODE, PMAX>(v, centre, g.loop_gain, g.P);
+                const mkey_t key = ((mkey_t) __float_as_uint(m) << 32) | (unsigned) sk;
+                going = going && key > level && key < before && !(m < threshold);
+                before = key;
+                const unsigned long long more = __builtin_amdgcn_ballot_w64(going);
+                if (!more)
+                    break;
+                opportunity += __builtin_popcountll(more);
+            }
+        }
     } else if (!repair) {
         const bool mine_picked = lane < MC_MAX && (picked >> lane & 1u);
         const int rmax = (mispredicted || zero_special || cool > 0 || limit - count < g.mmax * g.rmax)
@@ -1642,7 +1668,9 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         next->launches = st2.w + 1;
         next->gen = gen;
         next->aux = (repair ? 0 : next_steps_max) | cool_next << 8 | penalty_next << 16;
-        const int repeated = repeated0 + committed - __builtin_popcount(pendm);
+        // (the repeated-steps kernel counts the steps committed beyond the first of their lattice and
+        // launch; the single-step kernel those it could have planned)
+        const int repeated = repeated0 + (STEPS == 1 ? opportunity : committed - __builtin_popcount(pendm));
         next->repeated = repeated;
         next->pad2 = 0;
         // (what the host reads goes out last: the word in host memory is a long way off)
@@ -1650,7 +1678,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         if (progress) {
             // (the second word first, and only when it moves: whoever sees the launch counted finds
             // its other figures there)
-            if (STEPS > 1 && repeated != repeated0)
+            if (repeated != repeated0)
                 __hip_atomic_store(progress + 1, ((unsigned long long) (unsigned) gen << 32) | (unsigned) repeated,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(progress, progress_word(st2.w + 1, gen, done_now, count),
@@ -2004,10 +2032,12 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
     // the keeper says done.  Near the end the number of launches still needed is estimated from the
     // components per launch so far, so that few launches run after the loop has ended (each costs a
     // kernel boundary).
-    // Which kernel: single steps until the field shows few components per launch (a few sources far
-    // above the rest); then the repeated-steps kernel for as long as repeated steps are what gets
-    // committed, judged over windows of launches that ran wholly under the choice; a try that did
-    // not help is not repeated for a while (twice as long each time in a row).
+    // Which kernel: single steps (the first graph goes out at once) unless the start-up kernel's
+    // estimate says the field is a dominated one, or until the keeper reports that the repeated steps
+    // it could have planned are 0.4 of what a window committed; then the repeated-steps kernel
+    // for as long as repeated steps are a fifth of what gets committed, judged over windows of
+    // launches that ran wholly under the choice; a try that did not help is not repeated for a while
+    // (twice as long each time in a row).
     multi_graph *graphs[2] = {nullptr, nullptr};
     multi_args variants[2] = {a, a};
     variants[1].repeats = 1;
@@ -2015,6 +2045,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
     bool repeating = always_repeat, hinted = false;
     int choice_from = 0;                // launches enqueued before the current choice
     int wait_until = 0, backoff = 1;    // no new try before so many launches are enqueued
+    int streak = 0;                     // windows in a row that showed steps to repeat
     int win_l = 0, win_c = 0, win_r = 0;
     int enqueued = 0;
     const double t_start = now_s();
@@ -2036,7 +2067,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             // (the estimate arrives with the word of launch 0; if the first launch has overtaken
             // it, the windows below decide)
             hinted = true;
-            if (launches == 0 && (int) (word & 0x7fffffffu) >= MULTI_GRAPH) {
+            if (launches == 0 && (int) (word & 0x7fffffffu) >= 2 * MULTI_GRAPH) {
                 repeating = true;
                 choice_from = enqueued;
             }
@@ -2051,14 +2082,20 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                     win_r = repeated;
                 }
             } else if (launches - win_l >= 8) {
-                const double rate = (double) (count - win_c) / (launches - win_l);
+                // (under the single-step kernel: the repeated steps that could have been planned, as a
+                // share of what was committed; under the other: those that were committed.  A launch
+                // of the repeated-steps kernel is a sixth longer.)
                 const double share = count > win_c ? (double) (repeated - win_r) / (count - win_c) : 0.0;
                 if (!repeating) {
-                    if (rate < 4.0 && enqueued >= wait_until) {
+                    // (two windows in a row: what is enqueued now runs sixteen to thirty-two launches
+                    // from now, and a dominated phase that is over by then makes the change a loss)
+                    streak = share >= 0.4 ? streak + 1 : 0;
+                    if (streak >= 2 && enqueued >= wait_until) {
                         repeating = true;
                         choice_from = enqueued;
+                        streak = 0;
                     }
-                } else if (share < 0.1) {
+                } else if (share < 0.2) {
                     repeating = false;
                     choice_from = enqueued;
                     wait_until = enqueued + MULTI_GRAPH * backoff;
@@ -2075,9 +2112,9 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         // components per launch so far (at least 1, optimistic before anything is known)
         const double per = launches > 0 && count > 0 ? (double) count / launches : (double) mmax;
         int need = (int) ((max_cycles - count) / per) + 2 - in_flight;
-        // (two graphs ahead; four launches while the start-up kernel's estimate is not in: what is
-        // enqueued before it runs with single steps)
-        const int ahead = can_repeat && !hinted ? 4 : 2 * MULTI_GRAPH;
+        // (two graphs ahead; one while the start-up kernel's estimate is not in: what is enqueued
+        // before it runs with single steps)
+        const int ahead = can_repeat && !hinted ? MULTI_GRAPH : 2 * MULTI_GRAPH;
         if (need > ahead - in_flight)
             need = ahead - in_flight;
         if (in_flight == 0 && need < 2)

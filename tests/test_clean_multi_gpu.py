@@ -199,7 +199,8 @@ def test_multi_dominated_field(G, P, mode, patch, amplitudes, cycles):
         _check(fn, q, got, want)
         launches[name] = fn.last_launches()
     assert launches['repeated'] < 0.75 * launches['single'], launches
-    assert launches['auto'] < 0.9 * launches['single'], launches       # (the start-up estimate saw it)
+    # (the loop's own choice starts with single steps and changes over only for a phase that lasts)
+    assert launches['auto'] <= launches['single'] + 8, launches
 
 
 @pytest.mark.parametrize('seed', range(4))
