@@ -491,6 +491,24 @@ int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t po
                       float *tile_max, int32_t *tile_pos, int tiles_x, int tiles_y,
                       int max_cycles, int form, void *state, float *log, void *stream);
 
+/* The minor cycles of ONE MAJOR CYCLE in one call (the loop of frontend.py:560-585): the first cycle
+ * runs without a threshold (clean.py:879: its component is always taken); the rest stop below
+ *     max(noise_threshold, left_for_next * power of the first peak)      (frontend.py:568-575)
+ * -- or do not run at all if the first peak itself is not above that -- worked out on the device in
+ * the host's arithmetic (doubles; a metric as a flux and back as clean.py:166-184 has it), so that the
+ * host round trip between the first cycle and the others is gone.  Arguments as kimg_clean_cycles;
+ * noise_threshold = noise estimate x the clean threshold (in sigma), left_for_next = 1 - major gain;
+ * max_cycles counts the first cycle.  The log's first row is the first cycle's.  Runs where the
+ * multi-component form does (form: KIMG_CLEAN_FORM_AUTO or _MULTI with its caps); KIMG_EUNSUPPORTED
+ * otherwise, and the caller takes the two steps of the reference. */
+int kimg_clean_major_cycles(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
+                            int width, int height, int num_polarizations,
+                            const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                            int psf_width, int psf_height, int patch_width, int patch_height,
+                            int border, int mode, float loop_gain, double noise_threshold,
+                            double left_for_next, float *tile_max, int32_t *tile_pos, int tiles_x,
+                            int tiles_y, int max_cycles, int form, void *state, float *log, void *stream);
+
 /* The same loop for several channels of a band at once: cycle i of every channel runs in ONE
  * launch (the reference loops over channels serially, frontend.py:749-767, and within a channel
  * over cycles with a host round trip each, clean.py:848-891).  A minor cycle is a latency chain

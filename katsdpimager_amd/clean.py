@@ -466,6 +466,34 @@ class Clean(accel.OperationSequence):
         check(rc, 'kimg_clean_cycles')
         return self._collect_cycles() if collect else None
 
+    def run_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles):
+        """The minor cycles of one major cycle in one call (frontend.py:560-585; include/kimg.h:
+        kimg_clean_major_cycles): the first cycle runs without a threshold, the others stop below
+        ``max(noise_threshold, left_for_next * power of the first peak)`` -- worked out on the device,
+        in the host's arithmetic -- or do not run if the first peak is not above that.  Only
+        enqueues: read the results with :meth:`_collect_cycle_arrays` (the first row is the first
+        cycle's).  Returns False (and does nothing) where the form that can do this does not run:
+        the caller then takes the reference's two steps."""
+        self.ensure_all_bound()
+        if max_cycles <= 0 or (self.template.form & 0xff) not in (CLEAN_FORMS['auto'], CLEAN_FORMS['multi']):
+            return False
+        dirty, psf = self.buffer('dirty'), self.buffer('psf')
+        P, H, W = dirty.shape
+        cp = self.template.clean_parameters
+        self._ensure_log(max_cycles)
+        tile_max = self.buffer('tile_max')
+        rc = lib().kimg_clean_major_cycles(
+            dirty.ptr, self.buffer('model').ptr, W, H * W, W, H, P,
+            psf.ptr, psf.shape[2], psf.shape[1] * psf.shape[2], psf.shape[2], psf.shape[1],
+            psf_patch[2], psf_patch[1], self._update_tiles.border_pixels, cp.mode,
+            cp.loop_gain, float(noise_threshold), float(left_for_next), tile_max.ptr,
+            self.buffer('tile_pos').ptr, tile_max.shape[1], tile_max.shape[0], max_cycles,
+            self.template.form, self._state.ptr, self._log.ptr, self.command_queue.handle)
+        if rc == -10001:            # KIMG_EUNSUPPORTED
+            return False
+        check(rc, 'kimg_clean_major_cycles')
+        return True
+
     def _ensure_log(self, max_cycles):
         P = self.buffer('dirty').shape[0]
         if self._log is None or self._log.shape[0] < max_cycles:

@@ -2264,6 +2264,35 @@ void graph_release(graph_entry *entry, hipStream_t s)
 
 } // namespace
 
+// The minor cycles of one major cycle in one call (frontend.py:560-585): the first cycle runs without
+// a threshold, the threshold of the rest follows from its peak on the device.  Only where the
+// multi-component form runs (KIMG_EUNSUPPORTED otherwise: the caller takes kimg_clean_cycles then).
+extern "C" int kimg_clean_major_cycles(float *dirty, float *model, int64_t row_stride,
+                                       int64_t pol_stride, int width, int height, int num_polarizations,
+                                       const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
+                                       int psf_width, int psf_height, int patch_width, int patch_height,
+                                       int border, int mode, float loop_gain, double noise_threshold,
+                                       double left_for_next, float *tile_max, int32_t *tile_pos,
+                                       int tiles_x, int tiles_y, int max_cycles, int form, void *state,
+                                       float *log, void *stream)
+{
+    KIMG_CHECK_ARG(dirty && model && psf && tile_max && tile_pos && state && log);
+    KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && max_cycles >= 1);
+    KIMG_CHECK_ARG(patch_width > 0 && patch_height > 0 && patch_width <= psf_width
+                   && patch_height <= psf_height && tiles_x > 0 && tiles_y > 0);
+    KIMG_CHECK_ARG(mode == KIMG_CLEAN_I || mode == KIMG_CLEAN_SUMSQ);
+    KIMG_CHECK_ARG(noise_threshold == noise_threshold && left_for_next == left_for_next);      // (not NaN)
+    const int kind = form & 0xff;
+    KIMG_CHECK_ARG(kind == KIMG_CLEAN_FORM_AUTO || kind == KIMG_CLEAN_FORM_MULTI);
+    if (kimg_clean_multi_components(patch_width, patch_height, tiles_x, tiles_y) < (kind == KIMG_CLEAN_FORM_MULTI ? 1 : 2))
+        return KIMG_EUNSUPPORTED;
+    return kimg_clean_multi_run(dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf,
+                                psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width,
+                                patch_height, border, mode, loop_gain, 0.0f, tile_max, tile_pos, tiles_x,
+                                tiles_y, max_cycles, (form >> 8) & 0xff, (form >> 16) & 0x1f, true,
+                                noise_threshold, left_for_next, state, log, (hipStream_t) stream);
+}
+
 extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                                  int64_t pol_stride, int width, int height, int num_polarizations,
                                  const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
@@ -2297,7 +2326,7 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
                 dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf,
                 psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width, patch_height,
                 border, mode, loop_gain, threshold, tile_max, tile_pos, tiles_x, tiles_y,
-                max_cycles, components, repeats, state, log, s);
+                max_cycles, components, repeats, false, 0.0, 0.0, state, log, s);
             if (rc != KIMG_EUNSUPPORTED)
                 return rc;
         }

@@ -207,7 +207,9 @@ static_assert(sizeof(mc_state) == 6464, "Clean.last_launches reads `launches` at
 
 struct mc_scratch {
     int head[4];            // count, done, limit, threshold bits: what the host reads, as the other forms'
-    int pad[12];
+    int pad[12];            // [0] "MULT"; [1] the threshold follows from the call's first component;
+                            // [2..3], [4..5] two doubles: the noise threshold and the share of the first
+                            // peak that is left for the next major cycle (kimg_clean_major_cycles)
     mc_state st[2];         // by launch parity
     mc_record deltas[2][MC_THREADS];    // slot = lattice * seg + block
     // float tile_pix[tiles][4] follows
@@ -947,8 +949,31 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         st4 = *reinterpret_cast<const int4 *>(&cur->top_floor);
     }
     const int count0 = st.x, done = st.y, limit = st.z;
-    const float threshold = __int_as_float(st.w);
+    float threshold = __int_as_float(st.w);
     const int Mp = st2.x, top_n = st2.y, tau = st2.z;
+    // A call whose threshold follows from its first component (frontend.py:560-575: one cycle
+    // without a threshold, then threshold = max(noise threshold, (1 - major gain) x that peak) for
+    // the rest -- or no further cycle if the peak itself is not above it): the first launch plans
+    // that one component, the second commits it and works the threshold out, in the host's
+    // arithmetic (doubles; clean.py:166-184 for what a metric is as a flux).
+    bool first_alone = false, stop_after_first = false;
+    if (count0 == 0 && !done && scratch->pad[1]) {
+        if (Mp == 0) {
+            first_alone = true;
+            threshold = 0.0f;
+        } else {
+            const double noise_threshold = *reinterpret_cast<const double *>(&scratch->pad[2]);
+            const double left = *reinterpret_cast<const double *>(&scratch->pad[4]);
+            const mc_record *first = &cur->plan[0];
+            const double metric = (double) __uint_as_float((unsigned) (first->key >> 32));
+            const double power = MODE == KIMG_CLEAN_I ? metric : sqrt(metric);
+            const double mgain = left * power;
+            const double t = noise_threshold > mgain ? noise_threshold : mgain;
+            stop_after_first = power <= t;
+            threshold = (float) (MODE == KIMG_CLEAN_I ? t : t * t);
+        }
+    }
+    const int threshold_bits = __float_as_int(threshold);
     const int rest_n = min(top_n, MC_REST);
     if (done) {
         if (role == ROLE_KEEPER && tid == 0) {
@@ -1315,7 +1340,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         // (the first candidate is the largest tile of the image if it beats every tile that is not
         // listed; with an entry of the list in the pool it does)
         const bool first_proven = nsurv > 0 || mispredicted || lane_key(sk, 0) > list_floor;
-        const unsigned room = (unsigned) min(mispredicted ? 1 : g.mmax, limit - count);
+        const unsigned room = (unsigned) min(mispredicted || first_alone ? 1 : g.mmax, limit - count);
         // the walk considers the candidates in order while each is real, proven to be next (above
         // everything outside the pool) and passes the threshold: a prefix of the positions
         const unsigned elig = m_real & m_thr & (m_above | (first_proven ? 1u : 0u))
@@ -1349,6 +1374,11 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
     }
     if (role == ROLE_NEW)
         MC_STAMP(11);
+    if (stop_after_first) {
+        picked = 0;
+        M = 0;
+        done_now = true;
+    }
     // ---- how many steps each planned lattice takes -------------------------------------------------
     // The plan is the merge of the planned lattices' sequences sq[0] > sq[1] > ... (the value at the
     // peak before each of its steps) above a level below which nothing is proven: the bound of the
@@ -1400,7 +1430,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         }
     } else if (!repair) {
         const bool mine_picked = lane < MC_MAX && (picked >> lane & 1u);
-        const int rmax = (mispredicted || zero_special || cool > 0 || limit - count < g.mmax * g.rmax)
+        const int rmax = (mispredicted || zero_special || first_alone || cool > 0 || limit - count < g.mmax * g.rmax)
                              ? 1 : min(g.rmax, STEPS);
         mkey_t level = bound2;
         {
@@ -1663,7 +1693,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         } else if (steps_max > 1 && !mispredicted) {
             penalty_next = MC_COOL;
         }
-        *reinterpret_cast<int4 *>(next) = make_int4(count, done_now ? 1 : 0, limit, st.w);
+        *reinterpret_cast<int4 *>(next) = make_int4(count, done_now ? 1 : 0, limit, first_alone ? st.w : threshold_bits);
         next->planned = M;
         next->launches = st2.w + 1;
         next->gen = gen;
@@ -1674,7 +1704,7 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         next->repeated = repeated;
         next->pad2 = 0;
         // (what the host reads goes out last: the word in host memory is a long way off)
-        *reinterpret_cast<int4 *>(scratch->head) = make_int4(count, done_now ? 1 : 0, limit, st.w);
+        *reinterpret_cast<int4 *>(scratch->head) = make_int4(count, done_now ? 1 : 0, limit, first_alone ? st.w : threshold_bits);
         if (progress) {
             // (the second word first, and only when it moves: whoever sees the launch counted finds
             // its other figures there)
@@ -1710,6 +1740,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
                                                             const int32_t *tile_pos, mc_geom g,
                                                             mc_scratch *scratch, int limit,
                                                             float threshold, int gen, int mode,
+                                                            int relative, double noise_threshold, double left,
                                                             unsigned long long *progress)
 {
     __shared__ rest_lds sr;
@@ -1732,6 +1763,9 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
         st->gen = gen;
         *reinterpret_cast<int4 *>(scratch->head) = make_int4(0, 0, limit, __float_as_int(threshold));
         scratch->pad[0] = 0x4d554c54;   // "MULT": which form the buffer holds (Clean.last_launches)
+        scratch->pad[1] = relative;
+        *reinterpret_cast<double *>(&scratch->pad[2]) = noise_threshold;
+        *reinterpret_cast<double *>(&scratch->pad[4]) = left;
     }
 #ifdef KIMG_MC_STAMPS
     long long dbg_v[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1981,6 +2015,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          int psf_height, int patch_width, int patch_height, int border, int mode,
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
                          int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
+                         bool relative, double noise_threshold, double left_for_next,
                          void *state, float *log, hipStream_t s)
 {
     int mmax = kimg_clean_multi_components(patch_width, patch_height, tiles_x, tiles_y);
@@ -2025,7 +2060,8 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             dirty, row_stride, pol_stride, width, height, num_polarizations, tile_pos,
             tiles_x * tiles_y, a.scratch);
         mc_init_kernel<<<1, MC_THREADS, 0, s>>>(tile_max, tile_pos, a.g, a.scratch, max_cycles,
-                                                threshold, (int) gen, mode, a.progress);
+                                                threshold, (int) gen, mode, relative ? 1 : 0, noise_threshold,
+                                                left_for_next, a.progress);
         rc = kimg_launch_status();
     }
     // Pace: keep the device a graph or two ahead of what has been seen to complete, and stop when

@@ -36,6 +36,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          int psf_height, int patch_width, int patch_height, int border, int mode,
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
                          int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
+                         bool relative, double noise_threshold, double left_for_next,
                          void *state, float *log, hipStream_t s);
 
 constexpr int WAVE = 64;    // gfx950 wavefront

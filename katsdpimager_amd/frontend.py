@@ -156,19 +156,36 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
             with trace.range('noise_est'):
                 noise = imager.noise_est()      # (waits for the gridding: the turn ends here)
             out['noise'] = noise
-        with trace.range('first_cycle'):
-            imager.clean_reset()
-            peak_value = imager.clean_cycle(psf_patch)
-        out['peaks'].append(peak_value)
-        peak_power = clean.metric_to_power(clean_p.mode, peak_value)
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
                                                               num_pols)
+        values = None
+        if batched_clean and clean_batcher is None and hasattr(imager, 'clean_major_cycles') \
+                and noise_threshold == noise_threshold:         # (not NaN)
+            # the first cycle and the others in one call: the threshold follows from the first
+            # peak on the device, in this arithmetic (no host round trip in between)
+            with trace.range('clean[%d]' % i):
+                imager.clean_reset()
+                values = imager.clean_major_cycles(psf_patch, noise_threshold,
+                                                   1.0 - clean_p.major_gain, clean_p.minor)
+        if values:
+            peak_value = values[0]
+            values = values[1:]
+        else:
+            values = None
+            with trace.range('first_cycle'):
+                imager.clean_reset()
+                peak_value = imager.clean_cycle(psf_patch)
+        out['peaks'].append(peak_value)
+        peak_power = clean.metric_to_power(clean_p.mode, peak_value)
         mgain_threshold = (1.0 - clean_p.major_gain) * peak_power
         threshold = max(noise_threshold, mgain_threshold)
         if peak_power <= threshold:
             break
         threshold_metric = clean.power_to_metric(clean_p.mode, threshold)
-        if batched_clean:
+        if values is not None:
+            # the reference counts the cycle that found the peak below threshold too (:579-582)
+            out['minor'] += len(values) + (1 if len(values) < clean_p.minor - 1 else 0)
+        elif batched_clean:
             with trace.range('clean[%d]' % i):
                 if clean_batcher is not None:
                     values = imager.clean_cycles(psf_patch, threshold_metric, clean_p.minor - 1,

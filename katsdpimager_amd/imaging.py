@@ -663,6 +663,20 @@ class Imaging(accel.OperationSequence):
             self._pending_components.append((positions, pixels))
         return values.tolist()
 
+    @_serial
+    def clean_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles):
+        """The minor cycles of one major cycle (the first one included) in one call, the threshold
+        following from the first peak on the device (:meth:`clean.Clean.run_major_cycles`): the list
+        of peak metrics, or None where that is not available (the caller then runs
+        :meth:`clean_cycle` and :meth:`clean_cycles` as the reference does)."""
+        self._ready()
+        if not self._clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
+            return None
+        values, positions, pixels = self._clean._collect_cycle_arrays()
+        if len(values):
+            self._pending_components.append((positions, pixels))
+        return values.tolist()
+
     def _record_many(self, positions, pixels):
         """:meth:`_record` for a whole call's components at once: the fluxes of every position are
         added in cycle order (``np.add.at`` is unbuffered and goes through its indices in order),

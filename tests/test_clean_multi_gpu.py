@@ -239,3 +239,90 @@ def test_multi_repeated_steps_continue_and_stop():
             want.append((v, ref.last_pos, np.array(pix)))
         got = fn.run_cycles(patch, threshold, cycles)
         _check(fn, q, got, (want, img, model, ref._tile_max, ref._tile_pos))
+
+
+@pytest.mark.parametrize('case', ['deep', 'stops after the first', 'noise decides', 'limit', 'one cycle'])
+@pytest.mark.parametrize('mode,P', [(0, 1), (1, 1), (1, 3), (0, 2)])
+def test_major_cycles_in_one_call(mode, P, case):
+    """kimg_clean_major_cycles: the first cycle without a threshold and the others below
+    max(noise threshold, (1 - major gain) x the first peak), worked out on the device -- against the
+    two steps of the reference (frontend.py:560-585) on the restated CleanHost, with the threshold
+    made on the host the way the frontend makes it."""
+    from katsdpimager_amd import clean
+    G = 512
+    rs, psf, dirty = dominated_problem(90 + P + 4 * mode, G=G, P=P, n_sources=40,
+                                       amplitudes=(6.0,) if case == 'stops after the first' else (3.0, 2.5))
+    patch = (P, 47, 33)
+    major_gain = 0.999 if case == 'deep' else 0.05 if case == 'stops after the first' else 0.85
+    minor = {'limit': 40, 'one cycle': 1}.get(case, 400)
+    img, model = dirty.copy(), np.zeros_like(dirty)
+    ref = orc.Clean(G, 0.02, 0.1, mode, img, psf, model)
+    ref.reset()
+    v, pos, pix = ref(patch, 0.0)
+    want = [(v, ref.last_pos, np.array(pix))]
+    peak_power = clean.metric_to_power(mode, float(v))
+    noise = (0.12 * peak_power if case == 'noise decides' else 1e-4 * peak_power)
+    noise_threshold = noise * clean.noise_threshold_scale(mode, 5.0, P)
+    threshold = max(noise_threshold, (1.0 - major_gain) * peak_power)
+    if peak_power > threshold:
+        metric = float(np.float32(clean.power_to_metric(mode, threshold)))
+        for _ in range(minor - 1):
+            v, pos, pix = ref(patch, metric)
+            if v is None:
+                break
+            want.append((v, ref.last_pos, np.array(pix)))
+    if case == 'stops after the first':
+        assert len(want) == 1
+    elif case == 'limit':
+        assert len(want) == minor
+    elif case == 'noise decides':
+        assert 1 < len(want) < minor
+    elif case == 'deep':
+        assert len(want) > 100
+    for tuning in ({'form': 'multi'}, {'form': 'auto', 'repeats_always': True}):
+        fn, q = _clean(G, P, mode, 0.02, 0.1, dirty, psf, tuning)
+        assert fn.run_major_cycles(patch, noise_threshold, 1.0 - major_gain, minor)
+        values, positions, pixels = fn._collect_cycle_arrays()
+        got = [(values[i], tuple(positions[i]), pixels[i]) for i in range(len(values))]
+        _check(fn, q, got, (want, img, model, ref._tile_max, ref._tile_pos))
+
+
+def test_major_cycles_thresholds_as_the_host_makes_them():
+    """The threshold the device works out from the first peak is the float32 the host would pass:
+    for many peaks and both metrics, stopping exactly where the host's threshold stops."""
+    from katsdpimager_amd import clean
+    G = 256
+    rs = np.random.RandomState(7)
+    g1 = np.exp(-0.5 * ((np.arange(G) - G // 2) / 2.0) ** 2)
+    for trial in range(12):
+        mode = trial % 2
+        P = 1 + trial % 3 if mode else 1
+        psf = np.repeat(np.outer(g1, g1)[None], P, axis=0).astype(np.float32)
+        dirty = (0.001 * rs.standard_normal((P, G, G))).astype(np.float32)
+        # a ladder of isolated sources: the loop stops between two rungs, where the threshold falls
+        amps = np.sort(rs.uniform(0.2, 3.0, 30))[::-1]
+        for k, amp in enumerate(amps):
+            y, x = 20 + 40 * (k // 6), 20 + 40 * (k % 6)
+            dirty[:, y, x] += np.float32(amp) * rs.uniform(0.5, 1.0, P).astype(np.float32)
+        major_gain = float(rs.uniform(0.3, 0.95))
+        img, model = dirty.copy(), np.zeros_like(dirty)
+        ref = orc.Clean(G, 0.02, 1.0, mode, img, psf, model)
+        ref.reset()
+        patch = (P, 9, 9)
+        v, pos, pix = ref(patch, 0.0)
+        want = [(v, ref.last_pos, np.array(pix))]
+        peak_power = clean.metric_to_power(mode, float(v))
+        noise_threshold = float(rs.uniform(0.05, 0.5)) * clean.noise_threshold_scale(mode, 5.0, P)
+        threshold = max(noise_threshold, (1.0 - major_gain) * peak_power)
+        if peak_power > threshold:
+            metric = float(np.float32(clean.power_to_metric(mode, threshold)))
+            for _ in range(99):
+                v, pos, pix = ref(patch, metric)
+                if v is None:
+                    break
+                want.append((v, ref.last_pos, np.array(pix)))
+        fn, q = _clean(G, P, mode, 0.02, 1.0, dirty, psf, {'form': 'multi'})
+        assert fn.run_major_cycles(patch, noise_threshold, 1.0 - major_gain, 100)
+        values, positions, pixels = fn._collect_cycle_arrays()
+        got = [(values[i], tuple(positions[i]), pixels[i]) for i in range(len(values))]
+        _check(fn, q, got, (want, img, model, ref._tile_max, ref._tile_pos))
