@@ -775,6 +775,28 @@ class CleanBatcher:
                     e['ready'] = True
             self._cond.notify_all()
 
+    def run_major_cycles(self, clean, psf_patch, noise_threshold, left_for_next, max_cycles):
+        """``clean.run_major_cycles(...)`` (the minor cycles of a major cycle in one call, first
+        cycle included) for a channel whose cycles run on their own anyway (:func:`prefers_solo`):
+        nobody waits for it, and it waits for nobody.  Returns ``Clean._collect_cycle_arrays()``, or
+        None if the channel's cycles are of the kind that shares launches (the caller then runs the
+        first cycle itself and comes back with :meth:`run_cycles`)."""
+        import threading
+        if max_cycles <= 0 or not prefers_solo(clean, psf_patch, max_cycles):
+            return None
+        with self._cond:
+            self._expected.discard(threading.get_ident())
+            self._cleaning += 1
+            self._cond.notify_all()
+        try:
+            if not clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
+                return None
+            return clean._collect_cycle_arrays()
+        finally:
+            with self._cond:
+                self._cleaning -= 1
+                self._cond.notify_all()
+
     def run_cycles(self, clean, psf_patch, threshold, max_cycles, arrays=False):
         """``clean.run_cycles(psf_patch, threshold, max_cycles)``, sharing its launches with the
         other channels in flight.  ``arrays``: return ``Clean._collect_cycle_arrays()`` instead of

@@ -159,14 +159,19 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
                                                               num_pols)
         values = None
-        if batched_clean and clean_batcher is None and hasattr(imager, 'clean_major_cycles') \
+        if batched_clean and hasattr(imager, 'clean_major_cycles') \
                 and noise_threshold == noise_threshold:         # (not NaN)
             # the first cycle and the others in one call: the threshold follows from the first
             # peak on the device, in this arithmetic (no host round trip in between)
             with trace.range('clean[%d]' % i):
                 imager.clean_reset()
-                values = imager.clean_major_cycles(psf_patch, noise_threshold,
-                                                   1.0 - clean_p.major_gain, clean_p.minor)
+                if clean_batcher is not None:
+                    values = imager.clean_major_cycles(psf_patch, noise_threshold,
+                                                       1.0 - clean_p.major_gain, clean_p.minor,
+                                                       batcher=clean_batcher)
+                else:
+                    values = imager.clean_major_cycles(psf_patch, noise_threshold,
+                                                       1.0 - clean_p.major_gain, clean_p.minor)
         if values:
             peak_value = values[0]
             values = values[1:]

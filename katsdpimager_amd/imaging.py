@@ -664,15 +664,23 @@ class Imaging(accel.OperationSequence):
         return values.tolist()
 
     @_serial
-    def clean_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles):
+    def clean_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles, batcher=None):
         """The minor cycles of one major cycle (the first one included) in one call, the threshold
         following from the first peak on the device (:meth:`clean.Clean.run_major_cycles`): the list
         of peak metrics, or None where that is not available (the caller then runs
-        :meth:`clean_cycle` and :meth:`clean_cycles` as the reference does)."""
+        :meth:`clean_cycle` and :meth:`clean_cycles` as the reference does).  ``batcher``: the
+        :class:`clean.CleanBatcher` of the channels in flight, which has to know."""
         self._ready()
-        if not self._clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
-            return None
-        values, positions, pixels = self._clean._collect_cycle_arrays()
+        if batcher is not None:
+            arrays = batcher.run_major_cycles(self._clean, psf_patch, noise_threshold, left_for_next,
+                                              max_cycles)
+            if arrays is None:
+                return None
+            values, positions, pixels = arrays
+        else:
+            if not self._clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
+                return None
+            values, positions, pixels = self._clean._collect_cycle_arrays()
         if len(values):
             self._pending_components.append((positions, pixels))
         return values.tolist()
