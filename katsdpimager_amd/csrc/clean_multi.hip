@@ -2156,6 +2156,14 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         if (in_flight == 0 && need < 2)
             need = 2;
         const int v = repeating ? 1 : 0;
+        if (enqueued == 0 && need >= MULTI_GRAPH) {
+            // (a graph takes the host tens of microseconds to launch, the start-up kernels are over
+            // sooner: two plain launches bridge the gap)
+            for (int i = 0; i < 2 && rc == 0; i++)
+                rc = enqueue_launch(a, s, i & 1, repeating, i == 1 ? 1 : a.g.rmax);
+            enqueued += 2;
+            continue;
+        }
 #ifndef KIMG_MC_NO_GRAPH
         if (need >= MULTI_GRAPH && !graphs[v])
             graphs[v] = multi_graph_for(variants[v], s);
