@@ -500,14 +500,19 @@ int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride, int64_t po
  * noise_threshold = noise estimate x the clean threshold (in sigma), left_for_next = 1 - major gain;
  * max_cycles counts the first cycle.  The log's first row is the first cycle's.  Runs where the
  * multi-component form does (form: KIMG_CLEAN_FORM_AUTO or _MULTI with its caps); KIMG_EUNSUPPORTED
- * otherwise, and the caller takes the two steps of the reference. */
+ * otherwise, and the caller takes the two steps of the reference.
+ * cycles_done, first_peak (host pointers, either may be null): the number of cycles done and the
+ * metric of the first one, which the call has from the words the device writes for it -- what a
+ * driver needs to decide on the next major cycle without reading the device back (state and log can
+ * then be fetched while the next stage runs). */
 int kimg_clean_major_cycles(float *dirty, float *model, int64_t row_stride, int64_t pol_stride,
                             int width, int height, int num_polarizations,
                             const float *psf, int64_t psf_row_stride, int64_t psf_pol_stride,
                             int psf_width, int psf_height, int patch_width, int patch_height,
                             int border, int mode, float loop_gain, double noise_threshold,
                             double left_for_next, float *tile_max, int32_t *tile_pos, int tiles_x,
-                            int tiles_y, int max_cycles, int form, void *state, float *log, void *stream);
+                            int tiles_y, int max_cycles, int form, void *state, float *log, void *stream,
+                            int *cycles_done, float *first_peak);
 
 /* The same loop for several channels of a band at once: cycle i of every channel runs in ONE
  * launch (the reference loops over channels serially, frontend.py:749-767, and within a channel

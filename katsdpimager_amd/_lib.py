@@ -84,7 +84,7 @@ PROTOTYPES = {
     'kimg_clean_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, F,
                                   P, P, I, I, I, I, P, P, P]),
     'kimg_clean_major_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, c_double, c_double,
-                                        P, P, I, I, I, I, P, P, P]),
+                                        P, P, I, I, I, I, P, P, P, P, P]),
     'kimg_clean_cycles_batch': (c_int, [P, I, L, L, I, I, I, L, L, I, I, I, I, F, I, I, P]),
 }
 

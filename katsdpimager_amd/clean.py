@@ -407,6 +407,9 @@ class Clean(accel.OperationSequence):
             np.int32, queue=command_queue)
         self._log = None
         self._log_rows = 0
+        # the read-back run_major_cycles starts: its stream, its pinned buffer, (event, rows) while
+        # it is in flight, (host copy, rows) once it has arrived
+        self._read_stream = self._read_host = self._read_back = self._read_result = None
 
     def _run(self):
         raise NotImplementedError('use __call__(psf_patch, threshold) or run_cycles')
@@ -472,8 +475,12 @@ class Clean(accel.OperationSequence):
         ``max(noise_threshold, left_for_next * power of the first peak)`` -- worked out on the device,
         in the host's arithmetic -- or do not run if the first peak is not above that.  Only
         enqueues: read the results with :meth:`_collect_cycle_arrays` (the first row is the first
-        cycle's).  Returns False (and does nothing) where the form that can do this does not run:
-        the caller then takes the reference's two steps."""
+        cycle's).  Returns (cycles done, metric of the first one) -- which the call has without
+        reading the device back; the read-back of state and log is started on a stream of its own, so
+        that whatever the caller enqueues next does not wait for it -- or False (having done nothing)
+        where the form that can do this does not run: the caller then takes the reference's two
+        steps."""
+        import ctypes
         self.ensure_all_bound()
         if max_cycles <= 0 or (self.template.form & 0xff) not in (CLEAN_FORMS['auto'], CLEAN_FORMS['multi']):
             return False
@@ -482,19 +489,62 @@ class Clean(accel.OperationSequence):
         cp = self.template.clean_parameters
         self._ensure_log(max_cycles)
         tile_max = self.buffer('tile_max')
+        done, first = ctypes.c_int(0), ctypes.c_float(0.0)
         rc = lib().kimg_clean_major_cycles(
             dirty.ptr, self.buffer('model').ptr, W, H * W, W, H, P,
             psf.ptr, psf.shape[2], psf.shape[1] * psf.shape[2], psf.shape[2], psf.shape[1],
             psf_patch[2], psf_patch[1], self._update_tiles.border_pixels, cp.mode,
             cp.loop_gain, float(noise_threshold), float(left_for_next), tile_max.ptr,
             self.buffer('tile_pos').ptr, tile_max.shape[1], tile_max.shape[0], max_cycles,
-            self.template.form, self._state.ptr, self._log.ptr, self.command_queue.handle)
+            self.template.form, self._state.ptr, self._log.ptr, self.command_queue.handle,
+            ctypes.byref(done), ctypes.byref(first))
         if rc == -10001:            # KIMG_EUNSUPPORTED
             return False
         check(rc, 'kimg_clean_major_cycles')
-        return True
+        self._start_read_back()
+        return int(done.value), float(first.value)
+
+    def _start_read_back(self):
+        """State head and log on their way to pinned host memory, on a stream of their own behind
+        what the queue holds now (nothing of the caller's next stage waits for the copy, and the
+        copy does not wait for that stage)."""
+        import torch
+        q = self.command_queue
+        self._state.used_on(q)
+        self._log.used_on(q)
+        rows = min(self._log_rows, self._log.shape[0])
+        n = 4 + rows * self._log.shape[1]
+        if self._read_stream is None:
+            self._read_stream = torch.cuda.Stream(device=q.stream.device)
+        if self._read_host is None or self._read_host.numel() < n:
+            self._read_host = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(q.stream)
+        with torch.cuda.stream(self._read_stream):
+            self._read_stream.wait_event(ready)
+            head = self._state.tensor.reshape(-1)[:4]
+            if head.dtype != torch.float32:
+                head = head.view(torch.float32)
+            self._read_host[:4].copy_(head, non_blocking=True)
+            self._read_host[4:n].copy_(self._log.tensor[:rows].reshape(-1), non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._read_stream)
+        # (the queue's next work on these buffers comes after the copy: _finish_read_back)
+        self._read_back = (copied, rows)
+
+    def _finish_read_back(self):
+        """Wait for a read-back in flight (before the state or the log are written again) and keep
+        what it brought."""
+        if self._read_back is not None:
+            copied, rows = self._read_back
+            self._read_back = None
+            copied.synchronize()
+            both = self._read_host[:4 + rows * self._log.shape[1]].numpy().copy()
+            self._read_result = (both, rows)
 
     def _ensure_log(self, max_cycles):
+        self._finish_read_back()
+        self._read_result = None        # (of the loop before this one)
         P = self.buffer('dirty').shape[0]
         if self._log is None or self._log.shape[0] < max_cycles:
             self._log = accel.DeviceArray(self.command_queue.context, (max_cycles, 3 + P),
@@ -508,15 +558,19 @@ class Clean(accel.OperationSequence):
         # replicas, tens of megabytes)
         # ... and state and log in ONE read-back (each is a host round trip)
         import torch
-        q = self.command_queue
-        self._state.used_on(q)
-        self._log.used_on(q)
-        with torch.cuda.stream(q.stream):
-            head = self._state.tensor.reshape(-1)[:4]
-            if head.dtype != torch.float32:
-                head = head.view(torch.float32)
-            rows = min(self._log_rows, self._log.shape[0])
-            both = torch.cat([head, self._log.tensor[:rows].reshape(-1)]).cpu().numpy()
+        self._finish_read_back()
+        if self._read_result is not None:
+            both, rows = self._read_result      # (run_major_cycles started the read-back itself)
+        else:
+            q = self.command_queue
+            self._state.used_on(q)
+            self._log.used_on(q)
+            with torch.cuda.stream(q.stream):
+                head = self._state.tensor.reshape(-1)[:4]
+                if head.dtype != torch.float32:
+                    head = head.view(torch.float32)
+                rows = min(self._log_rows, self._log.shape[0])
+                both = torch.cat([head, self._log.tensor[:rows].reshape(-1)]).cpu().numpy()
         state = both[:4].view(np.int32)
         if int(state[1]) == 2:
             check(-10004, 'kimg_clean_cycles')       # KIMG_ETIMEOUT: the persistent loop gave up
@@ -778,9 +832,9 @@ class CleanBatcher:
     def run_major_cycles(self, clean, psf_patch, noise_threshold, left_for_next, max_cycles):
         """``clean.run_major_cycles(...)`` (the minor cycles of a major cycle in one call, first
         cycle included) for a channel whose cycles run on their own anyway (:func:`prefers_solo`):
-        nobody waits for it, and it waits for nobody.  Returns ``Clean._collect_cycle_arrays()``, or
-        None if the channel's cycles are of the kind that shares launches (the caller then runs the
-        first cycle itself and comes back with :meth:`run_cycles`)."""
+        nobody waits for it, and it waits for nobody.  Returns what that returns -- (cycles done,
+        metric of the first) -- or None if the channel's cycles are of the kind that shares launches
+        (the caller then runs the first cycle itself and comes back with :meth:`run_cycles`)."""
         import threading
         if max_cycles <= 0 or not prefers_solo(clean, psf_patch, max_cycles):
             return None
@@ -789,9 +843,7 @@ class CleanBatcher:
             self._cleaning += 1
             self._cond.notify_all()
         try:
-            if not clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
-                return None
-            return clean._collect_cycle_arrays()
+            return clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles) or None
         finally:
             with self._cond:
                 self._cleaning -= 1

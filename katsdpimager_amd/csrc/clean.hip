@@ -2274,7 +2274,7 @@ extern "C" int kimg_clean_major_cycles(float *dirty, float *model, int64_t row_s
                                        int border, int mode, float loop_gain, double noise_threshold,
                                        double left_for_next, float *tile_max, int32_t *tile_pos,
                                        int tiles_x, int tiles_y, int max_cycles, int form, void *state,
-                                       float *log, void *stream)
+                                       float *log, void *stream, int *cycles_done, float *first_peak)
 {
     KIMG_CHECK_ARG(dirty && model && psf && tile_max && tile_pos && state && log);
     KIMG_CHECK_ARG(num_polarizations >= 1 && num_polarizations <= 4 && max_cycles >= 1);
@@ -2290,7 +2290,8 @@ extern "C" int kimg_clean_major_cycles(float *dirty, float *model, int64_t row_s
                                 psf_row_stride, psf_pol_stride, psf_width, psf_height, patch_width,
                                 patch_height, border, mode, loop_gain, 0.0f, tile_max, tile_pos, tiles_x,
                                 tiles_y, max_cycles, (form >> 8) & 0xff, (form >> 16) & 0x1f, true,
-                                noise_threshold, left_for_next, state, log, (hipStream_t) stream);
+                                noise_threshold, left_for_next, state, log, (hipStream_t) stream, cycles_done,
+                                first_peak);
 }
 
 extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,

@@ -974,6 +974,9 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         }
     }
     const int threshold_bits = __float_as_int(threshold);
+    if (count0 == 0 && !done && Mp > 0 && role == ROLE_KEEPER && tid == 0 && progress && scratch->pad[1])
+        __hip_atomic_store(progress + 2, ((unsigned long long) (unsigned) gen << 32) | (unsigned) (cur->plan[0].key >> 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int rest_n = min(top_n, MC_REST);
     if (done) {
         if (role == ROLE_KEEPER && tid == 0) {
@@ -1792,6 +1795,9 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
         }
         __hip_atomic_store(progress + 1, (unsigned long long) (unsigned) gen << 32, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+        // (the first component's metric comes later: until then a tag no call has)
+        __hip_atomic_store(progress + 2, (unsigned long long) ((unsigned) gen ^ 0x8000u) << 32, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(progress, progress_word(0, gen, false, (int) steps), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -2016,7 +2022,7 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
                          int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
                          bool relative, double noise_threshold, double left_for_next,
-                         void *state, float *log, hipStream_t s)
+                         void *state, float *log, hipStream_t s, int *cycles_done, float *first_peak)
 {
     int mmax = kimg_clean_multi_components(patch_width, patch_height, tiles_x, tiles_y);
     if (mmax < 1 || ((uintptr_t) tile_max & 15) || ((uintptr_t) tile_pos & 7))
@@ -2212,6 +2218,30 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
             }
         }
         sched_yield();
+    }
+    if (rc == 0 && (cycles_done || first_peak)) {
+        // what the caller can have without reading the device back: the count of the word that said
+        // done, and the first component's metric (the keeper's word of the launch that committed it)
+        const unsigned long long word = seen[0], word2 = seen[2];
+        int count = (int) (word & 0x7fffffffu);
+        float peak = 0.0f;
+        bool have_peak = (word2 >> 32) == gen;
+        if (have_peak) {
+            const unsigned bits = (unsigned) word2;
+            memcpy(&peak, &bits, sizeof(peak));
+        }
+        if (first_peak && !have_peak && count > 0) {
+            // (the word did not arrive -- the fall-back path above ended the loop: read the log)
+            he = hipMemcpyAsync(&peak, log, sizeof(float), hipMemcpyDeviceToHost, s);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(s);
+            if (he != hipSuccess)
+                rc = -(int) he;
+        }
+        if (cycles_done)
+            *cycles_done = count;
+        if (first_peak)
+            *first_peak = peak;
     }
     for (int v = 0; v < 2; v++)
         if (graphs[v])

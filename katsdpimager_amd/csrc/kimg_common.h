@@ -37,7 +37,8 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
                          float loop_gain, float threshold, float *tile_max, int32_t *tile_pos,
                          int tiles_x, int tiles_y, int max_cycles, int components, int repeats,
                          bool relative, double noise_threshold, double left_for_next,
-                         void *state, float *log, hipStream_t s);
+                         void *state, float *log, hipStream_t s, int *cycles_done = nullptr,
+                         float *first_peak = nullptr);
 
 constexpr int WAVE = 64;    // gfx950 wavefront
 

@@ -172,11 +172,12 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
                 else:
                     values = imager.clean_major_cycles(psf_patch, noise_threshold,
                                                        1.0 - clean_p.major_gain, clean_p.minor)
+        rest = None                     # cycles after the first, where one call ran them all
         if values:
-            peak_value = values[0]
-            values = values[1:]
-        else:
+            peak_value, cycles = values
+            rest = cycles - 1
             values = None
+        if rest is None:
             with trace.range('first_cycle'):
                 imager.clean_reset()
                 peak_value = imager.clean_cycle(psf_patch)
@@ -187,9 +188,9 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
         if peak_power <= threshold:
             break
         threshold_metric = clean.power_to_metric(clean_p.mode, threshold)
-        if values is not None:
+        if rest is not None:
             # the reference counts the cycle that found the peak below threshold too (:579-582)
-            out['minor'] += len(values) + (1 if len(values) < clean_p.minor - 1 else 0)
+            out['minor'] += rest + (1 if rest < clean_p.minor - 1 else 0)
         elif batched_clean:
             with trace.range('clean[%d]' % i):
                 if clean_batcher is not None:

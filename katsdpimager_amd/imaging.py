@@ -622,6 +622,7 @@ class Imaging(accel.OperationSequence):
         folded into the dictionary when somebody asks for it (``model_to_predict``, tests): with
         degridding nobody does, and a thousand dictionary updates per major cycle are 0.5 ms of
         host time that the next channel's launches would wait for."""
+        self._settle_components()
         for positions, pixels in self._pending_components:
             self._record_many([tuple(p) for p in positions.tolist()], pixels)
         del self._pending_components[:]
@@ -636,6 +637,7 @@ class Imaging(accel.OperationSequence):
     def clean_cycle(self, psf_patch, threshold=0.0):
         """One minor cycle; returns the peak metric or None (imaging.py:389-396)."""
         self._ready()
+        self._settle_components()
         peak_value, peak_pos, model_pixel = self._clean(psf_patch, threshold)
         if peak_pos is not None:
             # (kept with the pending arrays: folding a thousand components of the last major
@@ -651,6 +653,7 @@ class Imaging(accel.OperationSequence):
         (a :class:`clean.CleanBatcher` shared by the channels imaged concurrently) lets the cycles
         of those channels share their launches; the results are the same."""
         self._ready()
+        self._settle_components()
         if max_cycles <= 0:
             return []
         if batcher is not None:
@@ -666,24 +669,32 @@ class Imaging(accel.OperationSequence):
     @_serial
     def clean_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles, batcher=None):
         """The minor cycles of one major cycle (the first one included) in one call, the threshold
-        following from the first peak on the device (:meth:`clean.Clean.run_major_cycles`): the list
-        of peak metrics, or None where that is not available (the caller then runs
+        following from the first peak on the device (:meth:`clean.Clean.run_major_cycles`).  Returns
+        (metric of the first cycle, cycles done) -- which the call has without reading the device
+        back: the components themselves are on their way on a stream of their own and are looked at
+        when somebody asks for them -- or None where that is not available (the caller then runs
         :meth:`clean_cycle` and :meth:`clean_cycles` as the reference does).  ``batcher``: the
         :class:`clean.CleanBatcher` of the channels in flight, which has to know."""
         self._ready()
+        self._settle_components()       # (the last call's read-back, before its buffers are written again)
         if batcher is not None:
-            arrays = batcher.run_major_cycles(self._clean, psf_patch, noise_threshold, left_for_next,
-                                              max_cycles)
-            if arrays is None:
-                return None
-            values, positions, pixels = arrays
+            got = batcher.run_major_cycles(self._clean, psf_patch, noise_threshold, left_for_next, max_cycles)
         else:
-            if not self._clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles):
-                return None
-            values, positions, pixels = self._clean._collect_cycle_arrays()
-        if len(values):
-            self._pending_components.append((positions, pixels))
-        return values.tolist()
+            got = self._clean.run_major_cycles(psf_patch, noise_threshold, left_for_next, max_cycles)
+        if not got:
+            return None
+        count, first = got
+        if count <= 0:
+            return None                 # (nothing there to CLEAN: as the reference's steps find out)
+        self._pending_components.append(self._clean)           # (its read-back in flight)
+        return first, count
+
+    def _settle_components(self):
+        """Turn read-backs in flight among the pending components into the arrays they bring."""
+        for i, item in enumerate(self._pending_components):
+            if not isinstance(item, tuple):
+                values, positions, pixels = item._collect_cycle_arrays()
+                self._pending_components[i] = (positions, pixels)
 
     def _record_many(self, positions, pixels):
         """:meth:`_record` for a whole call's components at once: the fluxes of every position are
