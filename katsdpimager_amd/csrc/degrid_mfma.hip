@@ -534,13 +534,22 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                             __builtin_amdgcn_sched_barrier(0);      // bounds the operands in flight
                     }
                 } else {
+                typedef float dg_v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int y = 0; y < WIN; y++) {
-                    const float bv = *reinterpret_cast<const float *>(
-                        TAPS == 64 ? pv + 8 * y : pv + ((off_v + 8 * y) & 0xf8)) * b_sign;
+                for (int y = 0; y < WIN; y += 2) {
+                    // two rows' taps with one sign multiplication (v_pk_mul_f32)
+                    dg_v2f bv;
+                    bv.x = *reinterpret_cast<const float *>(
+                        TAPS == 64 ? pv + 8 * y : pv + ((off_v + 8 * y) & 0xf8));
+                    bv.y = *reinterpret_cast<const float *>(
+                        TAPS == 64 ? pv + 8 * (y + 1) : pv + ((off_v + 8 * (y + 1)) & 0xf8));
+                    bv = bv * dg_v2f{b_sign, b_sign};
 #pragma unroll
                     for (int p = 0; p < P; p++)
-                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv, acc[p], 0, 0, 0);
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y], bv.x, acc[p], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < P; p++)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(win.g[p][y + 1], bv.y, acc[p], 0, 0, 0);
                 }
                 }
                 // ---- step 2: vis = sum_x ku[x] * T[x] ------------------------------------------
@@ -548,28 +557,31 @@ __global__ __launch_bounds__(NW * 64) void degrid_mfma_kernel(
                                              : tbytes + u_table
                                                    + (TAPS == 64 ? rec.y + h32 : (rec.y >> 16) * ROW_BYTES);
                 const int off_u = (rec.y & 0xff) + h32;
-                float sum[P];
+                // (the two products of the complex multiplication are summed apart, so that the sign
+                // of the cross term is applied once instead of to every tap)
+                float sum[P], cross[P];
 #pragma unroll
                 for (int p = 0; p < P; p++)
-                    sum[p] = 0.0f;
+                    sum[p] = cross[p] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int rk = (k & 3) + 8 * (k >> 2);
                     const float2 ku = *reinterpret_cast<const float2 *>(
                         TAPS == 64 ? pu + 8 * rk : pu + ((off_u + 8 * rk) & 0xf8));
-                    const float kis = ku.y * o_sign;
 #pragma unroll
                     for (int p = 0; p < P; p++) {
                         const float own = acc[p][k];
                         const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
                             __builtin_bit_cast(int, own), 0xB1, 0xf, 0xf, true));
                         sum[p] = fmaf(ku.x, own, sum[p]);
-                        sum[p] = fmaf(kis, other, sum[p]);
+                        cross[p] = fmaf(ku.y, other, cross[p]);
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < P; p++)
+                for (int p = 0; p < P; p++) {
+                    sum[p] = fmaf(o_sign, cross[p], sum[p]);
                     sum[p] += __shfl_xor(sum[p], 32, WAVE);
+                }
                 // ---- write back: lanes 0-31 hold (vis b, part) -----------------------------------
                 if (active && !h) {
                     const int64_t r = b0 + first + b_lane;

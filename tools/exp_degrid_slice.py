@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import synth
+from katsdpimager_amd import _lib as _kl
+if os.environ.get('KIMG_VARIANT_LIB'):
+    _kl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build_variants',
+                                'libkimg_%s.so' % os.environ['KIMG_VARIANT_LIB'])
 from katsdpimager_amd import accel, grid
 
 G, n, W, P, K = 4096, 50_000_000, 32, 1, 28
