@@ -2164,10 +2164,10 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
         const int v = repeating ? 1 : 0;
         if (enqueued == 0 && need >= MULTI_GRAPH) {
             // (a graph takes the host tens of microseconds to launch, the start-up kernels are over
-            // sooner: two plain launches bridge the gap)
-            for (int i = 0; i < 2 && rc == 0; i++)
-                rc = enqueue_launch(a, s, i & 1, repeating, i == 1 ? 1 : a.g.rmax);
-            enqueued += 2;
+            // sooner: four plain launches bridge the gap)
+            for (int i = 0; i < 4 && rc == 0; i++)
+                rc = enqueue_launch(a, s, i & 1, repeating, i == 3 ? 1 : a.g.rmax);
+            enqueued += 4;
             continue;
         }
 #ifndef KIMG_MC_NO_GRAPH
