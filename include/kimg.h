@@ -395,6 +395,13 @@ int kimg_fourier_beam(void *data, int64_t row_stride, int width, int height, flo
  * add_image.mako, apply_primary_beam.mako).  scale_host: P floats on the HOST. */
 int kimg_scale(float *image, int64_t row_stride, int64_t pol_stride, int width, int height,
                int num_polarizations, const float *scale_host, void *stream);
+/* The scaling of frontend.py:541-545 (dirty and PSF by 1 / the PSF's central pixel) without the host in
+ * between: out[p] = 1 / image[p][y][x] on the device (np.reciprocal of a float32), and kimg_scale with
+ * its factors read from device memory.  scale, out: P floats on the DEVICE. */
+int kimg_pixel_reciprocal(const float *image, int64_t row_stride, int64_t pol_stride, int width,
+                          int height, int num_polarizations, int x, int y, float *out, void *stream);
+int kimg_scale_device(float *image, int64_t row_stride, int64_t pol_stride, int width, int height,
+                      int num_polarizations, const float *scale, void *stream);
 int kimg_add_image(float *dest, int64_t dest_row_stride, int64_t dest_pol_stride,
                    const float *src, int64_t src_row_stride, int64_t src_pol_stride,
                    int width, int height, int num_polarizations, void *stream);

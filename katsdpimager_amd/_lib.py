@@ -70,6 +70,8 @@ PROTOTYPES = {
     'kimg_image_peak': (c_int, [P, L, L, P, L, I, I, I, F, P, P]),
     'kimg_image_nansum': (c_int, [P, L, L, I, I, I, P, P]),
     'kimg_scale': (c_int, [P, L, L, I, I, I, ctypes.POINTER(c_float), P]),
+    'kimg_pixel_reciprocal': (c_int, [P, L, L, I, I, I, I, I, P, P]),
+    'kimg_scale_device': (c_int, [P, L, L, I, I, I, P, P]),
     'kimg_add_image': (c_int, [P, L, L, P, L, L, I, I, I, P]),
     'kimg_apply_primary_beam': (c_int, [P, L, L, P, L, I, I, I, F, F, P]),
     'kimg_psf_patch': (c_int, [P, L, L, I, I, I, I, I, I, I, F, P, P]),

@@ -86,6 +86,19 @@ class PsfPatch(accel.Operation):
         pass
 
     def __call__(self, threshold, limit=None, **kwargs):
+        return self.finish(self.enqueue(threshold, limit, **kwargs))
+
+    def finish(self, bound_values=None):
+        """The patch from the two bounds :meth:`enqueue` left in **bound** (read here if the caller
+        has not fetched them some other way)."""
+        P, H, W = self.buffer('psf').shape
+        b = self.buffer('bound').get(self.command_queue) if bound_values is None or bound_values is True \
+            else np.asarray(bound_values)
+        box = 2 * b + 1
+        return (P, int(min(box[1], H)), int(min(box[0], W)))
+
+    def enqueue(self, threshold, limit=None, **kwargs):
+        """Launch the search only; :meth:`finish` reads its result."""
         self.bind(**kwargs)
         self.ensure_all_bound()
         psf = self.buffer('psf')
@@ -102,9 +115,7 @@ class PsfPatch(accel.Operation):
         rc = lib().kimg_psf_patch(psf.ptr, W, H * W, P, min_x, min_y, max_x, max_y, mid_x, mid_y,
                                   threshold, bound.ptr, self.command_queue.handle)
         check(rc, 'kimg_psf_patch')
-        b = bound.get(self.command_queue)
-        box = 2 * b + 1
-        return (P, int(min(box[1], H)), int(min(box[0], W)))
+        return True
 
 
 class NoiseEstTemplate:

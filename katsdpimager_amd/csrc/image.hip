@@ -223,6 +223,28 @@ __global__ __launch_bounds__(256) void scale_kernel(
         image[addr] *= scale.v[p];
 }
 
+// The same with the factors where an earlier kernel left them (kimg_pixel_reciprocal): a driver that
+// scales by 1 / (a pixel of the image) need not read that pixel back first.
+__global__ __launch_bounds__(256) void scale_device_kernel(
+    float *__restrict__ image, int64_t row_stride, int64_t pol_stride, int width, int num_pols,
+    const float *__restrict__ scale)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width)
+        return;
+    int64_t addr = (int64_t) blockIdx.y * row_stride + x;
+    for (int p = 0; p < num_pols; p++, addr += pol_stride)
+        image[addr] *= scale[p];
+}
+
+__global__ void pixel_reciprocal_kernel(const float *__restrict__ image, int64_t pol_stride, int64_t offset,
+                                        int num_pols, float *__restrict__ out)
+{
+    const int p = threadIdx.x;
+    if (p < num_pols)
+        out[p] = 1.0f / image[p * pol_stride + offset];     // (np.reciprocal of a float32: one rounding)
+}
+
 __global__ __launch_bounds__(256) void add_image_kernel(
     float *__restrict__ dest, int64_t dest_row_stride, int64_t dest_pol_stride,
     const float *__restrict__ src, int64_t src_row_stride, int64_t src_pol_stride,
@@ -1058,6 +1080,30 @@ extern "C" int kimg_scale(float *image, int64_t row_stride, int64_t pol_stride, 
     dim3 g(kimg_divup(width, 256), height);
     scale_kernel<<<g, 256, 0, (hipStream_t) stream>>>(image, row_stride, pol_stride, width,
                                                       num_polarizations, sc);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_pixel_reciprocal(const float *image, int64_t row_stride, int64_t pol_stride,
+                                     int width, int height, int num_polarizations, int x, int y,
+                                     float *out, void *stream)
+{
+    KIMG_CHECK_ARG(image && out && x >= 0 && x < width && y >= 0 && y < height);
+    if (num_polarizations < 1 || num_polarizations > 4)
+        return KIMG_EUNSUPPORTED;
+    pixel_reciprocal_kernel<<<1, 64, 0, (hipStream_t) stream>>>(image, pol_stride, (int64_t) y * row_stride + x,
+                                                                num_polarizations, out);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_scale_device(float *image, int64_t row_stride, int64_t pol_stride, int width,
+                                 int height, int num_polarizations, const float *scale, void *stream)
+{
+    KIMG_CHECK_ARG(image && scale && width > 0 && height > 0);
+    if (num_polarizations < 1 || num_polarizations > 4)
+        return KIMG_EUNSUPPORTED;
+    dim3 g(kimg_divup(width, 256), height);
+    scale_device_kernel<<<g, 256, 0, (hipStream_t) stream>>>(image, row_stride, pol_stride, width,
+                                                             num_polarizations, scale);
     return kimg_launch_status();
 }
 

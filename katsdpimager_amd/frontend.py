@@ -124,42 +124,64 @@ def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_
         mid_w = slice_mid_w(image_p, grid_p)
         with trace.range('make_psf'):
             make_dirty(reader, rel_channel, 'weights', imager, mid_w, vis_block, degrid)
-        with trace.range('psf_patch'):
-            dirty = imager.buffer('dirty')
-            centre = dirty.shape[1] // 2
-            psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
-            # (this read is where the PSF's gridding and transform are waited for: the turn at the
-            # device ends here; what follows is small launches and host round trips, which
-            # may run next to another channel's gridding)
-            dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
-    with trace.range('psf_patch'):
-        if np.any(psf_peak == 0):
-            return None
-        scale = np.reciprocal(psf_peak)
-        imager.scale_dirty(scale)
-        imager.dirty_to_psf()
-        psf_patch = imager.psf_patch()
-    out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise,
-               psf_patch=tuple(int(x) for x in psf_patch), scale=scale, major=0, minor=0,
+        started = None
+        deferred = (not fit_beam and major > 0 and getattr(imager, 'device_psf_stage', False) is True)
+        if deferred:
+            # the PSF's scaling and patch without the host in between: the reciprocal of the
+            # central pixel stays on the device, the patch's bounds and the factors come back on
+            # a stream of their own while the first dirty image is gridded; a channel without
+            # data (central pixel 0) is found out when they are looked at, after that gridding
+            with trace.range('psf_patch'):
+                imager.scale_dirty_by_centre()
+                imager.dirty_to_psf()
+                started = imager.psf_patch_start()
+        else:
+            with trace.range('psf_patch'):
+                dirty = imager.buffer('dirty')
+                centre = dirty.shape[1] // 2
+                psf_peak = np.zeros((dirty.shape[0],), dirty.dtype)
+                # (this read is where the PSF's gridding and transform are waited for: the turn at
+                # the device ends here; what follows is small launches and host round trips, which
+                # may run next to another channel's gridding)
+                dirty.get_region(imager.command_queue, psf_peak, np.s_[:, centre, centre], np.s_[:])
+    out = dict(weights_noise=weights_noise, normalized_noise=normalized_noise, major=0, minor=0,
                peaks=[], noise=None)
-    if fit_beam:
-        from . import beam
-        psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
-        out['restoring_beam'] = beam.fit_beam(psf_core)
+    if not deferred:
+        with trace.range('psf_patch'):
+            if np.any(psf_peak == 0):
+                return None
+            scale = np.reciprocal(psf_peak)
+            imager.scale_dirty(scale)
+            imager.dirty_to_psf()
+            psf_patch = imager.psf_patch()
+        out.update(psf_patch=tuple(int(x) for x in psf_patch), scale=scale)
+        if fit_beam:
+            from . import beam
+            psf_core = extract_psf(imager.command_queue, imager.buffer('psf'), psf_patch[1:])
+            out['restoring_beam'] = beam.fit_beam(psf_core)
     for i in range(major):
         with device_phase():
             with trace.range('make_dirty[%d]' % i):
                 make_dirty(reader, rel_channel, 'vis', imager, mid_w, vis_block, degrid,
                            i != 0, subtract_model)
-            imager.scale_dirty(scale)
+            if deferred and 'scale' not in out:
+                imager.scale_dirty_by_kept()
+            else:
+                imager.scale_dirty(scale)
             out['major'] += 1
             with trace.range('noise_est'):
                 noise = imager.noise_est()      # (waits for the gridding: the turn ends here)
             out['noise'] = noise
+        if started is not None:
+            psf_patch, scale = imager.psf_patch_finish(started)        # (arrived long ago)
+            started = None
+            if np.any(np.isinf(scale)):
+                return None             # (a central pixel of 0: frontend.py:543-544)
+            out.update(psf_patch=tuple(int(x) for x in psf_patch), scale=scale)
         noise_threshold = noise * clean.noise_threshold_scale(clean_p.mode, clean_p.threshold,
                                                               num_pols)
         values = None
-        if batched_clean and hasattr(imager, 'clean_major_cycles') \
+        if batched_clean and getattr(imager, 'one_call_major_cycles', False) is True \
                 and noise_threshold == noise_threshold:         # (not NaN)
             # the first cycle and the others in one call: the threshold follows from the first
             # peak on the device, in this arithmetic (no host round trip in between)

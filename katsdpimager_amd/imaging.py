@@ -148,6 +148,11 @@ class _SidePipeline:
 class Imaging(accel.OperationSequence):
     """All operations and buffers for imaging one channel (imaging.py:81-419)."""
 
+    #: what frontend.process_channel may use beyond the reference's calls (results the same):
+    #: :meth:`clean_major_cycles`, and :meth:`scale_dirty_by_centre` / :meth:`psf_patch_start`
+    one_call_major_cycles = True
+    device_psf_stage = True
+
     def __init__(self, template, command_queue, image_parameters, grid_parameters,
                  max_vis, max_sources, major, allocator=None, streams=1):
         if streams not in (1, 2):
@@ -215,6 +220,8 @@ class Imaging(accel.OperationSequence):
                 allocator)
         self._components = {}
         self._pending_components = []
+        self._kept_scale = None         # device float32 [P]: 1 / the PSF's central pixel
+        self._small_stream = None       # (small read-backs next to the queue's work)
         self._dirty_cleared = False
         operations = [
             ('weights', self._weights), ('gridder', self._gridder), ('predict', self._predict),
@@ -604,6 +611,70 @@ class Imaging(accel.OperationSequence):
         self._ready()
         cp = self.template.clean_parameters
         return self._psf_patch(cp.psf_cutoff, cp.psf_limit)
+
+    # ---- the PSF stage without the host in between (frontend.py:541-548) -----------------
+    # The reference reads the PSF's central pixel back, scales by its reciprocal, and reads the
+    # patch back; both read-backs leave the device idle while the host reacts.  Here the
+    # reciprocal stays on the device, and the small results travel on a stream of their own
+    # while the next gridding runs.
+    @_serial
+    def scale_dirty_by_centre(self):
+        """``scale_dirty(1 / dirty[:, centre, centre])`` with the factors made and kept on the
+        device (:meth:`scale_dirty_by_kept` applies them again, :meth:`psf_patch_finish` hands
+        them to the host)."""
+        from ._lib import lib, check
+        self._ready()
+        dirty = self.buffer('dirty')
+        P, H, W = dirty.shape
+        if self._kept_scale is None:
+            self._kept_scale = accel.DeviceArray(self.command_queue.context, (P,), np.float32,
+                                                 queue=self.command_queue)
+        centre = H // 2             # (frontend.py:541: one index for both axes)
+        check(lib().kimg_pixel_reciprocal(dirty.ptr, W, H * W, W, H, P, centre, centre,
+                                          self._kept_scale.ptr, self.command_queue.handle),
+              'kimg_pixel_reciprocal')
+        self.scale_dirty_by_kept()
+
+    @_serial
+    def scale_dirty_by_kept(self):
+        from ._lib import lib, check
+        self._ready()
+        dirty = self.buffer('dirty')
+        P, H, W = dirty.shape
+        check(lib().kimg_scale_device(dirty.ptr, W, H * W, W, H, P, self._kept_scale.ptr,
+                                      self.command_queue.handle), 'kimg_scale_device')
+
+    @_serial
+    def psf_patch_start(self):
+        """:meth:`psf_patch` without its read-back: the search is enqueued, and its two bounds and
+        the kept scale factors are copied to the host on a stream of their own behind it.
+        :meth:`psf_patch_finish` returns (patch, scale factors)."""
+        import torch
+        self._ready()
+        cp = self.template.clean_parameters
+        self._psf_patch.enqueue(cp.psf_cutoff, cp.psf_limit)
+        q = self.command_queue
+        bound = self._psf_patch.buffer('bound')
+        bound.used_on(q)
+        self._kept_scale.used_on(q)
+        if self._small_stream is None:
+            self._small_stream = torch.cuda.Stream(device=q.stream.device)
+        host_bound = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host_scale = torch.empty(self._kept_scale.shape[0], dtype=torch.float32, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(q.stream)
+        with torch.cuda.stream(self._small_stream):
+            self._small_stream.wait_event(ready)
+            host_bound.copy_(bound.tensor.reshape(-1)[:2].view(torch.int32), non_blocking=True)
+            host_scale.copy_(self._kept_scale.tensor.reshape(-1), non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._small_stream)
+        return copied, host_bound, host_scale
+
+    def psf_patch_finish(self, started):
+        copied, host_bound, host_scale = started
+        copied.synchronize()
+        return self._psf_patch.finish(host_bound.numpy().copy()), host_scale.numpy().copy()
 
     @_serial
     def noise_est(self):

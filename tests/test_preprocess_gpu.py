@@ -341,6 +341,11 @@ def test_store_driven_channel_vs_golden(golden, name):
         template = imaging.ImagingTemplate(ctx, ap, ip.fixed, wp, gp.fixed, cp)
         im = template.instantiate(q, ip, gp, c['vis_block'], 0, c['major'], streams=streams)
         im.ensure_all_bound()
+        if not batched:
+            # the reference's own sequence of calls throughout: the PSF's peak and patch read back
+            # by the host, the first minor cycle on its own (the other run takes the short cuts)
+            im.device_psf_stage = False
+            im.one_call_major_cycles = False
         stats = frontend.process_channel(rd, 0, im, ip, gp, cp, wp.weight_type, c['vis_block'],
                                          c['major'], c['degrid'], batched_clean=batched)
         results.append((stats, im.get_buffer('dirty'), im.get_buffer('model'),
