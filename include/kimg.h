@@ -223,6 +223,12 @@ int kimg_mean_weight(double *sums, const float *grid, int64_t row_stride, int wi
 int kimg_density_weights(double *sums, float *grid, int64_t row_stride, int64_t pol_stride,
                          int width, int height, int num_polarizations, float a, float b,
                          void *stream);
+/* Robust weighting without the host between the two kernels (weight.py:525-531): a = robust /
+ * (mean_sums[1] / mean_sums[0]) on the device, in the host's arithmetic (doubles, rounded to float32),
+ * mean_sums = what kimg_mean_weight left on the DEVICE; robust = (5 * 10^-robustness)^2. */
+int kimg_density_weights_robust(double *sums, float *grid, int64_t row_stride, int64_t pol_stride,
+                                int width, int height, int num_polarizations,
+                                const double *mean_sums, double robust, float b, void *stream);
 int kimg_fill(float *data, int64_t count, float value, void *stream);
 
 /* ---- visibility preprocessing: preprocess.cpp:390-513 (visibility_collector<P>::add_impl2) and

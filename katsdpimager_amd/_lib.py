@@ -35,6 +35,7 @@ PROTOTYPES = {
     'kimg_grid_weights': (c_int, [P, L, L, I, I, I, P, P, L, P]),
     'kimg_mean_weight': (c_int, [P, P, L, I, I, P]),
     'kimg_density_weights': (c_int, [P, P, L, L, I, I, I, F, F, P]),
+    'kimg_density_weights_robust': (c_int, [P, P, L, L, I, I, I, P, c_double, F, P]),
     'kimg_fill': (c_int, [P, L, F, P]),
     'kimg_preprocess_convert': (c_int, [I, I, L, P, P, P, P, P, P, P, F, I, I, I, F, P, P, P, P]),
     'kimg_preprocess_workspace_bytes': (ctypes.c_size_t, [L, I]),

@@ -103,10 +103,17 @@ __global__ __launch_bounds__(256) void mean_weight_kernel(
     block_accumulate<2>(acc, sums);
 }
 
+// mean_sums (optional): (sum W, sum W^2) as kimg_mean_weight leaves them; a is then robust / (their
+// quotient), worked out as the host would (weight.py:529: doubles, rounded to the float32 it passes)
 __global__ __launch_bounds__(256) void density_weights_kernel(
     double *__restrict__ sums, float *__restrict__ grid, int64_t row_stride, int64_t pol_stride,
-    int width, int height, int num_pols, float a, float b)
+    int width, int height, int num_pols, float a, float b, const double *__restrict__ mean_sums,
+    double robust)
 {
+    if (mean_sums) {
+        const double mean_weight = mean_sums[1] / mean_sums[0];
+        a = (float) (robust / mean_weight);
+    }
     double acc[3] = {0, 0, 0};
     constexpr int ROWS = 4;
     for (int y0 = blockIdx.y; y0 < height; y0 += gridDim.y * ROWS)
@@ -200,7 +207,20 @@ extern "C" int kimg_density_weights(double *sums, float *grid, int64_t row_strid
     hipStream_t s = (hipStream_t) stream;
     KIMG_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), s));
     density_weights_kernel<<<image_grid(width, height), 256, 0, s>>>(
-        sums, grid, row_stride, pol_stride, width, height, num_polarizations, a, b);
+        sums, grid, row_stride, pol_stride, width, height, num_polarizations, a, b, nullptr, 0.0);
+    return kimg_launch_status();
+}
+
+extern "C" int kimg_density_weights_robust(double *sums, float *grid, int64_t row_stride,
+                                           int64_t pol_stride, int width, int height,
+                                           int num_polarizations, const double *mean_sums,
+                                           double robust, float b, void *stream)
+{
+    KIMG_CHECK_ARG(sums && grid && mean_sums && width > 0 && height > 0 && num_polarizations > 0);
+    hipStream_t s = (hipStream_t) stream;
+    KIMG_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), s));
+    density_weights_kernel<<<image_grid(width, height), 256, 0, s>>>(
+        sums, grid, row_stride, pol_stride, width, height, num_polarizations, 0.0f, b, mean_sums, robust);
     return kimg_launch_status();
 }
 

@@ -94,13 +94,20 @@ class DensityWeights(accel.Operation):
         self.slots['grid'] = accel.IOSlot(grid_shape, np.float32)
         self.slots['sums'] = accel.IOSlot((3,), np.float64)
 
-    def _run(self):
+    def _run(self, mean_sums=None, robust=None):
+        """``mean_sums`` (device float64 [2] as :class:`MeanWeight` leaves it) and ``robust``: a =
+        robust / (mean weight) worked out on the device instead of ``self.a``."""
         grid = self.buffer('grid')
         sums = self.buffer('sums')
         P, H, W = grid.shape
-        rc = lib().kimg_density_weights(sums.ptr, grid.ptr, W, H * W, W, H, P, self.a, self.b,
-                                        self.command_queue.handle)
-        check(rc, 'kimg_density_weights')
+        if mean_sums is not None:
+            rc = lib().kimg_density_weights_robust(sums.ptr, grid.ptr, W, H * W, W, H, P, mean_sums.ptr,
+                                                   float(robust), self.b, self.command_queue.handle)
+            check(rc, 'kimg_density_weights_robust')
+        else:
+            rc = lib().kimg_density_weights(sums.ptr, grid.ptr, W, H * W, W, H, P, self.a, self.b,
+                                            self.command_queue.handle)
+            check(rc, 'kimg_density_weights')
         s = sums.get(self.command_queue)
         rms = np.sqrt(s[2]) / s[1]
         return rms, rms * np.sqrt(s[0])
@@ -126,13 +133,17 @@ class MeanWeight(accel.Operation):
         self.slots['sums'] = accel.IOSlot((2,), np.float64)
 
     def _run(self):
+        s = self.enqueue().get(self.command_queue)
+        return s[1] / s[0]
+
+    def enqueue(self):
+        """The two sums, left on the device (returns the buffer)."""
         grid = self.buffer('grid')
         sums = self.buffer('sums')
         P, H, W = grid.shape
         rc = lib().kimg_mean_weight(sums.ptr, grid.ptr, W, W, H, self.command_queue.handle)
         check(rc, 'kimg_mean_weight')
-        s = sums.get(self.command_queue)
-        return s[1] / s[0]
+        return sums
 
 
 class WeightsTemplate:
@@ -205,10 +216,11 @@ class Weights(accel.OperationSequence):
     def finalize(self):
         self.ensure_all_bound()
         if self._mean_weight is not None:
-            mean_weight = self._mean_weight()
-            S2 = (5 * 10**(-self.robustness))**2 / mean_weight     # weight.py:529
-            self._density_weights.a = S2
+            # weight.py:525-531 without the host between the two kernels: S2 = robust / mean weight
+            # is worked out where the sums are (kimg_density_weights_robust)
             self._density_weights.b = 1.0
+            return self._density_weights._run(self._mean_weight.enqueue(),
+                                              (5 * 10**(-self.robustness))**2)
         if self._density_weights is not None:
             return self._density_weights()
         grid = self.buffer('grid')
