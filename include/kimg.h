@@ -101,6 +101,12 @@ extern "C" {
 #define KIMG_CLEAN_SUMSQ 1  /* clean.py:31 */
 
 int kimg_version(void);
+
+/* Load every code object of the library on the current device now, in the calling thread.  The runtime
+ * otherwise loads a code object at the first launch of one of its kernels, and first launches that
+ * several host threads make at the same moment (channels imaged concurrently) are not safe against
+ * that load: call this once per device before any thread uses the library.  Idempotent. */
+int kimg_preload(void);
 /* Static string describing a return code of this library. */
 const char *kimg_error_string(int code);
 /* How many of the device's CUs the window kernels (kimg_grid / kimg_degrid, MFMA variants) fill with

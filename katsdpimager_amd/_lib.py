@@ -7,6 +7,7 @@ runtime and rocFFT already loaded by torch (same SONAMEs) -- device pointers
 and streams created by torch are then valid inside the library.
 """
 import ctypes
+import threading
 import os
 from ctypes import c_int, c_int64, c_float, c_double, c_size_t, c_uint32, c_void_p, c_char_p
 
@@ -82,6 +83,7 @@ PROTOTYPES = {
     'kimg_find_peak': (c_int, [P, L, L, I, P, P, I, I, P, P, P, P]),
     'kimg_subtract_psf': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, P, I, I, F, P]),
     'kimg_noise_est_scratch_bytes': (c_size_t, []),
+    'kimg_preload': (c_int, []),
     'kimg_noise_est': (c_int, [P, L, L, I, I, I, I, F, P, P, P]),
     'kimg_clean_state_bytes': (c_size_t, [I, I, I]),
     'kimg_clean_cycles': (c_int, [P, P, L, L, I, I, I, P, L, L, I, I, I, I, I, I, F, F,
@@ -117,8 +119,25 @@ class KimgError(RuntimeError):
 _lib = None
 
 
+_load_lock = threading.Lock()
+
+
 def lib():
     """Load libkimg.so once; raise KimgLibraryError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        return _load()
+
+
+def preload():
+    """``kimg_preload`` (include/kimg.h): every code object of the library loaded on the current
+    device now, in this thread -- before several threads make their first launches at once."""
+    check(lib().kimg_preload(), 'kimg_preload')
+
+
+def _load():
     global _lib
     if _lib is not None:
         return _lib

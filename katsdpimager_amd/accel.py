@@ -47,6 +47,11 @@ class Context:
             raise RuntimeError('katsdpimager_amd needs a HIP device; there is no CPU fallback')
         self.device = torch.device('cuda', device_index)
         torch.cuda.set_device(self.device)
+        # every code object of libkimg loaded on this device now, by this thread: first launches
+        # that several threads make at the same moment are not safe against the runtime's lazy
+        # loading (include/kimg.h: kimg_preload)
+        from . import _lib
+        _lib.preload()
 
     def create_command_queue(self, stream=None):
         return CommandQueue(self, stream)

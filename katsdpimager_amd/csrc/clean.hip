@@ -2214,12 +2214,15 @@ graph_entry *cycles_graph(const cycle_args &a, hipStream_t s)
     if (!slot)
         return nullptr;             // every entry busy: the caller enqueues plain launches
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    // (captured on the library's own stream of this thread, launched on the caller's: see
+    // kimg_capture_stream)
+    hipStream_t cs = kimg_capture_stream();
+    if (cs == nullptr || hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return nullptr;
     int rc = 0;
     for (int i = 0; i < GRAPH_CYCLES && rc == 0; i++)
-        rc = enqueue_cycle(a, s, i);
-    const hipError_t ended = hipStreamEndCapture(s, &graph);
+        rc = enqueue_cycle(a, cs, i);
+    const hipError_t ended = hipStreamEndCapture(cs, &graph);
     if (ended != hipSuccess || rc != 0) {
         if (ended == hipSuccess && graph != nullptr)
             (void) hipGraphDestroy(graph);      // (a launch failed during the capture)
@@ -2351,12 +2354,11 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
     if (solo_ok && (form == KIMG_CLEAN_FORM_ONE_WORKGROUP
                     || (form == KIMG_CLEAN_FORM_AUTO && bx * by <= SOLO_AUTO_BLOCKS))) {
 #define SOLO(MODE) do { \
-        static bool attr_set = false; \
-        if (!attr_set) { \
-            KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cycle_solo_kernel<MODE>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int) SOLO_LDS_LIMIT)); \
-            attr_set = true; \
+        { \
+            const int lds_rc = kimg_dynamic_lds(reinterpret_cast<const void *>(&cycle_solo_kernel<MODE>), \
+                                                SOLO_LDS_LIMIT); \
+            if (lds_rc) \
+                return lds_rc; \
         } \
         cycle_solo_kernel<MODE><<<1, 1024, solo_lds, s>>>( \
             dirty, model, row_stride, width, height, psf, psf_row_stride, psf_width, psf_height, \
@@ -2388,12 +2390,11 @@ extern "C" int kimg_clean_cycles(float *dirty, float *model, int64_t row_stride,
         KIMG_HIP(hipMemsetAsync(hdr, 0, sizeof(persist_header), s));
         const dim3 g(bx, by);
 #define PERSIST(MODE) do { \
-        static bool attr_set = false; \
-        if (!attr_set) { \
-            KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cycle_persistent_kernel<MODE>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int) PERSIST_LDS_LIMIT)); \
-            attr_set = true; \
+        { \
+            const int lds_rc = kimg_dynamic_lds(reinterpret_cast<const void *>(&cycle_persistent_kernel<MODE>), \
+                                                PERSIST_LDS_LIMIT); \
+            if (lds_rc) \
+                return lds_rc; \
         } \
         cycle_persistent_kernel<MODE><<<g, 1024, persist_lds, s>>>( \
             dirty, model, row_stride, pol_stride, width, height, num_polarizations, psf, \
@@ -2777,3 +2778,6 @@ extern "C" int kimg_noise_est(const float *image, int64_t row_stride, int64_t po
     }
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(subtract_psf_kernel)

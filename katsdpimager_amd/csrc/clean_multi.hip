@@ -1875,14 +1875,17 @@ multi_graph *multi_graph_for(const multi_args &a, hipStream_t s)
     if (!slot)
         return nullptr;                 // every entry busy: the caller enqueues plain launches
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    // (captured on the library's own stream of this thread, launched on the caller's: see
+    // kimg_capture_stream)
+    hipStream_t cs = kimg_capture_stream();
+    if (cs == nullptr || hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return nullptr;
     int rc = 0;
     // (the last launch of a graph of the repeated-steps kernel plans single steps: whatever comes
     // next, of either kind, can read what it leaves behind)
     for (int i = 0; i < MULTI_GRAPH && rc == 0; i++)
-        rc = enqueue_launch(a, s, i & 1, a.repeats != 0, i == MULTI_GRAPH - 1 ? 1 : a.g.rmax);
-    const hipError_t ended = hipStreamEndCapture(s, &graph);
+        rc = enqueue_launch(a, cs, i & 1, a.repeats != 0, i == MULTI_GRAPH - 1 ? 1 : a.g.rmax);
+    const hipError_t ended = hipStreamEndCapture(cs, &graph);
     if (ended != hipSuccess || rc != 0) {
         if (ended == hipSuccess && graph != nullptr)
             (void) hipGraphDestroy(graph);
@@ -2249,3 +2252,6 @@ int kimg_clean_multi_run(float *dirty, float *model, int64_t row_stride, int64_t
     progress_release(slot);
     return rc;
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(mc_tile_pix_kernel)

@@ -673,11 +673,11 @@ int launch(const float *grid, int64_t row_stride, int64_t pol_stride, int Gg, co
             pad_rows_kernel<<<kimg_divup(rows * 32, 256), 256, 0, stream>>>(
                 kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * 32);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
-        attr_set = true;
+    {
+        const int rc = kimg_dynamic_lds(
+            reinterpret_cast<const void *>(&degrid_mfma_kernel<P, NW, TAPS, TWO, TG, F16>), LDS_LIMIT);
+        if (rc)
+            return rc;
     }
     const int blocks_max = kimg_window_cus_now();
     int64_t vis_per_block = (num_vis + blocks_max - 1) / blocks_max;
@@ -822,3 +822,6 @@ int kimg_degrid_mfma(const void *grid, int64_t grid_row_stride, int64_t grid_pol
     }
     return 0;
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(dg_table_max_kernel)

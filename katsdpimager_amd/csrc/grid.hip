@@ -408,3 +408,6 @@ extern "C" int kimg_predict(void *vis, const int16_t *uv, const int16_t *w_plane
 #undef LAUNCH
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(grid_generic_kernel<1>)

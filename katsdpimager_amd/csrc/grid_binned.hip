@@ -352,3 +352,6 @@ extern "C" int kimg_grid_jumps(const int16_t *uv, int64_t num_vis, int kernel_wi
     jump_count_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const int2 *>(uv), num_vis, slack, count);
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(bin_key_kernel)

@@ -1155,12 +1155,11 @@ int launch(float *grid, int64_t row_stride, int64_t pol_stride, int Gg, const fl
             pad_table_kernel<ROW, F16><<<kimg_divup(rows * ROW, 256), 256, 0, stream>>>(
                 kern, rows, ts.K, ts.tu0, ts.Ku, out + (size_t) rows * ROW, tab_max);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        KIMG_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_LIMIT));
-        attr_set = true;
+    {
+        const int rc = kimg_dynamic_lds(
+            reinterpret_cast<const void *>(&grid_mfma_kernel<P, NW, SUB, ROW, TWO, TG, F16>), LDS_LIMIT);
+        if (rc)
+            return rc;
     }
     // bits 8-15: span stagger of a SIMD's waves, percent.  Bits 0-1 (test builds with
     // -DKIMG_NO_ATOMICS, the counterpart of the reference's NO_ATOMICS switch,
@@ -1352,3 +1351,6 @@ extern "C" int kimg_debug_grid_timing(void *buffer)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(table_max_kernel)

@@ -1387,24 +1387,12 @@ int fft_plan_for(int G, hipStream_t s, fft_plan *out)
 
 // (once per kernel, device and size: the attribute is set when a launch needs more dynamic LDS than
 // any before it, not with every transform)
-std::mutex fft_attribute_mutex;
-std::map<std::pair<const void *, int>, size_t> fft_attribute_set;
-
 template<typename Kernel>
 int fft_lds_attribute(Kernel kernel, size_t lds)
 {
     if (lds <= 64 * 1024)
         return 0;
-    int device = 0;
-    KIMG_HIP(hipGetDevice(&device));
-    const void *fn = reinterpret_cast<const void *>(kernel);
-    std::lock_guard<std::mutex> lock(fft_attribute_mutex);
-    size_t &have = fft_attribute_set[std::make_pair(fn, device)];
-    if (lds > have) {
-        KIMG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        have = lds;
-    }
-    return 0;
+    return kimg_dynamic_lds(reinterpret_cast<const void *>(kernel), lds);
 }
 
 size_t fft_lds_bytes(int G, const fft_plan &plan)
@@ -1623,3 +1611,6 @@ extern "C" int kimg_convolve_beam(float *image, int64_t row_stride, int size, fl
 #undef CONVOLVE
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(grid_to_half_layer_kernel)

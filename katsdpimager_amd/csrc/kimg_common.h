@@ -27,6 +27,31 @@ struct kimg_window_cus_scope {
     int before;
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of kernel `fn` on the current device raised to `bytes`
+// (never lowered), once per kernel and device, under one lock (api.hip): channels imaged on several
+// host threads reach their first launches together, and two threads setting the attribute of one
+// kernel -- or one setting it while the other launches it -- is what their first pass must not do.
+int kimg_dynamic_lds(const void *fn, size_t bytes);
+
+// The stream graphs are captured on: one per host thread, the library's own.  A caller's stream is
+// never put into capture mode -- streams can be shared between threads without either knowing
+// (torch hands out the streams of a pool of 32 per device round robin), and what another thread
+// launches on a capturing stream is recorded into the graph instead of run: its kernels never happen,
+// and happen later, with its pointers, whenever the graph is launched.  (api.hip)
+hipStream_t kimg_capture_stream();
+
+// One kernel of every translation unit (= code object) of the library, for kimg_preload (api.hip):
+// returns 0 so that a namespace-scope initialiser can call it.
+int kimg_register_kernel(const void *fn);
+// ... and a function that launches an empty kernel of the translation unit on the null stream: the
+// one thing that is certain to make the runtime load the code object
+int kimg_register_touch(void (*launch)());
+#define KIMG_PRELOAD_THIS_UNIT(kernel) \
+    namespace { __global__ void kimg_touch_kernel() {} \
+                void kimg_touch_launch() { kimg_touch_kernel<<<1, 1, 0, nullptr>>>(); } } \
+    static const int kimg_preload_registered = \
+        kimg_register_kernel(reinterpret_cast<const void *>(&kernel)) + kimg_register_touch(&kimg_touch_launch);
+
 // The multi-component form of the CLEAN loop (clean_multi.hip), reached through kimg_clean_cycles
 int kimg_clean_multi_components(int patch_width, int patch_height, int tiles_x, int tiles_y);
 size_t kimg_clean_multi_state_bytes(int tiles_x, int tiles_y);

@@ -112,9 +112,11 @@ extern "C" int kimg_kernel_table(void *table, const double *ws, int w_planes, in
         return KIMG_EUNSUPPORTED;
     const double pi = 3.14159265358979323846;
     double step = 1.0 / (kernel_width * cell_wavelengths * image_oversample);
-    if (lds > 64 * 1024)
-        KIMG_HIP(hipFuncSetAttribute((const void *) kernel_table_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    if (lds > 64 * 1024) {
+        const int rc = kimg_dynamic_lds((const void *) kernel_table_kernel, lds);
+        if (rc)
+            return rc;
+    }
     dim3 grid(w_planes, (unsigned) ((n_out + KT_THREADS - 1) / KT_THREADS));
     hipLaunchKernelGGL(kernel_table_kernel, grid, dim3(KT_THREADS), lds, (hipStream_t) stream,
                        (float2 *) table, ws, kernel_width, oversample, (int) n_img,
@@ -122,3 +124,6 @@ extern "C" int kimg_kernel_table(void *table, const double *ws, int w_planes, in
                        antialias_width / bessel_i0(beta), -0.5 * cell_wavelengths / oversample);
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(kernel_table_kernel)

@@ -606,3 +606,6 @@ extern "C" int kimg_real_to_complex(void *dst, const float *src, int64_t count, 
         count, src, static_cast<float2 *>(dst));
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(pp_slice_counts_kernel)

@@ -297,3 +297,6 @@ extern "C" int kimg_store_reorder(int num_polarizations, int64_t num_vis, int ke
 #undef MERGE
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(strip_key_kernel)

@@ -236,3 +236,6 @@ extern "C" int kimg_fill(float *data, int64_t count, float value, void *stream)
     fill_kernel<<<blocks, 256, 0, (hipStream_t) stream>>>(data, count, value);
     return kimg_launch_status();
 }
+
+// (kimg_preload, api.hip)
+KIMG_PRELOAD_THIS_UNIT(mean_weight_kernel)

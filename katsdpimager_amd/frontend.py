@@ -97,6 +97,7 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     """
     if not any(reader.len(rel_channel, s) for s in range(reader.num_w_slices(rel_channel))):
         return None
+    _check_imager_parameters(imager, image_p, grid_p)
     import contextlib
     if clean_batcher is not None and getattr(clean_batcher, 'phased', False):
         try:
@@ -110,6 +111,29 @@ def process_channel(reader, rel_channel, imager, image_p, grid_p, clean_p, weigh
     return _process_channel_stages(
         reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type, vis_block, major,
         degrid, subtract_model, batched_clean, fit_beam, clean_batcher, contextlib.nullcontext)
+
+
+def _check_imager_parameters(imager, image_p, grid_p):
+    """An imager is made for one set of image and grid parameters (the reference makes one per
+    channel, frontend.py:497-520); a worker that re-uses its imager for the channels of a band may
+    do so only where their parameters are the imager's (an imager made for another channel's cell
+    size and wavelength images this one wrongly, by per cent, without any error)."""
+    own_image = getattr(imager, 'image_parameters', None)
+    own_grid = getattr(imager, 'grid_parameters', None)
+    if own_image is None or own_grid is None:
+        return
+    for name in ('pixels', 'pixel_size', 'cell_size', 'wavelength'):
+        a, b = getattr(own_image, name, None), getattr(image_p, name, None)
+        if a is not None and b is not None and float(a) != float(b):
+            raise ValueError('the imager was made for {} = {!r}, the channel has {!r}'.format(name, a, b))
+    for name in ('w_slices', 'w_planes'):
+        a, b = getattr(own_grid, name, None), getattr(grid_p, name, None)
+        if a is not None and b is not None and a != b:
+            raise ValueError('the imager was made for {} = {!r}, the channel has {!r}'.format(name, a, b))
+    a, b = getattr(own_grid, 'fixed', None), getattr(grid_p, 'fixed', None)
+    if a is not None and b is not None and getattr(a, 'max_w', None) is not None \
+            and getattr(b, 'max_w', None) is not None and float(a.max_w) != float(b.max_w):
+        raise ValueError('the imager was made for max_w = {!r}, the channel has {!r}'.format(a.max_w, b.max_w))
 
 
 def _process_channel_stages(reader, rel_channel, imager, image_p, grid_p, clean_p, weight_type,

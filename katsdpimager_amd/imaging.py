@@ -168,6 +168,10 @@ class Imaging(accel.OperationSequence):
         assert image_parameters.fixed == template.fixed_image_parameters
         assert grid_parameters.fixed == template.fixed_grid_parameters
         self.template = template
+        #: what this imager was made for (frontend.process_channel refuses a channel whose own
+        #: parameters differ: the kernel table, the taper and the image geometry follow from them)
+        self.image_parameters = image_parameters
+        self.grid_parameters = grid_parameters
         lm_scale = float(image_parameters.pixel_size)
         lm_bias = -0.5 * image_parameters.pixels * lm_scale
         num_pols = len(image_parameters.fixed.polarizations)

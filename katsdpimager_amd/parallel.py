@@ -86,8 +86,9 @@ def image_assigned_channels(make_job, num_channels, workers=4, runner=None):
 
     ``make_job(channel)`` -- or ``make_job(channel, worker)`` with ``worker`` in ``range(workers)``,
     so that a callback can keep ONE imager and command queue per worker and re-use it for every
-    channel that worker images -- returns the keyword arguments of ``frontend.process_channel`` for
-    one channel.  Jobs are made lazily, when a worker is free to image them, and dropped when their
+    channel that worker images, where the channels' image and grid parameters are the same
+    (``frontend.process_channel`` refuses an imager made for others) -- returns the keyword
+    arguments of ``frontend.process_channel`` for one channel.  Jobs are made lazily, when a worker is free to image them, and dropped when their
     channel is done: at most `workers` imagers (grids, images, FFT layer, CLEAN state, workspaces)
     exist at any time however many channels the rank owns (the reference images a band's channels one
     after the other with one imager, frontend.py:749-767).  Returns {channel: result} for this rank's

@@ -110,6 +110,8 @@ class _SliceStore:
         self.arrays = None
         #: True once :meth:`reorder` has put the records into the window kernels' order
         self.ordered = False
+        import threading
+        self._slack_lock = threading.Lock()     # (readers on several host threads: ensure_slack)
 
     def _allocate(self, rows):
         P = self.P
@@ -123,10 +125,20 @@ class _SliceStore:
         return arrays
 
     def ensure_slack(self, slack):
-        """Make full-size block views of up to ``slack`` rows possible (reallocates once)."""
-        if slack > self.slack:
-            self.slack = slack
-            self.reserve(0, exact=True)
+        """Make full-size block views of up to ``slack`` rows possible (reallocates once).
+
+        This is reached from whoever READS the store -- a channel's imager, on a queue and possibly
+        a host thread of its own -- while the copy into the larger arrays runs on the store's queue:
+        the copy is waited for here, so that the reader's stream finds the records there (the first
+        channels of a band imaged concurrently otherwise gridded whatever the new arrays held:
+        nothing, for a weights grid of zeros and a PSF of zeros)."""
+        with self._slack_lock:
+            if slack > self.slack:
+                self.slack = slack
+                before = self.arrays
+                self.reserve(0, exact=True)
+                if self.arrays is not before:
+                    self.queue.finish()
 
     def reserve(self, extra, exact=False):
         need = self.length + extra + self.slack

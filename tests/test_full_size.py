@@ -696,3 +696,119 @@ def test_c2_orders_binned_vs_track_order():
             assert variant == 'mfma'
             assert float((got - ref).abs().max()) <= 1e-5 * peak, (order.__name__, merge)
     fn.locality_hint = None
+
+
+# ---- BASELINE config 3: eight spectral-line channels, one per GPU -- as far as one GPU goes --------
+def test_c3_eight_channels_through_the_sharded_driver():
+    """Config 3 (8 channels, 4096^2, 32 W-planes, K = 28) through `parallel.image_assigned_channels`, the
+    driver a rank of the 8-GPU job runs (channel c on rank c mod world size; frontend.py:749-767 loops
+    channels serially).  With one GPU the world has one rank and it owns all eight channels: they
+    are imaged with four in flight (one host thread and one HIP stream per worker, jobs and imagers
+    made lazily) and every channel's result is held against the same channel imaged on its own, one
+    after the other -- components at the same pixels, fluxes and residual images to the float32
+    tolerance that the gridders' atomics leave.  The channels differ (frequency scaling of uvw,
+    their own sources), so a mix-up between streams would show."""
+    import torch
+    import synth
+    from katsdpimager_amd import accel, frontend, imaging, parallel, parameters, preprocess, weight
+    ctx, q = context_queue()
+    channels, n_in = 8, 1_500_000
+    cp = parameters.CleanParameters(200, 0.1, 0.85, 5.0, 0, 0.01, 0.5, 0.02)
+    wparm = parameters.WeightParameters(weight.WeightType.ROBUST, 0.0)
+    stores, params = [], []
+    for c in range(channels):
+        obs = synth.make_observation(4096, n_in, 32, 1, device=ctx.device, seed=20 + c,
+                                     channel_scale=parallel.channel_frequency_scale(c, channels))
+        synth.add_point_sources(obs, 40, seed=100 + c, noise=0.02)
+        ipd, gpd, apd = synth.make_parameters(obs, 1, 28, degrid=True)
+        # (the inputs stay alive until the collector has read them: its kernels run on the queue's
+        # stream, and memory handed back to torch's allocator before they are done could be given
+        # out again under them)
+        d_uvw = accel.DeviceArray(ctx, (n_in, 3), np.float32, tensor=obs.uvw)
+        d_wts = accel.DeviceArray(ctx, (1, n_in, 1), np.float32, tensor=obs.weights[None].contiguous())
+        d_vis = accel.DeviceArray(ctx, (1, n_in, 1), np.complex64, tensor=obs.raw_vis[None].contiguous())
+        torch.cuda.synchronize()
+        coll = preprocess.VisibilityCollectorDevice(q, [ipd], [gpd], 1 << 20)
+        coll.add(d_uvw, d_wts, d_vis, None, None, np.identity(1, np.complex64), None)
+        coll.close()
+        q.finish()
+        torch.cuda.synchronize()
+        stores.append(coll.reader())
+        params.append((ipd, gpd, apd))
+        del obs, d_uvw, d_wts, d_vis, coll
+    torch.cuda.synchronize()
+    block = max(r.len(0, 0) for r in stores)
+    imagers = {}
+
+    def make_job(channel, worker=0, own_queue=True):
+        # (an imager per channel: the channels' parameters differ -- cell size and wavelength follow
+        # the frequency -- and frontend.process_channel refuses an imager made for others)
+        ipd, gpd, apd = params[channel]
+        key = (channel, own_queue)
+        if key not in imagers:
+            queue = ctx.create_command_queue() if own_queue else q
+            template = imaging.ImagingTemplate(ctx, apd, ipd.fixed, wparm, gpd.fixed, cp)
+            im = template.instantiate(queue, ipd, gpd, block, 0, 2)
+            im.ensure_all_bound()
+            imagers[key] = im
+        return dict(reader=stores[channel], rel_channel=0, imager=imagers[key], image_p=ipd, grid_p=gpd,
+                    clean_p=cp, weight_type=wparm.weight_type, vis_block=block, major=2, degrid=True)
+
+    def summary(job, stats):
+        im = job['imager']
+        comps = {k: float(v[0]) for k, v in im._model_components.items()}
+        return stats, comps, im.get_buffer('dirty')
+
+    # the sharded driver: this rank's share of eight channels (all of them), four in flight
+    got = {}
+
+    # (what a channel's imager holds is read when its worker is done with the channel)
+    orig = frontend.process_channel
+
+    def process_and_read(**kwargs):
+        stats = orig(**kwargs)
+        channel = stores.index(kwargs['reader'])
+        got[channel] = summary(kwargs, stats)
+        return stats
+    frontend.process_channel = process_and_read
+    try:
+        out = parallel.image_assigned_channels(lambda ch, worker: make_job(ch, worker), channels, workers=4)
+    finally:
+        frontend.process_channel = orig
+    assert sorted(out) == list(range(channels)) and sorted(got) == list(range(channels))
+    # every channel on its own, one after the other
+    for c in range(channels):
+        job = make_job(c, 0, own_queue=False)
+        stats = frontend.process_channel(**job)
+        q.finish()
+        want_stats, want_comps, want_dirty = summary(job, stats)
+        got_stats, got_comps, got_dirty = got[c]
+        assert got_stats['psf_patch'] == want_stats['psf_patch'] and got_stats['major'] == want_stats['major'] == 2
+        assert got_stats['minor'] == want_stats['minor']
+        # (1.5 M float32 terms summed in two different orders: 1e-4; the second major cycle starts from
+        # what 200 components of the first left, where the faint ones may differ)
+        np.testing.assert_allclose(got_stats['peaks'][0], want_stats['peaks'][0], rtol=1e-4)
+        np.testing.assert_allclose(got_stats['peaks'], want_stats['peaks'], rtol=1e-2)
+        common = set(got_comps) & set(want_comps)
+        assert len(common) >= 0.9 * max(len(got_comps), len(want_comps)), (c, len(common), len(want_comps))
+        # (the bright ones may not move)
+        brightest = sorted(want_comps, key=lambda k: -abs(want_comps[k]))[:20]
+        assert all(k in got_comps for k in brightest)
+        # (two runs whose peaks differ in the last bits may give the last cycles before the limit to
+        # different sources: a component's flux may differ by a cycle's worth -- the loop gain times
+        # the level the loop has come down to -- not by more)
+        level = min(abs(p) for p in want_stats['peaks'])
+        for k in common:
+            assert abs(got_comps[k] - want_comps[k]) <= 0.11 * level + 3e-4 * abs(want_comps[k]), (c, k)
+        total_got, total_want = sum(got_comps.values()), sum(want_comps.values())
+        assert abs(total_got - total_want) <= 0.01 * abs(total_want)
+        # (the residual is what is left after the components: a few faint ones that resolve
+        # differently between two runs of float atomics are a larger share of it than of the image)
+        assert relerr(got_dirty, want_dirty) < 2e-3
+    # an imager made for another channel's parameters is refused
+    wrong = make_job(1, 0, own_queue=False)
+    wrong['imager'] = imagers[(0, False)]
+    with pytest.raises(ValueError):
+        frontend.process_channel(**wrong)
+    # the channels are not each other's: a different one's components do not fit
+    assert len(set(got[0][1]) & set(got[1][1])) < 0.2 * len(got[0][1])
