@@ -96,7 +96,10 @@ constexpr int MC_MAX_TILES = 2047;      // tiles per axis (11 bits each in a key
 // along (keys of one tile are never compared).  Everything a component needs but its pixel values.
 __device__ inline mkey_t mc_key(float value, int tx, int ty, int yy, int xx)
 {
-    const unsigned lo = (((unsigned) ~((ty << 11) | tx)) & 0x3FFFFFu) << 10 | (unsigned) (yy << 5 | xx);
+    // (the pixel's five bits each way are cut to size: a position that is not its tile's -- tile arrays
+    // somebody else wrote -- must not reach into the tile's bits and send a record to a tile that
+    // does not exist)
+    const unsigned lo = (((unsigned) ~((ty << 11) | tx)) & 0x3FFFFFu) << 10 | (unsigned) ((yy & 31) << 5 | (xx & 31));
     return ((mkey_t) __float_as_uint(value) << 32) | lo;
 }
 
@@ -1146,6 +1149,8 @@ __global__ __launch_bounds__(MC_THREADS) void cycle_multi_kernel(
         if (live && (fullm >> li & 1u)) {
             const mc_cand c = mc_decode(dkey, g.border);
             const int t = c.ty * g.tiles_x + c.tx;
+            if (c.tx >= g.tiles_x || c.ty >= g.tiles_y)
+                return;                 // (no such tile: a record nobody of this call made)
             tile_max[t] = c.value;
             *reinterpret_cast<int2 *>(tile_pos + 2 * t) = make_int2(c.y, c.x);
             *reinterpret_cast<float4 *>(tile_pix + 4 * t) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
