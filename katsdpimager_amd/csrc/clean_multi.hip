@@ -1786,18 +1786,23 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
     // the eight best tiles could take, each at its own peak, before they are down to the ninth -- a
     // field with a few sources far above the rest is worth the repeated-steps kernel from the start.
     __syncthreads();
-    if (tid == 0 && progress) {
+    if (tid < 64 && progress) {
+        // (lane i < 8: the i-th best tile; all of a wave's lanes take part in the sum)
         const int n = st->top_n;
         const float ref = n > MC_MAX ? __uint_as_float((unsigned) (st->top[MC_MAX].key >> 32))
                                      : __uint_as_float((unsigned) (st->top_floor >> 32));
         // (a step takes the value at the peak down by the loop gain; the metric is the value, or its square)
         const float per_step = -logf(fmaxf(1.0f - g.loop_gain, 1e-3f)) * (mode == KIMG_CLEAN_I ? 1.0f : 2.0f);
         float steps = 0.0f;
-        for (int i = 0; i < n && i < MC_MAX; i++) {
-            const float v = __uint_as_float((unsigned) (st->top[i].key >> 32));
+        if (tid < n && tid < MC_MAX) {
+            const float v = __uint_as_float((unsigned) (st->top[tid].key >> 32));
             if (ref > 0.0f && v > ref && per_step > 0.0f)
-                steps += fminf(logf(v / ref) / per_step, 1000.0f);
+                steps = fminf(logf(v / ref) / per_step, 1000.0f);
         }
+        for (int off = 4; off > 0; off >>= 1)
+            steps += __shfl_down(steps, off, WAVE);
+        if (tid != 0)
+            return;
         __hip_atomic_store(progress + 1, (unsigned long long) (unsigned) gen << 32, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
         // (the first component's metric comes later: until then a tag no call has)
