@@ -1040,3 +1040,103 @@ def test_trace_ranges_off_and_on():
                 pass
         trace.disable()
     assert not trace.enabled()
+
+
+class _ShortCutRecorder(_Recorder):
+    """An imager that offers what frontend.process_channel may use beyond the reference's calls."""
+    one_call_major_cycles = True
+    device_psf_stage = True
+
+    def psf_patch_start(self):
+        self.calls.append(('psf_patch_start',))
+        return 'started'
+
+    def psf_patch_finish(self, started):
+        assert started == 'started'
+        self.calls.append(('psf_patch_finish',))
+        return (1, 9, 11), np.array([0.5], np.float32)
+
+    def clean_major_cycles(self, psf_patch, noise_threshold, left_for_next, max_cycles, batcher=None):
+        self.calls.append(('clean_major_cycles', max_cycles, round(float(left_for_next), 6)))
+        # (first peak, cycles done -- the first one included)
+        return self._peaks.pop(0), 1 + min(self._cycles, max_cycles - 1)
+
+
+def test_frontend_driver_short_cuts():
+    """With an imager that offers them the driver scales the PSF by a value that stays on the device,
+    starts the PSF patch's read-back before the first dirty image and looks at it after, and runs a
+    major cycle's minor cycles in one call; what it reports is what the reference's sequence reports."""
+    from katsdpimager_amd import frontend, weight
+    image_p, grid_p, clean_p = _driver_params()
+    im = _ShortCutRecorder(peaks=[1.0, 1.0], cycles_before_threshold=3)
+    out = frontend.process_channel(_DeviceReader([5, 0, 3]), 0, im, image_p, grid_p, clean_p,
+                                   weight.WeightType.UNIFORM, 4, 2, True)
+    names = [c[0] for c in im.calls]
+    # the PSF stage: no read of the central pixel, no psf_patch() with its read-back
+    assert 'psf_patch' not in names and 'scale_dirty' not in names[:names.index('psf_patch_finish')]
+    assert names.index('scale_dirty_by_centre') < names.index('dirty_to_psf') < names.index('psf_patch_start')
+    # ... the first dirty image is gridded before the patch is looked at
+    first_grid_after_psf = [i for i, n in enumerate(names) if n == 'grid' and i > names.index('psf_patch_start')][0]
+    assert first_grid_after_psf < names.index('psf_patch_finish')
+    assert names.index('scale_dirty_by_kept') < names.index('psf_patch_finish')
+    # ... and the later major cycles scale by the value the host now has
+    assert 'scale_dirty' in names[names.index('psf_patch_finish'):]
+    # one call per major cycle, first cycle included; no clean_cycle, no clean_cycles
+    assert names.count('clean_major_cycles') == 2 and 'clean_cycle' not in names and 'clean_cycles' not in names
+    assert [c for c in im.calls if c[0] == 'clean_major_cycles'][0][1:] == (10, 0.15)
+    assert out['psf_patch'] == (1, 9, 11) and out['major'] == 2
+    # 3 cycles after the first found a peak, the next one did not: counted as frontend.py:579-582 does
+    assert out['minor'] == 2 * 4 and out['peaks'] == [1.0, 1.0]
+    np.testing.assert_array_equal(out['scale'], np.array([0.5], np.float32))
+    # the reference's own sequence reports the same
+    ref = _Recorder(peaks=[1.0, 1.0], cycles_before_threshold=3)
+    want = frontend.process_channel(_DeviceReader([5, 0, 3]), 0, ref, image_p, grid_p, clean_p,
+                                    weight.WeightType.UNIFORM, 4, 2, True)
+    assert want['minor'] == out['minor'] and want['major'] == out['major'] and want['peaks'] == out['peaks']
+
+
+def test_process_channel_refuses_an_imager_made_for_other_parameters():
+    import types
+    from katsdpimager_amd import frontend, weight
+    image_p, grid_p, clean_p = _driver_params()
+    im = _Recorder(peaks=[1.0], cycles_before_threshold=1)
+    im.image_parameters = types.SimpleNamespace(wavelength=0.21, fixed=image_p.fixed)
+    im.grid_parameters = grid_p
+    with pytest.raises(ValueError, match='wavelength'):
+        frontend.process_channel(_HostReader([5]), 0, im, image_p, grid_p, clean_p,
+                                 weight.WeightType.UNIFORM, 4, 1, True)
+    im.image_parameters = image_p
+    im.grid_parameters = types.SimpleNamespace(fixed=grid_p.fixed, w_slices=2)
+    with pytest.raises(ValueError, match='w_slices'):
+        frontend.process_channel(_HostReader([5]), 0, im, image_p, grid_p, clean_p,
+                                 weight.WeightType.UNIFORM, 4, 1, True)
+    im.grid_parameters = grid_p
+    assert frontend.process_channel(_HostReader([5]), 0, im, image_p, grid_p, clean_p,
+                                    weight.WeightType.UNIFORM, 4, 1, True) is not None
+
+
+def test_clean_batcher_major_cycles_of_a_channel_on_its_own():
+    """CleanBatcher.run_major_cycles: a channel whose cycles run on their own takes the one call (and
+    the batcher's count of running channels comes back to where it was); one whose cycles share
+    launches is told to run the first cycle itself."""
+    from katsdpimager_amd import clean
+
+    class Solo:
+        template = None
+        calls = []
+
+        def run_major_cycles(self, patch, noise_threshold, left, max_cycles):
+            self.calls.append((patch, max_cycles))
+            return 7, 1.5
+
+    b = clean.CleanBatcher(2)
+    solo = Solo()
+    orig = clean.prefers_solo
+    try:
+        clean.prefers_solo = lambda c, patch, cycles: c is solo
+        assert b.run_major_cycles(solo, (1, 9, 9), 0.1, 0.15, 100) == (7, 1.5)
+        assert solo.calls == [((1, 9, 9), 100)] and b._cleaning == 0
+        assert b.run_major_cycles(object(), (1, 9, 9), 0.1, 0.15, 100) is None
+        assert b.run_major_cycles(solo, (1, 9, 9), 0.1, 0.15, 0) is None
+    finally:
+        clean.prefers_solo = orig
