@@ -1752,17 +1752,49 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
                                                             unsigned long long *progress)
 {
     __shared__ rest_lds sr;
-    __shared__ int s_max;
+    __shared__ int s_tau;
+    __shared__ int s_hist[1024];
+    __shared__ int s_above[MC_THREADS];
     const int tid = threadIdx.x;
     mc_state *st = &scratch->st[0];
     const float *tile_pix = reinterpret_cast<const float *>(scratch + 1);
+    // Where to cut the tile maxima for the first list: the value above which the 128 best tiles lie,
+    // to a quarter of an octave, from one pass (a histogram over the top eleven bits of the float
+    // patterns, which order like the values) -- stepping down from the maximum by a factor 0.7 per
+    // pass took a dozen passes on a field whose first source stands far above the rest.
+    for (int i = tid; i < 1024; i += MC_THREADS)
+        s_hist[i] = 0;
     if (tid == 0)
-        s_max = -1;
+        s_tau = -1;
     __syncthreads();
-    int best = -1;
-    for (int t = tid; t < g.tiles_x * g.tiles_y; t += MC_THREADS)
-        best = max(best, __float_as_int(tile_max[t]));
-    atomicMax(&s_max, best);
+    for (int t = tid; t < g.tiles_x * g.tiles_y; t += MC_THREADS) {
+        const int bits = __float_as_int(tile_max[t]);
+        atomicAdd(&s_hist[min(max(bits, 0) >> 21, 1023)], 1);
+    }
+    __syncthreads();
+    s_above[tid] = s_hist[4 * tid] + s_hist[4 * tid + 1] + s_hist[4 * tid + 2] + s_hist[4 * tid + 3];
+    __syncthreads();
+    for (int d = 1; d < MC_THREADS; d <<= 1) {          // tiles in this thread's bins and above
+        const int v = tid + d < MC_THREADS ? s_above[tid + d] : 0;
+        __syncthreads();
+        s_above[tid] += v;
+        __syncthreads();
+    }
+    {
+        constexpr int WANT = 128;
+        const int higher = tid + 1 < MC_THREADS ? s_above[tid + 1] : 0;
+        if (s_above[tid] >= WANT && higher < WANT) {
+            int acc = higher, bin = 4 * tid;
+            for (int k = 3; k >= 0; k--) {
+                acc += s_hist[4 * tid + k];
+                if (acc >= WANT) {
+                    bin = 4 * tid + k;
+                    break;
+                }
+            }
+            s_tau = (bin << 21) - 1;    // (bin 0: -1, every tile)
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         *reinterpret_cast<int4 *>(st) = make_int4(0, 0, limit, __float_as_int(threshold));
@@ -1780,7 +1812,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_init_kernel(const float *tile_m
 #else
     long long *dbg_v = nullptr;
 #endif
-    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, lower_tau(s_max), 128, INT_MIN / 2,
+    mc_build_rest(tile_max, tile_pos, tile_pix, nullptr, g, s_tau, 1, INT_MIN / 2,
                   INT_MIN / 2, 0, 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f), false, make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), 0, 0, st, sr, dbg_v, 0);
     // What the host starts from (the word of launch 0 carries it in place of a count): how many steps
     // the eight best tiles could take, each at its own peak, before they are down to the ninth -- a
