@@ -1244,10 +1244,10 @@ def major_loop_extras(args, ctx, q, obs, template, ipd, gpd, cp, wparm, reader):
         torch.cuda.synchronize()
         out['four_channels_%d_in_flight_ms' % workers] = round((time.perf_counter() - t0) * 1e3, 2)
         if workers > 1:
-            # the default: the channels take turns at gridding (see the 12-channel stream below)
+            # the channels taking turns at gridding (round 3's default; see the 12-channel stream below)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            frontend.process_channels(jobs, workers=workers)
+            frontend.process_channels(jobs, workers=workers, stagger=True)
             torch.cuda.synchronize()
             out['four_channels_%d_in_flight_turns_ms' % workers] = round(
                 (time.perf_counter() - t0) * 1e3, 2)

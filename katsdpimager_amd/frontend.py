@@ -337,8 +337,8 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
     callback re-uses one imager per ``worker`` index.  With ``batch_clean`` the minor cycles of
     the channels in flight share their launches (see :func:`process_channels`).  ``stagger``: the
     channels in flight take turns at their throughput-bound stages (``clean.CleanBatcher``
-    ``phased``) so that one channel grids while the others CLEAN; None = on for up to four
-    channels in flight.  ``window_cus``: how many CUs the gridder and degridder of the imagers in
+    ``phased``) so that one channel grids while the others CLEAN; None = off (it paid while the
+    channels' cycles shared one-component launches; it costs now that they do not).  ``window_cus``: how many CUs the gridder and degridder of the imagers in
     flight fill while there are several (``Imaging.set_window_cus``: it travels with every
     kimg_grid / kimg_degrid call of those imagers, so two streams in one process -- on the same or
     on different GPUs -- do not see each other's setting; None = 192 of 256, so that the other
@@ -372,9 +372,13 @@ def process_channel_stream(make_job, channels, workers=4, batch_clean=True, stag
     batcher = None
     if batch_clean and count > 1:
         if stagger is None:
-            # measured (12 channels): taking turns wins with 2-4 channels in flight
-            # (11.0 -> 10.2, 8.2 -> 7.3 ms per channel) and loses with 6 (7.5 -> 9.3)
-            stagger = count <= 4
+            # Taking turns won with 2-4 channels in flight while a channel's minor cycles were one
+            # component per launch batched across the channels (round 3: 11.0 -> 10.2, 8.2 -> 7.3 ms
+            # per channel).  With several components per launch the cycles run on their own, wait
+            # for nobody and leave most of the device to whoever grids, and the channels do better
+            # in step (round 4, 12 channels, four in flight: 4.8 ms per channel against 5.9 taking
+            # turns; four channels at once: 20.2 against 23.4 ms): off unless asked for.
+            stagger = False
         batcher = clean.CleanBatcher(count, phased=bool(stagger))
 
     def one(index, channel, worker):
